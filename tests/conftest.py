@@ -1,0 +1,64 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Golden:
+    """One golden case written by tests/golden/make_golden.py (reference outputs)."""
+
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.z = {k: z[k] for k in z.files}
+        self.meta = json.loads(str(self.z["meta"]))
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    @property
+    def static(self):
+        return self.z["static"]
+
+    @property
+    def dyn(self):
+        d = self.z["dyn"]
+        return d if d.size else None
+
+    @property
+    def dist(self):
+        d = self.z["dist"]
+        return d if d.size else None
+
+    def planner_kwargs(self):
+        kw = dict(self.meta["planner"])
+        if self.meta.get("footprint"):
+            kw["footprint_offsets"] = self.meta["footprint_offsets"]
+            kw["footprint_radius"] = self.meta["footprint_radius"]
+        return kw
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    return Golden(request.param)
+
+
+def wrap_angle(a):
+    return (np.asarray(a) + np.pi) % (2 * np.pi) - np.pi

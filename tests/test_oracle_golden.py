@@ -1,0 +1,94 @@
+"""The CPU oracle (oracle/fot_oracle.c) against the reference's outputs.
+
+Pins the oracle: every golden case was produced by importing the reference
+planner (tests/golden/make_golden.py).  No GPU needed.
+"""
+import numpy as np
+import pytest
+
+from conftest import wrap_angle
+from oracle import oracle as orc
+
+FIELDS = orc.PATH_FIELDS
+TOL = 1e-9
+
+
+def _spline(g):
+    return orc.Spline(g["wx"], g["wy"])
+
+
+def _plan(g, table=True):
+    sp = _spline(g)
+    params = orc.make_params(**g.planner_kwargs())
+    m = g.meta
+    ego = orc.make_ego(*m["ego"], last_kappa=m["last_kappa"], prev_s=m["prev_s"])
+    return orc.plan(params, sp, ego, m["target_speed"], m["overrides"], m["max_stop"],
+                    static=g.static, dyn=g.dyn, dist=g.dist, table=table), params, sp
+
+
+def test_spline_coefficients(golden):
+    sp = _spline(golden)
+    s, ax, bx, cx, dx, ay, by, cy, dy = sp.coeffs()
+    for got, key in ((s, "sp_s"), (ax, "sp_ax"), (bx, "sp_bx"), (cx, "sp_cx"), (dx, "sp_dx"),
+                     (ay, "sp_ay"), (by, "sp_by"), (cy, "sp_cy"), (dy, "sp_dy")):
+        np.testing.assert_allclose(got, golden[key], rtol=1e-11, atol=1e-12, err_msg=key)
+
+
+def test_frenet_state(golden):
+    m = golden.meta
+    sp = _spline(golden)
+    ego = orc.make_ego(*m["ego"], last_kappa=m["last_kappa"], prev_s=m["prev_s"])
+    rc, fr, ref, prev_s = orc.cartesian_to_frenet_state(sp, ego)
+    assert rc == 0
+    np.testing.assert_allclose(fr, golden["frenet0"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(ref, golden["ref0"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(prev_s, float(golden["prev_s_after"]), rtol=0, atol=1e-12)
+
+
+def test_candidate_table(golden):
+    out, _, _ = _plan(golden)
+    assert out.n_cand == len(golden["cand_cost"])
+    np.testing.assert_array_equal(out.cand_nt, golden["cand_nt"])
+    np.testing.assert_array_equal(out.cand_keep, golden["cand_keep"])
+    np.testing.assert_allclose(out.cand_cost, golden["cand_cost"], rtol=TOL, atol=TOL)
+    np.testing.assert_array_equal(out.cand_status, golden["cand_status"].astype(np.int32))
+
+
+def test_selection(golden):
+    out, _, _ = _plan(golden, table=False)
+    stats = golden["stats"]
+    want = {orc.STATUS_NAMES[i]: int(stats[i]) for i in range(8) if stats[i] >= 0}
+    assert out.stats == want
+    bi = int(golden["best_index"])
+    assert out.best_index == bi
+    if bi < 0:
+        assert out.status == orc.PLAN_NO_PATH and out.path is None
+        assert out.new_last_kappa == golden.meta["last_kappa"]
+        return
+    assert out.status == orc.PLAN_OK
+    np.testing.assert_allclose(out.cost, float(golden["best_cost"]), rtol=TOL)
+    for f in FIELDS:
+        want_arr = golden["best_" + f]
+        got = out.path[f]
+        assert len(got) == len(want_arr), f
+        if f == "yaw":
+            np.testing.assert_allclose(wrap_angle(got - want_arr), 0.0, atol=TOL)
+        else:
+            np.testing.assert_allclose(got, want_arr, rtol=TOL, atol=TOL, err_msg=f)
+    np.testing.assert_allclose(out.new_last_kappa, float(golden["last_kappa_after"]), rtol=TOL, atol=TOL)
+
+
+def test_probe_paths(golden):
+    params = orc.make_params(**golden.planner_kwargs())
+    sp = _spline(golden)
+    for r, idx in enumerate(golden["probe_idx"]):
+        keep, arr, cost = orc.candidate_path(params, sp, golden["frenet0"], golden.meta["target_speed"], int(idx))
+        assert keep == int(golden["cand_keep"][idx])
+        np.testing.assert_allclose(cost, golden["cand_cost"][idx], rtol=TOL)
+        for fi, f in enumerate(FIELDS):
+            want = golden["probe_" + f][r, :keep]
+            got = arr[fi, :keep]
+            if f == "yaw":
+                np.testing.assert_allclose(wrap_angle(got - want), 0.0, atol=TOL)
+            else:
+                np.testing.assert_allclose(got, want, rtol=TOL, atol=TOL, err_msg=f"{f} cand {idx}")
