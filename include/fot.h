@@ -1,0 +1,193 @@
+/*
+ * fot.h -- C ABI of libfot.so, the MI355X (gfx950) Frenet optimal-trajectory planner.
+ *
+ * Drop-in boundary for ONE hot path of mnhrk15/integrated_path_planning:
+ * FrenetPlanner.plan() (reference src/planning/frenet_planner.py:227-304) and
+ * everything it calls.  The reference is pure Python and has no FFI of its own;
+ * each entry point below names the reference interface it replaces, and
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; every call returns FOT_OK (0)
+ *     or a negative FOT_ERR_*; fot_last_error(h) has the message.
+ *   - "no feasible trajectory" is NOT an error: fot_result.status says so
+ *     (the reference returns None, frenet_planner.py:294-304).
+ *   - the caller owns every buffer it passes; the library neither keeps nor
+ *     modifies inputs (reference: integrated_simulator.py:698 passes copies).
+ *   - one handle = one GPU + one stream + its own workspace.  Handles share no
+ *     state, so one handle per host thread / per rank is safe; a single handle
+ *     is not thread-safe (the reference planner is not either: it carries
+ *     _last_kappa and converter._prev_s, frenet_planner.py:218, coordinate_converter.py:283;
+ *     here that state is explicit in fot_ego / fot_result).
+ *   - all arithmetic that decides a candidate's status is float64, like the reference.
+ */
+#ifndef FOT_H
+#define FOT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOT_MAX_NT 64        /* samples per candidate: round(max_t/dt)+1 must be <= 64 */
+#define FOT_MAX_CIRCLES 8    /* ego footprint circles (footprint.py:26) */
+#define FOT_MAX_TI 32        /* time horizons  int((max_t-min_t)/dt)+1 */
+#define FOT_MAX_TV 32        /* terminal speeds per horizon */
+#define FOT_MAX_BRAKE 16     /* brake-ladder entries (frenet_planner.py:475) */
+#define FOT_MAX_SAMPLES 64   /* prediction samples S of a distribution */
+
+/* error codes */
+#define FOT_OK 0
+#define FOT_ERR_INVALID (-1)      /* bad argument */
+#define FOT_ERR_UNSUPPORTED (-2)  /* configuration exceeds a FOT_MAX_* limit */
+#define FOT_ERR_HIP (-3)          /* HIP runtime failure (no device, out of memory, ...) */
+#define FOT_ERR_NO_PATH_SET (-4)  /* fot_set_path_* not called yet */
+
+/* candidate status == index into fot_result.stats[]; order of the reference's
+ * last_check_stats dict (frenet_planner.py:910-918, 324) */
+enum {
+    FOT_ST_SPEED = 0, FOT_ST_ACCEL = 1, FOT_ST_CURVATURE = 2, FOT_ST_LAT_ACCEL = 3,
+    FOT_ST_ROAD = 4, FOT_ST_COLLISION = 5, FOT_ST_OK = 6, FOT_ST_STOP_DISTANCE = 7,
+    FOT_ST_DROPPED = 8           /* silently dropped, not counted (frenet_planner.py:933-956) */
+};
+
+/* fot_result.status */
+enum {
+    FOT_PLAN_OK = 0,             /* a path was selected */
+    FOT_PLAN_NO_PATH = 1,        /* plan() would return None after the checks */
+    FOT_PLAN_C2F_FAILED = 2      /* plan() would return None at frenet_planner.py:266-268 */
+};
+
+/* obstacle element type */
+enum { FOT_F32 = 0, FOT_F64 = 1 };
+/* fot_batch.dyn_dims[i][0] */
+enum { FOT_DYN_NONE = 0, FOT_DYN_SINGLE = 1, FOT_DYN_DISTRIBUTION = 2 };
+
+/* replaces the constructor arguments of FrenetPlanner (frenet_planner.py:149-210) */
+typedef struct fot_params {
+    double max_speed, max_accel, max_curvature, max_lat_accel;
+    double dt, d_road_w, max_road_width;
+    double robot_radius, obstacle_radius;
+    double min_t, max_t, d_t_s;
+    double k_j, k_t, k_d, k_s_dot, k_lat, k_lon;
+    double chance_epsilon, collision_margin_inflation;
+    int32_t n_circles;           /* 0: single circle of robot_radius; else EgoFootprint (footprint.py:14-45) */
+    int32_t _pad;
+    double footprint_radius;
+    double footprint_offsets[FOT_MAX_CIRCLES];
+} fot_params;
+
+/* replaces EgoVehicleState (data_structures.py:32-51) + the planner's cross-call state */
+typedef struct fot_ego {
+    double x, y, yaw, v, a;
+    double last_kappa;           /* FrenetPlanner._last_kappa */
+    double prev_s;               /* CoordinateConverter._prev_s */
+    int32_t has_prev_s;          /* 0: first call (global nearest-point search) */
+    int32_t _pad;
+} fot_ego;
+
+/* replaces constraint_overrides (frenet_planner.py:921-930); NaN = key absent */
+typedef struct fot_overrides {
+    double max_speed, max_accel, max_curvature, max_lat_accel;
+} fot_overrides;
+
+/* replaces the returned FrenetPath (data_structures.py:149-220) + last_check_stats + state updates */
+typedef struct fot_result {
+    int32_t status;              /* FOT_PLAN_* */
+    int32_t best_index;          /* candidate index in generation order (Ti -> tv -> di, brake ladder last); -1 */
+    int32_t n_cand;              /* candidates generated */
+    int32_t n_keep;              /* samples in the path arrays below */
+    double cost;
+    int32_t stats[8];            /* last_check_stats, FOT_ST_* order */
+    int32_t stats_valid;         /* 0 when the reference leaves last_check_stats = None */
+    int32_t _pad;
+    double new_last_kappa;       /* value of _last_kappa after the call */
+    double new_prev_s;           /* value of converter._prev_s after the call */
+    double frenet0[6];           /* s, s_d, s_dd, d, d_d, d_dd of the ego (frenet_planner.py:371) */
+    double ref0[6];              /* rs, rx, ry, rtheta, rkappa, rdkappa (coordinate_converter.py:308) */
+    double t[FOT_MAX_NT], s[FOT_MAX_NT], s_d[FOT_MAX_NT], s_dd[FOT_MAX_NT], s_ddd[FOT_MAX_NT];
+    double d[FOT_MAX_NT], d_d[FOT_MAX_NT], d_dd[FOT_MAX_NT], d_ddd[FOT_MAX_NT];
+    double x[FOT_MAX_NT], y[FOT_MAX_NT], yaw[FOT_MAX_NT], v[FOT_MAX_NT], a[FOT_MAX_NT], c[FOT_MAX_NT];
+} fot_result;
+
+/* One batch of independent ego/scenario instances = the arguments of n_inst
+ * plan() calls (frenet_planner.py:227-236).  The small per-instance arrays and
+ * the shape metadata are ALWAYS host memory; the obstacle coordinates (and the
+ * results) are host memory for fot_plan_batch and device memory for
+ * fot_plan_batch_device. */
+typedef struct fot_batch {
+    int32_t n_inst;
+    int32_t obstacle_dtype;              /* FOT_F32 | FOT_F64 */
+    const fot_ego *ego;                  /* [n_inst] host */
+    const double *target_speed;          /* [n_inst] host */
+    const fot_overrides *overrides;      /* [n_inst] host, or NULL */
+    const double *max_stop_distance;     /* [n_inst] host, NaN = None; or NULL */
+    /* static_obstacles [Ns,2] per instance, concatenated; instance i owns points [static_off[i], static_off[i+1]) */
+    const void *static_xy;               /* host | device */
+    const int32_t *static_off;           /* [n_inst+1] host, or NULL (no static obstacles) */
+    /* dynamic_obstacles [P,T,2] / dynamic_obstacles_distribution [S,P,T,2] per instance, concatenated;
+     * instance i starts at point dyn_off[i]; dyn_dims[i] = {mode, S, P, T} (S = 1 for FOT_DYN_SINGLE) */
+    const void *dyn_xy;                  /* host | device */
+    const int64_t *dyn_off;              /* [n_inst] host, or NULL (no dynamic obstacles) */
+    const int32_t *dyn_dims;             /* [n_inst][4] host */
+} fot_batch;
+
+typedef struct fot_handle fot_handle;
+
+const char *fot_version(void);
+
+/* FrenetPlanner.__init__ (frenet_planner.py:149-225).  device < 0: current device. */
+int fot_create(const fot_params *params, int device, fot_handle **out);
+void fot_destroy(fot_handle *h);
+const char *fot_last_error(const fot_handle *h);   /* h may be NULL: error of the last failed fot_create */
+
+/* reference_path: CubicSpline2D(waypoints) (cubic_spline.py:190-213) built natively ... */
+int fot_set_path_waypoints(fot_handle *h, int32_t n, const double *wx, const double *wy);
+/* ... or adopted verbatim from an existing CubicSpline2D object: knots s[n] and the
+ * CubicSpline1D coefficient arrays a[n], b[n-1], c[n], d[n-1] of sx and sy (cubic_spline.py:30-45) */
+int fot_set_path_coeffs(fot_handle *h, int32_t n, const double *s,
+                        const double *ax, const double *bx, const double *cx, const double *dx,
+                        const double *ay, const double *by, const double *cy, const double *dy);
+/* read the spline back (same array sizes); n_out receives the knot count; arrays may be NULL */
+int fot_get_path_coeffs(const fot_handle *h, int32_t *n_out, double *s,
+                        double *ax, double *bx, double *cx, double *dx,
+                        double *ay, double *by, double *cy, double *dy);
+/* CubicSpline2D.calc_position/calc_yaw/calc_curvature/calc_curvature_rate (cubic_spline.py:215-288)
+ * evaluated on the device; NaN outside the domain.  Host arrays of n doubles. */
+int fot_spline_eval(fot_handle *h, int32_t n, const double *s, double *x, double *y,
+                    double *yaw, double *kappa, double *dkappa);
+
+/* n_inst x FrenetPlanner.plan() with host-resident obstacles and results; synchronous */
+int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out);
+/* same with device-resident obstacle coordinates and a device-resident fot_result[n_inst];
+ * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream) and NOT synchronised */
+int fot_plan_batch_device(fot_handle *h, const fot_batch *batch, fot_result *out_dev, void *stream);
+/* block until everything the handle enqueued on its own stream has finished */
+int fot_synchronize(fot_handle *h);
+
+/* FrenetPlanner._cartesian_to_frenet_state (frenet_planner.py:334-374) for n egos.
+ * frenet[n][6], ref[n][6], new_prev_s[n], ok[n] (1 = converted) -- host arrays */
+int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
+                           double *frenet, double *ref, double *new_prev_s, int32_t *ok);
+
+/* Per-candidate table of instance `inst` of the most recent plan call on this handle
+ * (what _check_paths put in each list, frenet_planner.py:932-991).  Arrays of `cap`
+ * entries, any may be NULL; returns the number of candidates or a negative error. */
+int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
+                         int32_t *status, int32_t *keep, int32_t *n_t);
+
+/* FrenetPlanner._path_is_collision_free (frenet_planner.py:1035-1233) for n_paths externally
+ * supplied paths against ONE obstacle set.  x, y, yaw, t: [n_paths][FOT_MAX_NT] host, len[n_paths];
+ * static_xy [n_static][2] double host; dyn [S][P][T][2] double host with mode as in dyn_dims.
+ * free_out[n_paths]: 1 = collision free. */
+int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len,
+                              const double *x, const double *y, const double *yaw, const double *t,
+                              int32_t n_static, const double *static_xy,
+                              int32_t mode, int32_t S, int32_t P, int32_t T, const double *dyn,
+                              int32_t *free_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOT_H */

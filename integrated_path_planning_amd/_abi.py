@@ -1,0 +1,132 @@
+"""ctypes mirror of include/fot.h and the loader of libfot.so.
+
+The library is the product: if it is missing or cannot be loaded this module
+raises -- there is no Python or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_NT = 64
+MAX_CIRCLES = 8
+MAX_SAMPLES = 64
+
+OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_PATH_SET = -1, -2, -3, -4
+ST_SPEED, ST_ACCEL, ST_CURVATURE, ST_LAT_ACCEL, ST_ROAD, ST_COLLISION, ST_OK, ST_STOP_DISTANCE, ST_DROPPED = range(9)
+PLAN_OK, PLAN_NO_PATH, PLAN_C2F_FAILED = 0, 1, 2
+F32, F64 = 0, 1
+DYN_NONE, DYN_SINGLE, DYN_DISTRIBUTION = 0, 1, 2
+
+# reference's last_check_stats keys in fot_result.stats[] order (frenet_planner.py:910-918, 324)
+STATUS_NAMES = ["max_speed_error", "max_accel_error", "max_curvature_error", "max_lat_accel_error",
+                "road_bound_error", "collision_error", "ok", "stop_distance_error"]
+# FrenetPath fields in fot_result order (data_structures.py:164-178)
+PATH_FIELDS = ["t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd", "x", "y", "yaw", "v", "a", "c"]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("max_speed", C.c_double), ("max_accel", C.c_double), ("max_curvature", C.c_double),
+        ("max_lat_accel", C.c_double),
+        ("dt", C.c_double), ("d_road_w", C.c_double), ("max_road_width", C.c_double),
+        ("robot_radius", C.c_double), ("obstacle_radius", C.c_double),
+        ("min_t", C.c_double), ("max_t", C.c_double), ("d_t_s", C.c_double),
+        ("k_j", C.c_double), ("k_t", C.c_double), ("k_d", C.c_double), ("k_s_dot", C.c_double),
+        ("k_lat", C.c_double), ("k_lon", C.c_double),
+        ("chance_epsilon", C.c_double), ("collision_margin_inflation", C.c_double),
+        ("n_circles", C.c_int32), ("_pad", C.c_int32),
+        ("footprint_radius", C.c_double),
+        ("footprint_offsets", C.c_double * MAX_CIRCLES),
+    ]
+
+
+class Ego(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("yaw", C.c_double), ("v", C.c_double),
+                ("a", C.c_double), ("last_kappa", C.c_double), ("prev_s", C.c_double),
+                ("has_prev_s", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Overrides(C.Structure):
+    _fields_ = [("max_speed", C.c_double), ("max_accel", C.c_double),
+                ("max_curvature", C.c_double), ("max_lat_accel", C.c_double)]
+
+
+_ARR = C.c_double * MAX_NT
+
+
+class Result(C.Structure):
+    _fields_ = ([("status", C.c_int32), ("best_index", C.c_int32), ("n_cand", C.c_int32), ("n_keep", C.c_int32),
+                 ("cost", C.c_double), ("stats", C.c_int32 * 8), ("stats_valid", C.c_int32), ("_pad", C.c_int32),
+                 ("new_last_kappa", C.c_double), ("new_prev_s", C.c_double),
+                 ("frenet0", C.c_double * 6), ("ref0", C.c_double * 6)]
+                + [(f, _ARR) for f in PATH_FIELDS])
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_inst", C.c_int32), ("obstacle_dtype", C.c_int32),
+                ("ego", C.POINTER(Ego)), ("target_speed", C.POINTER(C.c_double)),
+                ("overrides", C.POINTER(Overrides)), ("max_stop_distance", C.POINTER(C.c_double)),
+                ("static_xy", C.c_void_p), ("static_off", C.POINTER(C.c_int32)),
+                ("dyn_xy", C.c_void_p), ("dyn_off", C.POINTER(C.c_int64)), ("dyn_dims", C.POINTER(C.c_int32))]
+
+
+RESULT_BYTES = C.sizeof(Result)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfot.so")
+
+# every symbol include/fot.h declares
+SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_set_path_waypoints",
+           "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
+           "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
+           "fot_check_collision_paths"]
+
+_lib = None
+
+
+class FotError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfot error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libfot.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.fot_version.restype = C.c_char_p
+    L.fot_last_error.restype = C.c_char_p
+    L.fot_last_error.argtypes = [vp]
+    L.fot_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp)]
+    L.fot_destroy.argtypes = [vp]
+    L.fot_destroy.restype = None
+    L.fot_set_path_waypoints.argtypes = [vp, C.c_int32, dp, dp]
+    L.fot_set_path_coeffs.argtypes = [vp, C.c_int32] + [dp] * 9
+    L.fot_get_path_coeffs.argtypes = [vp, ip] + [dp] * 9
+    L.fot_spline_eval.argtypes = [vp, C.c_int32] + [dp] * 6
+    L.fot_plan_batch.argtypes = [vp, C.POINTER(Batch), C.POINTER(Result)]
+    L.fot_plan_batch_device.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    L.fot_synchronize.argtypes = [vp]
+    L.fot_frenet_state_batch.argtypes = [vp, C.c_int32, C.POINTER(Ego), dp, dp, dp, ip]
+    L.fot_debug_candidates.argtypes = [vp, C.c_int32, C.c_int32, dp, ip, ip, ip]
+    L.fot_check_collision_paths.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, C.c_int32, dp,
+                                            C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip]
+    _lib = L
+    return L
+
+
+def check(handle, rc):
+    if rc != OK:
+        msg = lib().fot_last_error(handle)
+        raise FotError(rc, msg.decode() if msg else "")

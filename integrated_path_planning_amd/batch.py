@@ -1,0 +1,121 @@
+"""Packing of independent ego/scenario instances into one ``fot_batch`` (include/fot.h).
+
+One instance = the arguments of one ``FrenetPlanner.plan()`` call of the
+reference (frenet_planner.py:227-236).  Obstacle tensors of all instances are
+concatenated; shapes travel as host metadata.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+
+@dataclass
+class PlanRequest:
+    """Arguments of one plan() call plus the planner's cross-call state."""
+    x: float
+    y: float
+    yaw: float
+    v: float
+    a: float
+    target_speed: float = 30.0 / 3.6
+    last_kappa: float = 0.0
+    prev_s: Optional[float] = None
+    overrides: Optional[dict] = None
+    max_stop_distance: Optional[float] = None
+    static: Optional[np.ndarray] = None          # [Ns, 2]
+    dyn: Optional[np.ndarray] = None             # [P, T, 2]
+    dist: Optional[np.ndarray] = None            # [S, P, T, 2]
+
+
+def _dyn_of(req: PlanRequest):
+    """Which dynamic tensor plan() would use (frenet_planner.py:1043-1047, 1205-1208)."""
+    if req.dist is not None and np.size(req.dist) > 0:
+        d = np.asarray(req.dist)
+        if d.ndim != 4 or d.shape[-1] != 2:
+            raise ValueError(f"distribution must be [S, P, T, 2], got {d.shape}")
+        return _abi.DYN_DISTRIBUTION, d
+    if req.dyn is not None and np.size(req.dyn) > 0 and np.shape(req.dyn)[-1] == 2:
+        d = np.asarray(req.dyn)
+        if d.ndim != 3:
+            raise ValueError(f"dynamic obstacles must be [P, T, 2], got {d.shape}")
+        return _abi.DYN_SINGLE, d[None]
+    return _abi.DYN_NONE, None
+
+
+class PackedBatch:
+    """Host-side ``fot_batch`` with the NumPy buffers that back its pointers."""
+
+    def __init__(self, requests: Sequence[PlanRequest], obstacle_dtype=np.float64):
+        n = len(requests)
+        self.n = n
+        self.np_dtype = np.dtype(obstacle_dtype)
+        if self.np_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("obstacle_dtype must be float32 or float64")
+        self.ego = (_abi.Ego * max(n, 1))()
+        self.target = np.zeros(max(n, 1), dtype=np.float64)
+        self.overrides = (_abi.Overrides * max(n, 1))()
+        self.max_stop = np.full(max(n, 1), np.nan, dtype=np.float64)
+        self.static_off = np.zeros(n + 1, dtype=np.int32)
+        self.dyn_off = np.zeros(max(n, 1), dtype=np.int64)
+        self.dyn_dims = np.zeros((max(n, 1), 4), dtype=np.int32)
+        statics: List[np.ndarray] = []
+        dyns: List[np.ndarray] = []
+        dyn_cursor = 0
+        nan = float("nan")
+        for i, r in enumerate(requests):
+            e = self.ego[i]
+            e.x, e.y, e.yaw, e.v, e.a = float(r.x), float(r.y), float(r.yaw), float(r.v), float(r.a)
+            e.last_kappa = float(r.last_kappa)
+            e.has_prev_s = 0 if r.prev_s is None else 1
+            e.prev_s = 0.0 if r.prev_s is None else float(r.prev_s)
+            self.target[i] = float(r.target_speed)
+            ov = r.overrides or {}
+            o = self.overrides[i]
+            o.max_speed = float(ov.get("max_speed", nan))
+            o.max_accel = float(ov.get("max_accel", nan))
+            o.max_curvature = float(ov.get("max_curvature", nan))
+            o.max_lat_accel = float(ov.get("max_lat_accel", nan))
+            if r.max_stop_distance is not None:
+                self.max_stop[i] = float(r.max_stop_distance)
+            st = np.empty((0, 2)) if r.static is None or len(r.static) == 0 else np.asarray(r.static).reshape(-1, 2)
+            statics.append(st.astype(self.np_dtype, copy=False))
+            self.static_off[i + 1] = self.static_off[i] + st.shape[0]
+            mode, d = _dyn_of(r)
+            self.dyn_off[i] = dyn_cursor
+            if mode != _abi.DYN_NONE:
+                S, P, T = d.shape[0], d.shape[1], d.shape[2]
+                self.dyn_dims[i] = (mode, S, P, T)
+                dyns.append(np.ascontiguousarray(d, dtype=self.np_dtype).reshape(-1, 2))
+                dyn_cursor += S * P * T
+        self.static_xy = (np.concatenate(statics, axis=0) if statics else np.empty((0, 2))).astype(self.np_dtype)
+        self.static_xy = np.ascontiguousarray(self.static_xy)
+        self.dyn_xy = np.ascontiguousarray(np.concatenate(dyns, axis=0) if dyns else np.empty((0, 2), self.np_dtype))
+        self.n_candidates_hint = None
+        self.c = self._make_struct(self.static_xy.ctypes.data if self.static_xy.size else None,
+                                   self.dyn_xy.ctypes.data if self.dyn_xy.size else None)
+
+    def _make_struct(self, static_ptr, dyn_ptr) -> _abi.Batch:
+        b = _abi.Batch()
+        b.n_inst = self.n
+        b.obstacle_dtype = _abi.F32 if self.np_dtype == np.dtype(np.float32) else _abi.F64
+        b.ego = C.cast(self.ego, C.POINTER(_abi.Ego))
+        b.target_speed = self.target.ctypes.data_as(C.POINTER(C.c_double))
+        b.overrides = C.cast(self.overrides, C.POINTER(_abi.Overrides))
+        b.max_stop_distance = self.max_stop.ctypes.data_as(C.POINTER(C.c_double))
+        b.static_xy = static_ptr
+        b.static_off = self.static_off.ctypes.data_as(C.POINTER(C.c_int32)) if static_ptr else None
+        b.dyn_xy = dyn_ptr
+        b.dyn_off = self.dyn_off.ctypes.data_as(C.POINTER(C.c_int64)) if dyn_ptr else None
+        b.dyn_dims = self.dyn_dims.ctypes.data_as(C.POINTER(C.c_int32)) if dyn_ptr else None
+        return b
+
+    def with_device_obstacles(self, static_dev_ptr: Optional[int], dyn_dev_ptr: Optional[int]) -> _abi.Batch:
+        """Same batch with the obstacle coordinates already resident in HBM."""
+        return self._make_struct(static_dev_ptr if self.static_xy.size else None,
+                                 dyn_dev_ptr if self.dyn_xy.size else None)

@@ -1,0 +1,497 @@
+// fot_host.cpp -- the C ABI of libfot.so (include/fot.h): handle, device workspace, batch staging.
+// No torch, no oracle, no CPU fallback: every entry point drives the gfx950 kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fot_kernels.h"
+#include "fot_setup.hpp"
+
+using namespace fot;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct fot_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t staging_done = nullptr;       // the pinned staging buffer may be overwritten after this
+    bool staging_pending = false;
+    fot_params params;
+    DevParams P;
+    DevBuf dP;
+    HostSpline spline;
+    DevBuf dSpline;
+    bool has_path = false;
+    // workspace
+    PinnedBuf staging;
+    DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
+    DevBuf dState, dLonInfo, dLonTab;
+    DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dPts;
+    DevBuf dStat, dRows;                     // prepared obstacles
+    DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
+    DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
+    BatchLayout last;                        // layout of the most recent plan call
+    bool last_valid = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(fot_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(fot_handle *h, hipError_t e, const char *what)
+{
+    return fail(h, FOT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail((h), e_, #expr); } while (0)
+#define LAUNCH_TRY(h, expr) do { int r_ = (expr); if (r_ != 0) return hip_fail((h), (hipError_t)r_, #expr); } while (0)
+
+SplineView spline_view(const fot_handle *h)
+{
+    SplineView v;
+    const double *b = h->dSpline.as<double>();
+    const int n = h->spline.n;
+    v.s = b; v.ax = b + n; v.bx = b + 2 * n; v.cx = b + 3 * n; v.dx = b + 4 * n;
+    v.ay = b + 5 * n; v.by = b + 6 * n; v.cy = b + 7 * n; v.dy = b + 8 * n;
+    v.n = n; v._pad = 0;
+    return v;
+}
+
+int upload_spline(fot_handle *h)
+{
+    const int n = h->spline.n;
+    std::vector<double> flat((size_t)9 * n, 0.0);
+    const std::vector<double> *src[9] = { &h->spline.s, &h->spline.ax, &h->spline.bx, &h->spline.cx, &h->spline.dx,
+                                          &h->spline.ay, &h->spline.by, &h->spline.cy, &h->spline.dy };
+    for (int f = 0; f < 9; ++f)
+        std::memcpy(flat.data() + (size_t)f * n, src[f]->data(), sizeof(double) * std::min((size_t)n, src[f]->size()));
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, h->dSpline.ensure(flat.size() * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->dSpline.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->has_path = true;
+    h->last_valid = false;
+    return FOT_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Stage descriptors, size the workspace and enqueue the whole pipeline on `st`.
+// d_static / d_dyn are device pointers to the caller's obstacle coordinates, d_out a device fot_result[n_inst].
+int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
+                 hipStream_t st)
+{
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    BatchLayout &L = h->last;
+    h->last_valid = false;
+    std::string err;
+    int rc = build_batch_layout(h->params, h->P, b, L, err);
+    if (rc != FOT_OK) return fail(h, rc, err);
+    if (L.n_inst == 0) { h->last_valid = true; return FOT_OK; }
+    if (!d_out) return fail(h, FOT_ERR_INVALID, "out is NULL");
+
+    HIP_TRY(h, hipSetDevice(h->device));
+    // --- staging: descriptors + wave maps in one pinned block, one H2D copy
+    const size_t desc_bytes = align256(sizeof(InstDesc) * (size_t)L.n_inst);
+    const size_t map_bytes = align256(sizeof(int32_t) * (size_t)L.n_waves);
+    const size_t meta_bytes = desc_bytes + 2 * map_bytes;
+    if (h->staging_pending) { HIP_TRY(h, hipEventSynchronize(h->staging_done)); h->staging_pending = false; }
+    HIP_TRY(h, h->staging.ensure(meta_bytes));
+    char *stg = (char *)h->staging.p;
+    std::memcpy(stg, L.desc.data(), sizeof(InstDesc) * (size_t)L.n_inst);
+    std::memcpy(stg + desc_bytes, L.wave_inst.data(), sizeof(int32_t) * (size_t)L.n_waves);
+    std::memcpy(stg + desc_bytes + map_bytes, L.wave_base.data(), sizeof(int32_t) * (size_t)L.n_waves);
+
+    // --- workspace (grow-only; a growing hipFree/hipMalloc synchronises, steady state does not)
+    const DevParams &P = h->P;
+    HIP_TRY(h, h->dMeta.ensure(meta_bytes));
+    HIP_TRY(h, h->dState.ensure(sizeof(InstState) * (size_t)L.n_inst));
+    HIP_TRY(h, h->dLonInfo.ensure(sizeof(LonInfo) * (size_t)std::max<int64_t>(L.n_lon, 1)));
+    HIP_TRY(h, h->dLonTab.ensure(sizeof(double) * LON_FIELDS * FOT_MAX_NT * (size_t)std::max<int64_t>(L.n_lon, 1)));
+    const size_t slots = (size_t)std::max<int64_t>(L.n_slots, 1);
+    HIP_TRY(h, h->dCost.ensure(sizeof(double) * slots));
+    HIP_TRY(h, h->dVlast.ensure(sizeof(double) * slots));
+    HIP_TRY(h, h->dTravel.ensure(sizeof(double) * slots));
+    HIP_TRY(h, h->dStatus.ensure(slots));
+    HIP_TRY(h, h->dKeep.ensure(slots));
+    HIP_TRY(h, h->dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
+    HIP_TRY(h, h->dStat.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_static, 1)));
+    HIP_TRY(h, h->dRows.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_dyn_points, 1)));
+
+    HIP_TRY(h, hipMemcpyAsync(h->dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipEventRecord(h->staging_done, st));
+    h->staging_pending = true;
+    HIP_TRY(h, hipMemsetAsync(d_out, 0, sizeof(fot_result) * (size_t)L.n_inst, st));
+
+    const InstDesc *d_desc = (const InstDesc *)h->dMeta.p;
+    const int32_t *d_wave_inst = (const int32_t *)((char *)h->dMeta.p + desc_bytes);
+    const int32_t *d_wave_base = (const int32_t *)((char *)h->dMeta.p + desc_bytes + map_bytes);
+    const DevParams *dP = h->dP.as<DevParams>();
+    const SplineView sv = spline_view(h);
+    CandArrays ca;
+    ca.cost = h->dCost.as<double>(); ca.v_last = h->dVlast.as<double>(); ca.travel = h->dTravel.as<double>();
+    ca.status = h->dStatus.as<uint8_t>(); ca.keep = h->dKeep.as<uint8_t>();
+
+    LAUNCH_TRY(h, launch_prep_static(d_static, b.obstacle_dtype, h->dStat.as<d2>(), L.n_static, st));
+    LAUNCH_TRY(h, launch_prep_dyn(d_desc, L.n_inst, L.max_dyn_points, d_dyn, b.obstacle_dtype, h->dRows.as<d2>(), st));
+    LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, h->dState.as<InstState>(), L.n_inst, st));
+    LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
+                                   h->dLonTab.as<double>(), L.n_inst, L.max_lon, st));
+    LAUNCH_TRY(h, launch_evaluate(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
+                                  h->dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
+                                  h->dPts.as<d2>(), st));
+    if (L.n_static > 0 || L.n_dyn_points > 0)
+        LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, h->dStat.as<d2>(),
+                                     h->dRows.as<d2>(), h->dPts.as<d2>(), ca, st));
+    LAUNCH_TRY(h, launch_select(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
+                                h->dLonTab.as<double>(), ca, d_out, L.n_inst, st));
+    h->last_valid = true;
+    return FOT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fot_version(void) { return "libfot 0.1 (gfx950, float64 lattice)"; }
+
+const char *fot_last_error(const fot_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fot_create(const fot_params *params, int device, fot_handle **out)
+{
+    if (!params || !out) return fail(nullptr, FOT_ERR_INVALID, "params/out is NULL");
+    *out = nullptr;
+    DevParams P;
+    std::string err;
+    int rc = build_dev_params(*params, P, err);
+    if (rc != FOT_OK) return fail(nullptr, rc, err);
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, FOT_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0) { e = hipGetDevice(&device); if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDevice"); }
+    if (device >= n_dev) return fail(nullptr, FOT_ERR_INVALID, "device index out of range");
+    fot_handle *h = new (std::nothrow) fot_handle();
+    if (!h) return fail(nullptr, FOT_ERR_HIP, "out of host memory");
+    h->device = device;
+    h->params = *params;
+    h->P = P;
+    auto bail = [&](hipError_t ee, const char *what) {
+        int r = hip_fail(nullptr, ee, what);
+        fot_destroy(h);
+        return r;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&h->staging_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemcpy(h->dP.p, &h->P, sizeof(DevParams), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    *out = h;
+    return FOT_OK;
+}
+
+void fot_destroy(fot_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dMeta, &h->dState, &h->dLonInfo, &h->dLonTab, &h->dCost, &h->dVlast,
+                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dPts, &h->dStat, &h->dRows, &h->dUserStatic,
+                       &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
+    for (DevBuf *b : bufs) b->release();
+    h->staging.release();
+    if (h->staging_done) (void)hipEventDestroy(h->staging_done);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int fot_set_path_waypoints(fot_handle *h, int32_t n, const double *wx, const double *wy)
+{
+    if (!h) return FOT_ERR_INVALID;
+    std::string err;
+    HostSpline sp;
+    int rc = build_spline(n, wx, wy, sp, err);
+    if (rc != FOT_OK) return fail(h, rc, err);
+    h->spline = sp;
+    return upload_spline(h);
+}
+
+int fot_set_path_coeffs(fot_handle *h, int32_t n, const double *s,
+                        const double *ax, const double *bx, const double *cx, const double *dx,
+                        const double *ay, const double *by, const double *cy, const double *dy)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n < 2 || !s || !ax || !bx || !cx || !dx || !ay || !by || !cy || !dy)
+        return fail(h, FOT_ERR_INVALID, "spline needs >= 2 knots and all nine coefficient arrays");
+    HostSpline &sp = h->spline;
+    sp.n = n;
+    sp.s.assign(s, s + n);
+    sp.ax.assign(ax, ax + n); sp.bx.assign(bx, bx + n - 1); sp.cx.assign(cx, cx + n); sp.dx.assign(dx, dx + n - 1);
+    sp.ay.assign(ay, ay + n); sp.by.assign(by, by + n - 1); sp.cy.assign(cy, cy + n); sp.dy.assign(dy, dy + n - 1);
+    sp.bx.resize(n, 0.0); sp.dx.resize(n, 0.0); sp.by.resize(n, 0.0); sp.dy.resize(n, 0.0);
+    return upload_spline(h);
+}
+
+int fot_get_path_coeffs(const fot_handle *h, int32_t *n_out, double *s,
+                        double *ax, double *bx, double *cx, double *dx,
+                        double *ay, double *by, double *cy, double *dy)
+{
+    if (!h || !h->has_path) return FOT_ERR_NO_PATH_SET;
+    const HostSpline &sp = h->spline;
+    const int n = sp.n;
+    if (n_out) *n_out = n;
+    auto cp = [](double *dst, const std::vector<double> &src, int cnt) {
+        if (dst) std::memcpy(dst, src.data(), sizeof(double) * (size_t)cnt);
+    };
+    cp(s, sp.s, n);
+    cp(ax, sp.ax, n); cp(bx, sp.bx, n - 1); cp(cx, sp.cx, n); cp(dx, sp.dx, n - 1);
+    cp(ay, sp.ay, n); cp(by, sp.by, n - 1); cp(cy, sp.cy, n); cp(dy, sp.dy, n - 1);
+    return FOT_OK;
+}
+
+int fot_spline_eval(fot_handle *h, int32_t n, const double *s, double *x, double *y,
+                    double *yaw, double *kappa, double *dkappa)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    if (n <= 0) return FOT_OK;
+    if (!s) return fail(h, FOT_ERR_INVALID, "s is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->dTmpA.ensure(sizeof(double) * (size_t)n));
+    HIP_TRY(h, h->dTmpB.ensure(sizeof(double) * 5 * (size_t)n));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    LAUNCH_TRY(h, launch_spline_eval(spline_view(h), n, h->dTmpA.as<double>(), h->dTmpB.as<double>(), h->stream));
+    std::vector<double> outv((size_t)5 * n);
+    HIP_TRY(h, hipMemcpyAsync(outv.data(), h->dTmpB.p, sizeof(double) * 5 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double *dst[5] = { x, y, yaw, kappa, dkappa };
+    for (int f = 0; f < 5; ++f)
+        if (dst[f]) std::memcpy(dst[f], outv.data() + (size_t)f * n, sizeof(double) * (size_t)n);
+    return FOT_OK;
+}
+
+int fot_plan_batch_device(fot_handle *h, const fot_batch *batch, fot_result *out_dev, void *stream)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!batch) return fail(h, FOT_ERR_INVALID, "batch is NULL");
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return enqueue_plan(h, *batch, batch->static_xy, batch->dyn_xy, out_dev, st);
+}
+
+int fot_synchronize(fot_handle *h)
+{
+    if (!h) return FOT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FOT_OK;
+}
+
+int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!batch) return fail(h, FOT_ERR_INVALID, "batch is NULL");
+    if (batch->n_inst > 0 && !out) return fail(h, FOT_ERR_INVALID, "out is NULL");
+    if (batch->n_inst <= 0) return batch->n_inst == 0 ? FOT_OK : fail(h, FOT_ERR_INVALID, "n_inst < 0");
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    // extents of the caller's obstacle arrays
+    BatchLayout probe;
+    std::string err;
+    int rc = build_batch_layout(h->params, h->P, *batch, probe, err);
+    if (rc != FOT_OK) return fail(h, rc, err);
+    const size_t elem = batch->obstacle_dtype == FOT_F32 ? sizeof(float) : sizeof(double);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t st_bytes = (size_t)probe.n_static * 2 * elem, dy_bytes = (size_t)probe.dyn_src_points * 2 * elem;
+    HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
+    HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
+    HIP_TRY(h, h->dOut.ensure(sizeof(fot_result) * (size_t)batch->n_inst));
+    if (st_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserStatic.p, batch->static_xy, st_bytes, hipMemcpyHostToDevice, h->stream));
+    if (dy_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserDyn.p, batch->dyn_xy, dy_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = enqueue_plan(h, *batch, h->dUserStatic.p, h->dUserDyn.p, h->dOut.as<fot_result>(), h->stream);
+    if (rc != FOT_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, h->dOut.p, sizeof(fot_result) * (size_t)batch->n_inst, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FOT_OK;
+}
+
+int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
+                           double *frenet, double *ref, double *new_prev_s, int32_t *ok)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    if (n <= 0) return FOT_OK;
+    if (!ego) return fail(h, FOT_ERR_INVALID, "ego is NULL");
+    std::vector<InstDesc> desc((size_t)n);
+    for (int i = 0; i < n; ++i) { desc[i] = InstDesc(); desc[i].ego = ego[i]; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc) * (size_t)n));
+    HIP_TRY(h, h->dTmpB.ensure(sizeof(InstState) * (size_t)n));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, desc.data(), sizeof(InstDesc) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), h->dTmpA.as<InstDesc>(),
+                                      h->dTmpB.as<InstState>(), n, h->stream));
+    std::vector<InstState> st((size_t)n);
+    HIP_TRY(h, hipMemcpyAsync(st.data(), h->dTmpB.p, sizeof(InstState) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        if (frenet) std::memcpy(frenet + 6 * (size_t)i, st[i].frenet0, sizeof(double) * 6);
+        if (ref) std::memcpy(ref + 6 * (size_t)i, st[i].ref0, sizeof(double) * 6);
+        if (new_prev_s) new_prev_s[i] = st[i].new_prev_s;
+        if (ok) ok[i] = st[i].c2f_ok;
+    }
+    return FOT_OK;
+}
+
+int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
+                         int32_t *status, int32_t *keep, int32_t *n_t)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->last_valid) return fail(h, FOT_ERR_INVALID, "no completed plan call on this handle");
+    const BatchLayout &L = h->last;
+    if (inst < 0 || inst >= L.n_inst) return fail(h, FOT_ERR_INVALID, "instance index out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const InstDesc &D = L.desc[inst];
+    InstState S;
+    HIP_TRY(h, hipMemcpy(&S, h->dState.as<InstState>() + inst, sizeof(InstState), hipMemcpyDeviceToHost));
+    const int n = S.n_cand;
+    const int m = n < cap ? n : cap;
+    if (m <= 0) return n;
+    std::vector<uint8_t> st8((size_t)m), kp8((size_t)m);
+    if (cost) HIP_TRY(h, hipMemcpy(cost, h->dCost.as<double>() + D.cand_off, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(st8.data(), h->dStatus.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(kp8.data(), h->dKeep.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i) {
+        if (status) status[i] = st8[i];
+        if (keep) keep[i] = kp8[i];
+        if (n_t) {
+            if (i < D.n_grid) n_t[i] = h->P.ti[i / (D.n_tv * h->P.n_di)].n_t;
+            else n_t[i] = h->P.n_total;
+        }
+    }
+    return n;
+}
+
+int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len,
+                              const double *x, const double *y, const double *yaw, const double *t,
+                              int32_t n_static, const double *static_xy,
+                              int32_t mode, int32_t S, int32_t Pn, int32_t T, const double *dyn,
+                              int32_t *free_out)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n_paths <= 0) return FOT_OK;
+    if (!len || !x || !y || !t || !free_out) return fail(h, FOT_ERR_INVALID, "NULL path array");
+    const DevParams &P = h->P;
+    if (P.has_footprint && !yaw) return fail(h, FOT_ERR_INVALID, "yaw is required with a multi-circle footprint");
+    // one single-instance batch carries the obstacle set
+    fot_ego ego = {};
+    double target = 0.0;
+    int32_t soff[2] = { 0, n_static > 0 ? n_static : 0 };
+    int64_t doff[1] = { 0 };
+    int32_t dims[4] = { mode, S, Pn, T };
+    fot_batch b = {};
+    b.n_inst = 1; b.obstacle_dtype = FOT_F64; b.ego = &ego; b.target_speed = &target;
+    b.static_xy = static_xy; b.static_off = soff; b.dyn_xy = dyn; b.dyn_off = doff; b.dyn_dims = dims;
+    BatchLayout L;
+    std::string err;
+    int rc = build_batch_layout(h->params, P, b, L, err);
+    if (rc != FOT_OK) return fail(h, rc, err);
+    h->last_valid = false;
+
+    // collision points [n_circ][FOT_MAX_NT][n_paths] and time indices [FOT_MAX_NT][n_paths]
+    // (footprint expansion: frenet_planner.py:1152-1170; time index: :1226)
+    const size_t np = (size_t)n_paths;
+    std::vector<d2> pts((size_t)P.n_circ * FOT_MAX_NT * np);
+    std::vector<int32_t> tidx((size_t)FOT_MAX_NT * np, 0);
+    for (int i = 0; i < n_paths; ++i) {
+        if (len[i] < 0 || len[i] > FOT_MAX_NT) return fail(h, FOT_ERR_INVALID, "path length out of range");
+        for (int k = 0; k < len[i]; ++k) {
+            const size_t src = (size_t)i * FOT_MAX_NT + k;
+            tidx[(size_t)k * np + i] = (int32_t)std::nearbyint(t[src] / P.dt);
+            for (int c = 0; c < P.n_circ; ++c) {
+                d2 v;
+                if (P.has_footprint) {
+                    v.x = x[src] + P.circ_off[c] * std::cos(yaw[src]);
+                    v.y = y[src] + P.circ_off[c] * std::sin(yaw[src]);
+                } else {
+                    v.x = x[src]; v.y = y[src];
+                }
+                pts[((size_t)c * FOT_MAX_NT + k) * np + i] = v;
+            }
+        }
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const size_t st_bytes = sizeof(double) * 2 * (size_t)L.n_static, dy_bytes = sizeof(double) * 2 * (size_t)L.dyn_src_points;
+    HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
+    HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
+    HIP_TRY(h, h->dStat.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_static, 1)));
+    HIP_TRY(h, h->dRows.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_dyn_points, 1)));
+    HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc)));
+    HIP_TRY(h, h->dTmpB.ensure(sizeof(d2) * pts.size()));
+    HIP_TRY(h, h->dTmpC.ensure(sizeof(int32_t) * (tidx.size() + np)));
+    HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * np));
+    if (st_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserStatic.p, static_xy, st_bytes, hipMemcpyHostToDevice, st));
+    if (dy_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserDyn.p, dyn, dy_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, L.desc.data(), sizeof(InstDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpB.p, pts.data(), sizeof(d2) * pts.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpC.p, tidx.data(), sizeof(int32_t) * tidx.size(), hipMemcpyHostToDevice, st));
+    int32_t *d_len = h->dTmpC.as<int32_t>() + tidx.size();
+    HIP_TRY(h, hipMemcpyAsync(d_len, len, sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
+    LAUNCH_TRY(h, launch_prep_static(h->dUserStatic.p, FOT_F64, h->dStat.as<d2>(), L.n_static, st));
+    LAUNCH_TRY(h, launch_prep_dyn(h->dTmpA.as<InstDesc>(), 1, L.max_dyn_points, h->dUserDyn.p, FOT_F64, h->dRows.as<d2>(), st));
+    LAUNCH_TRY(h, launch_collide_ext(h->dP.as<DevParams>(), h->dTmpA.as<InstDesc>(), n_paths, d_len, h->dTmpB.as<d2>(),
+                                     h->dTmpC.as<int32_t>(), h->dStat.as<d2>(), h->dRows.as<d2>(),
+                                     h->dTmpD.as<int32_t>(), st));
+    HIP_TRY(h, hipMemcpyAsync(free_out, h->dTmpD.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return FOT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// fot_kernels.hip -- gfx950 kernels of the Frenet optimal-trajectory planner.
+//
+// Pipeline of one fot_plan_batch (all float64, one launch each over the whole batch):
+//   k_prep_static / k_prep_dyn : caller's obstacle tensors -> double2, dynamic ones transposed to
+//                                [T][S*P] rows so that one time step is one contiguous, wave-uniform row
+//   k_frenet_state   : 1 wave / instance   nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
+//   k_lon_table      : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t)
+//   k_evaluate       : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks,
+//                      collision points to scratch in [wave][circle][k][lane] order (coalesced 1 KiB stores)
+//   k_collide        : 1 lane / candidate that survived: static + time-indexed dynamic (chance-constrained)
+//   k_select         : 1 wave / instance: stop-distance filter, rejection histogram, first-minimum argmin
+//                      (shuffle reduction, lowest index wins ties), selected path written out
+#include <hip/hip_runtime.h>
+
+#include "fot_math.hpp"
+#include "fot_kernels.h"
+
+namespace fot {
+
+// ---------------------------------------------------------------------------
+// obstacle preparation
+// ---------------------------------------------------------------------------
+
+template <typename T>
+__global__ void k_prep_static(const T *__restrict__ src, d2 *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    d2 o;
+    o.x = (double)src[2 * i];
+    o.y = (double)src[2 * i + 1];
+    dst[i] = o;
+}
+
+// [S][P][T][2] -> rows[T][S*P]; blockIdx.y = instance
+template <typename T>
+__global__ void k_prep_dyn(const InstDesc *__restrict__ desc, const T *__restrict__ src, d2 *__restrict__ rows)
+{
+    const InstDesc &D = desc[blockIdx.y];
+    if (D.dyn_mode == FOT_DYN_NONE) return;
+    const int SP = D.S * D.P;
+    const int64_t total = (int64_t)SP * D.T;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // output index k*SP + sp
+    if (o >= total) return;
+    const int k = (int)(o / SP), sp = (int)(o - (int64_t)k * SP);
+    const int64_t in = D.dyn_off + (int64_t)sp * D.T + k;
+    d2 v;
+    v.x = (double)src[2 * in];
+    v.y = (double)src[2 * in + 1];
+    rows[D.row_off + o] = v;
+}
+
+// ---------------------------------------------------------------------------
+// ego -> Frenet state
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ ScanBest wave_argmin(ScanBest b)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ScanBest o;
+        o.dist = __shfl_xor(b.dist, off, WAVE);
+        o.idx = __shfl_xor(b.idx, off, WAVE);
+        scan_merge(b, o);
+    }
+    return b;
+}
+
+__global__ void __launch_bounds__(WAVE)
+k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
+               InstState *__restrict__ state, int n_inst)
+{
+    const int inst = blockIdx.x;
+    if (inst >= n_inst) return;
+    const DevParams &P = *Pp;
+    const InstDesc &D = desc[inst];
+    const int lane = threadIdx.x;
+    const double x = D.ego.x, y = D.ego.y;
+    const double s_end = sp.s[sp.n - 1];
+
+    double best_s = 0.0;
+    bool need_global = true;
+    if (D.ego.has_prev_s) {                                   // cached window +-10 m, 100 samples
+        const double s_min = fmax(0.0, D.ego.prev_s - 10.0);
+        const double s_max = fmin(s_end, D.ego.prev_s + 10.0);
+        ScanBest b = wave_argmin(scan_samples(sp, x, y, s_min, s_max, 100, lane, WAVE, false));
+        best_s = b.idx >= 0 ? linspace_at(s_min, s_max, 100, b.idx) : 0.0;
+        const bool at_lower = fabs(best_s - s_min) < 1e-3 && s_min > 0.0;
+        const bool at_upper = fabs(best_s - s_max) < 1e-3 && s_max < s_end;
+        need_global = at_lower || at_upper;
+    }
+    const int n_glob = global_search_count(sp);
+    if (need_global) {
+        ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
+        best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
+    }
+    best_s = refine_nearest(sp, x, y, best_s);                // uniform across the wave
+    const double new_prev_s = best_s;
+
+    double fr[6], ref[6];
+    bool ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
+    if (!ok) {
+        double px, py;
+        spline_xy(sp, best_s, px, py);
+        if (isnan(px) || isnan(py)) {                         // coordinate_converter.py:289-295
+            ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
+            best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
+            ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
+        }
+    }
+    if (lane == 0) {
+        InstState &S = state[inst];
+        for (int i = 0; i < 6; ++i) { S.frenet0[i] = ok ? fr[i] : NAN; S.ref0[i] = ok ? ref[i] : NAN; }
+        S.new_prev_s = new_prev_s;
+        S.c2f_ok = ok ? 1 : 0;
+        const int nb = (ok && fr[1] > 0.1) ? P.n_brake : 0;   // BRAKE_MIN_SPEED gate
+        S.n_brake = nb;
+        S.n_cand = ok ? D.n_grid + nb : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// longitudinal profiles + reference frame table
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(WAVE)
+k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
+            const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, double *__restrict__ lon_tab)
+{
+    const DevParams &P = *Pp;
+    const int inst = blockIdx.y;
+    const InstDesc &D = desc[inst];
+    const InstState &S = state[inst];
+    if (!S.c2f_ok) return;
+    const int slot = blockIdx.x;
+    const int n_grid_lon = P.n_ti * D.n_tv;
+    if (slot >= n_grid_lon + S.n_brake) return;
+
+    LonInfo L;
+    if (slot < n_grid_lon) {
+        const int ti = slot / D.n_tv, itv = slot - ti * D.n_tv;
+        lon_coeffs(S.frenet0, tv_value(P, D, itv), P.ti[ti], L);
+        L.n_t = P.ti[ti].n_t;
+        L.n_eval = L.n_t;
+    } else {
+        const TimeInfo &tb = P.brake[slot - n_grid_lon];
+        lon_coeffs(S.frenet0, 0.0, tb, L);
+        L.n_t = P.n_total;
+        L.n_eval = tb.n_t;
+    }
+    const int k = threadIdx.x;
+    double *tab = lon_tab + (int64_t)(D.lon_off + slot) * (LON_FIELDS * FOT_MAX_NT);
+    double jerk2 = 0.0, sd_k = 0.0;
+    if (k < L.n_t) {
+        LonSample ls;
+        double sddd;
+        make_lon_sample(sp, L, k, P.dt, ls, sddd);
+        tab[0 * FOT_MAX_NT + k] = ls.s;     tab[1 * FOT_MAX_NT + k] = ls.sd;    tab[2 * FOT_MAX_NT + k] = ls.sdd;
+        tab[3 * FOT_MAX_NT + k] = ls.rx;    tab[4 * FOT_MAX_NT + k] = ls.ry;
+        tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
+        tab[7 * FOT_MAX_NT + k] = ls.kr;    tab[8 * FOT_MAX_NT + k] = ls.dkr;
+        tab[9 * FOT_MAX_NT + k] = sddd;
+        jerk2 = sddd * sddd;
+        sd_k = ls.sd;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) jerk2 += __shfl_xor(jerk2, off, WAVE);
+    const double sd_last = __shfl(sd_k, L.n_t - 1, WAVE);
+    if (k == 0) {
+        L.Js = jerk2;
+        L.sd_last = sd_last;
+        lon_info[D.lon_off + slot] = L;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// candidate evaluation
+// ---------------------------------------------------------------------------
+
+struct ScratchSink {
+    d2 *base;          // this wave's scratch + lane
+    int n_total;
+    __device__ __forceinline__ void put(int k, int ci, double x, double y)
+    {
+        d2 v; v.x = x; v.y = y;
+        base[((int64_t)ci * n_total + k) * WAVE] = v;
+    }
+};
+
+struct ScratchSource {
+    const d2 *base;
+    int n_total;
+    __device__ __forceinline__ void get(int k, int ci, double &x, double &y) const
+    {
+        const d2 v = base[((int64_t)ci * n_total + k) * WAVE];
+        x = v.x; y = v.y;
+    }
+    __device__ __forceinline__ int tindex(int k) const { return k; }
+};
+
+__global__ void __launch_bounds__(256)
+k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+           const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
+           const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
+           double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
+           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep, d2 *__restrict__ pts)
+{
+    const int wave = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (wave >= n_waves) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const DevParams &P = *Pp;
+    const int inst = wave_inst[wave];
+    const InstDesc &D = desc[inst];
+    const InstState &S = state[inst];
+    const int idx = wave_base[wave] + lane;                    // candidate index inside the instance
+    const int64_t slot = (int64_t)D.cand_off + idx;
+    if (!S.c2f_ok || idx >= S.n_cand) {
+        cand_status[slot] = 255;                               // padding lane: never counted
+        cand_keep[slot] = 0;
+        return;
+    }
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+    const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
+    const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+    double q[6];
+    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+
+    ScratchSink sink;
+    sink.base = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
+    sink.n_total = P.n_total;
+    CandResult r;
+    evaluate_candidate(P, D, L, tab, q, sink, r);
+    cand_cost[slot] = r.cost;
+    cand_vlast[slot] = r.v_last;
+    cand_travel[slot] = r.travel;
+    cand_status[slot] = (uint8_t)r.status;
+    cand_keep[slot] = (uint8_t)r.keep;
+}
+
+// ---------------------------------------------------------------------------
+// collision
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
+          const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
+          const d2 *__restrict__ stat, const d2 *__restrict__ rows, const d2 *__restrict__ pts,
+          uint8_t *__restrict__ cand_status, const uint8_t *__restrict__ cand_keep)
+{
+    const int wave = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (wave >= n_waves) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const DevParams &P = *Pp;
+    const int inst = wave_inst[wave];
+    const InstDesc &D = desc[inst];
+    if (D.n_static == 0 && D.dyn_mode == FOT_DYN_NONE) return;
+    const int64_t slot = (int64_t)D.cand_off + wave_base[wave] + lane;
+    if (cand_status[slot] != ST_PENDING) return;
+    ScratchSource src;
+    src.base = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
+    src.n_total = P.n_total;
+    if (collide_candidate(P, D, stat + D.static_off, rows + D.row_off, (int)cand_keep[slot], src))
+        cand_status[slot] = FOT_ST_COLLISION;
+}
+
+// ---------------------------------------------------------------------------
+// selection + output
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(WAVE)
+k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+         const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
+         const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
+         const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
+         const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
+{
+    const int inst = blockIdx.x;
+    if (inst >= n_inst) return;
+    const DevParams &P = *Pp;
+    const InstDesc &D = desc[inst];
+    const InstState &S = state[inst];
+    const int lane = threadIdx.x;
+    fot_result &R = out[inst];
+
+    if (!S.c2f_ok) {
+        if (lane == 0) {
+            R.status = FOT_PLAN_C2F_FAILED; R.best_index = -1; R.n_cand = 0; R.n_keep = 0;
+            R.cost = INFINITY; R.stats_valid = 0;
+            R.new_last_kappa = D.ego.last_kappa; R.new_prev_s = S.new_prev_s;
+            for (int i = 0; i < 6; ++i) { R.frenet0[i] = NAN; R.ref0[i] = NAN; }
+        }
+        return;
+    }
+
+    int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    ScanBest best = { INFINITY, -1 };
+    for (int idx = lane; idx < S.n_cand; idx += WAVE) {
+        const int64_t slot = (int64_t)D.cand_off + idx;
+        int st = cand_status[slot];
+        st = final_status(st, cand_vlast[slot], cand_travel[slot], D.max_stop);
+        cand_status[slot] = (uint8_t)st;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cnt[c] += (st == c) ? 1 : 0;
+        if (st == FOT_ST_OK) {
+            const double cost = cand_cost[slot];
+            if (cost < best.dist) { best.dist = cost; best.idx = idx; }   // first strict minimum of this lane
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        for (int off = 32; off >= 1; off >>= 1) cnt[c] += __shfl_xor(cnt[c], off, WAVE);
+    best = wave_argmin(best);                                              // lowest index wins ties
+
+    if (lane == 0) {
+        R.status = best.idx >= 0 ? FOT_PLAN_OK : FOT_PLAN_NO_PATH;
+        R.best_index = best.idx;
+        R.n_cand = S.n_cand;
+        R.cost = best.idx >= 0 ? best.dist : INFINITY;
+        for (int c = 0; c < 8; ++c) R.stats[c] = cnt[c];
+        R.stats_valid = 1;
+        R.new_prev_s = S.new_prev_s;
+        for (int i = 0; i < 6; ++i) { R.frenet0[i] = S.frenet0[i]; R.ref0[i] = S.ref0[i]; }
+    }
+    if (best.idx < 0) {
+        if (lane == 0) { R.n_keep = 0; R.new_last_kappa = D.ego.last_kappa; }
+        return;
+    }
+    const int keep = cand_keep[(int64_t)D.cand_off + best.idx];
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
+    const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
+    const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+    double q[6];
+    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+    if (lane < keep) {
+        double o[15];
+        final_sample(P, L, tab, q, lane, o);
+        R.t[lane] = o[0]; R.s[lane] = o[1]; R.s_d[lane] = o[2]; R.s_dd[lane] = o[3]; R.s_ddd[lane] = o[4];
+        R.d[lane] = o[5]; R.d_d[lane] = o[6]; R.d_dd[lane] = o[7]; R.d_ddd[lane] = o[8];
+        R.x[lane] = o[9]; R.y[lane] = o[10]; R.yaw[lane] = o[11]; R.v[lane] = o[12]; R.a[lane] = o[13];
+        R.c[lane] = o[14];
+        if (lane == 1) R.new_last_kappa = o[14];                           // frenet_planner.py:301-302
+    }
+    if (lane == 0) {
+        R.n_keep = keep;
+        if (keep <= 1) R.new_last_kappa = D.ego.last_kappa;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// spline evaluation (fot_spline_eval)
+// ---------------------------------------------------------------------------
+
+__global__ void k_spline_eval(SplineView sp, int n, const double *__restrict__ s, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SplinePt p;
+    spline_point(sp, s[i], p);
+    double cr, sr, kappa, dkappa;
+    spline_frame(p, cr, sr, kappa, dkappa);
+    out[0 * (int64_t)n + i] = p.x;
+    out[1 * (int64_t)n + i] = p.y;
+    out[2 * (int64_t)n + i] = atan2(p.dy, p.dx);
+    out[3 * (int64_t)n + i] = kappa;
+    out[4 * (int64_t)n + i] = dkappa;
+}
+
+// external-path collision check: one lane per path, points read from a [n_circ][FOT_MAX_NT][n_paths] array
+struct ExtSource {
+    const d2 *base;
+    const int32_t *tidx;   // [FOT_MAX_NT][n_paths], this path's column
+    int64_t stride_k, stride_c;
+    __device__ __forceinline__ int tindex(int k) const { return tidx[k * stride_k]; }
+    __device__ __forceinline__ void get(int k, int ci, double &x, double &y) const
+    {
+        const d2 v = base[ci * stride_c + k * stride_k];
+        x = v.x; y = v.y;
+    }
+};
+
+__global__ void k_collide_ext(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int n_paths,
+                              const int32_t *__restrict__ len, const d2 *__restrict__ pts,
+                              const int32_t *__restrict__ tidx, const d2 *__restrict__ stat, const d2 *__restrict__ rows, int32_t *__restrict__ free_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_paths) return;
+    ExtSource src;
+    src.base = pts + i;
+    src.tidx = tidx + i;
+    src.stride_k = n_paths;
+    src.stride_c = (int64_t)FOT_MAX_NT * n_paths;
+    const bool hit = len[i] > 0 && collide_candidate(*Pp, desc[0], stat, rows, len[i], src);
+    free_out[i] = hit ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+
+#define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int launch_prep_static(const void *src, int dtype, d2 *dst, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    const int bs = 256;
+    const unsigned grid = (unsigned)((n + bs - 1) / bs);
+    if (dtype == FOT_F32) k_prep_static<float><<<grid, bs, 0, st>>>((const float *)src, dst, n);
+    else k_prep_static<double><<<grid, bs, 0, st>>>((const double *)src, dst, n);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_points, const void *src, int dtype, d2 *rows,
+                    hipStream_t st)
+{
+    if (max_points <= 0 || n_inst <= 0) return 0;
+    const int bs = 256;
+    dim3 grid((unsigned)((max_points + bs - 1) / bs), (unsigned)n_inst);
+    if (dtype == FOT_F32) k_prep_dyn<float><<<grid, bs, 0, st>>>(desc, (const float *)src, rows);
+    else k_prep_dyn<double><<<grid, bs, 0, st>>>(desc, (const double *)src, rows);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
+                        hipStream_t st)
+{
+    if (n_inst <= 0) return 0;
+    k_frenet_state<<<n_inst, WAVE, 0, st>>>(P, sp, desc, state, n_inst);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
+                     LonInfo *lon_info, double *lon_tab, int n_inst, int max_lon, hipStream_t st)
+{
+    if (n_inst <= 0 || max_lon <= 0) return 0;
+    dim3 grid((unsigned)max_lon, (unsigned)n_inst);
+    k_lon_table<<<grid, WAVE, 0, st>>>(P, sp, desc, state, lon_info, lon_tab);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+                    const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
+                    CandArrays c, d2 *pts, hipStream_t st)
+{
+    if (n_waves <= 0) return 0;
+    const int wpb = 256 / WAVE;
+    k_evaluate<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, state, lon_info, lon_tab, wave_inst, wave_base,
+                                                         n_waves, c.cost, c.v_last, c.travel, c.status, c.keep, pts);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
+                   int n_waves, const d2 *stat, const d2 *rows, const d2 *pts, CandArrays c, hipStream_t st)
+{
+    if (n_waves <= 0) return 0;
+    const int wpb = 256 / WAVE;
+    k_collide<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, wave_inst, wave_base, n_waves, stat, rows, pts,
+                                                        c.status, c.keep);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+                  const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st)
+{
+    if (n_inst <= 0) return 0;
+    k_select<<<n_inst, WAVE, 0, st>>>(P, desc, state, lon_info, lon_tab, c.cost, c.v_last, c.travel, c.status,
+                                     c.keep, out, n_inst);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    k_spline_eval<<<(n + 255) / 256, 256, 0, st>>>(sp, n, s, out);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_collide_ext(const DevParams *P, const InstDesc *desc, int n_paths, const int32_t *len, const d2 *pts,
+                       const int32_t *tidx, const d2 *stat, const d2 *rows, int32_t *free_out, hipStream_t st)
+{
+    if (n_paths <= 0) return 0;
+    k_collide_ext<<<(n_paths + 63) / 64, 64, 0, st>>>(P, desc, n_paths, len, pts, tidx, stat, rows, free_out);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace fot

@@ -1,0 +1,525 @@
+// fot_math.hpp -- the planner arithmetic, float64, usable from gfx950 kernels and
+// (for the CPU-side logic tests in tests/emu) from plain C++.
+//
+// What each block computes is defined by the reference
+// (mnhrk15/integrated_path_planning); the line references say where.  The
+// formulation is our own: trigonometry of the reference frame is carried as
+// (cos, sin) pairs, so the per-sample Frenet->Cartesian transform needs no
+// transcendental, and only the selected path gets an atan2 for its yaw.
+#pragma once
+
+#include <math.h>
+#include "fot_types.h"
+
+namespace fot {
+
+// ---------------------------------------------------------------------------
+// cubic spline (reference: src/planning/cubic_spline.py:47-166, 215-288)
+// ---------------------------------------------------------------------------
+
+struct SplinePt {
+    double x, y, dx, dy, ddx, ddy, dddx, dddy;
+};
+
+// segment of v: number of knots <= v, minus one, clipped to [0, n-2]  (:154-166)
+FOT_HD int spline_index(const SplineView &sp, double v)
+{
+    int lo = 0, hi = sp.n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (sp.s[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    int idx = lo - 1;
+    idx = idx < 0 ? 0 : idx;
+    idx = idx > sp.n - 2 ? sp.n - 2 : idx;
+    return idx;
+}
+
+// position and derivatives; everything NaN outside [s_0, s_end]  (:62, :91)
+FOT_HD bool spline_point(const SplineView &sp, double s, SplinePt &o)
+{
+    if (!(s >= sp.s[0] && s <= sp.s[sp.n - 1])) {
+        const double q = NAN;
+        o.x = o.y = o.dx = o.dy = o.ddx = o.ddy = o.dddx = o.dddy = q;
+        return false;
+    }
+    const int i = spline_index(sp, s);
+    const double h = s - sp.s[i], h2 = h * h;
+    const double bx = sp.bx[i], cx = sp.cx[i], dx = sp.dx[i];
+    const double by = sp.by[i], cy = sp.cy[i], dy = sp.dy[i];
+    o.x = sp.ax[i] + bx * h + cx * h2 + dx * (h2 * h);
+    o.y = sp.ay[i] + by * h + cy * h2 + dy * (h2 * h);
+    o.dx = bx + 2.0 * cx * h + 3.0 * dx * h2;
+    o.dy = by + 2.0 * cy * h + 3.0 * dy * h2;
+    o.ddx = 2.0 * cx + 6.0 * dx * h;
+    o.ddy = 2.0 * cy + 6.0 * dy * h;
+    o.dddx = 6.0 * dx;
+    o.dddy = 6.0 * dy;
+    return true;
+}
+
+FOT_HD void spline_xy(const SplineView &sp, double s, double &x, double &y)
+{
+    if (!(s >= sp.s[0] && s <= sp.s[sp.n - 1])) { x = NAN; y = NAN; return; }
+    const int i = spline_index(sp, s);
+    const double h = s - sp.s[i], h2 = h * h;
+    x = sp.ax[i] + sp.bx[i] * h + sp.cx[i] * h2 + sp.dx[i] * (h2 * h);
+    y = sp.ay[i] + sp.by[i] * h + sp.cy[i] * h2 + sp.dy[i] * (h2 * h);
+}
+
+// tangent direction as (cos, sin), curvature (:246) and curvature rate (:265-273)
+FOT_HD void spline_frame(const SplinePt &p, double &cos_r, double &sin_r, double &kappa, double &dkappa)
+{
+    const double d = p.dx * p.dx + p.dy * p.dy;
+    const double rt = sqrt(d);
+    cos_r = p.dx / rt;
+    sin_r = p.dy / rt;
+    const double d15 = d * rt;
+    const double a = p.dx * p.ddy - p.dy * p.ddx;
+    const double b = p.dx * p.dddy - p.dy * p.dddx;
+    const double c = p.dx * p.ddx + p.dy * p.ddy;
+    kappa = a / d15;
+    dkappa = b / d15 - 3.0 * a * c / (d15 * d);
+}
+
+// ---------------------------------------------------------------------------
+// nearest point on the path (reference: src/core/coordinate_converter.py:202-339)
+// ---------------------------------------------------------------------------
+
+// numpy.linspace(a, b, num)[i]
+FOT_HD double linspace_at(double a, double b, int num, int i)
+{
+    if (num == 1) return a;
+    if (i == num - 1) return b;
+    const double step = (b - a) / (double)(num - 1);
+    if (step == 0.0) return a + ((double)i / (double)(num - 1)) * (b - a);
+    return a + (double)i * step;
+}
+
+struct ScanBest {
+    double dist;
+    int idx;
+};
+
+FOT_HD void scan_merge(ScanBest &a, const ScanBest &b)
+{
+    if (b.idx >= 0 && (a.idx < 0 || b.dist < a.dist || (b.dist == a.dist && b.idx < a.idx))) a = b;
+}
+
+// distance scan over linspace(s_lo, s_hi, num) restricted to samples lane, lane+nlanes, ...
+// keeps the first strict minimum (:230-237); nan_first reproduces np.argmin (:336)
+FOT_HD ScanBest scan_samples(const SplineView &sp, double x, double y, double s_lo, double s_hi, int num,
+                             int lane, int nlanes, bool nan_first)
+{
+    ScanBest best = { INFINITY, -1 };
+    for (int i = lane; i < num; i += nlanes) {
+        const double s = linspace_at(s_lo, s_hi, num, i);
+        double px, py;
+        spline_xy(sp, s, px, py);
+        double dist = hypot(x - px, y - py);
+        if (nan_first && isnan(dist)) dist = -INFINITY;
+        if (dist < best.dist) { best.dist = dist; best.idx = i; }
+    }
+    return best;
+}
+
+FOT_HD int global_search_count(const SplineView &sp)
+{
+    const int num = (int)(sp.s[sp.n - 1] / 0.1);
+    return num < 100 ? 100 : num;
+}
+
+// 20 rounds of {left, centre, right}, step 0.2 halving when the centre wins (:253-280)
+FOT_HD double refine_nearest(const SplineView &sp, double x, double y, double best_s)
+{
+    const double s_end = sp.s[sp.n - 1];
+    double ds = 0.2;
+    for (int it = 0; it < 20; ++it) {
+        const double s_left = fmax(0.0, best_s - ds);
+        const double s_right = fmin(s_end, best_s + ds);
+        double px, py;
+        spline_xy(sp, s_left, px, py);
+        const double dist_left = hypot(x - px, y - py);
+        spline_xy(sp, s_right, px, py);
+        const double dist_right = hypot(x - px, y - py);
+        spline_xy(sp, best_s, px, py);
+        const double dist_curr = hypot(x - px, y - py);
+        if (dist_left < dist_curr && dist_left < dist_right) best_s = s_left;
+        else if (dist_right < dist_curr && dist_right < dist_left) best_s = s_right;
+        else ds *= 0.5;
+    }
+    return best_s;
+}
+
+// reference point at rs + Cartesian->Frenet of the ego
+// (coordinate_converter.py:285-308, :26-88; frenet_planner.py:362-371).  false = the reference raises.
+FOT_HD bool frenet_state_at(const SplineView &sp, const fot_ego &ego, double rs, double *fr, double *ref)
+{
+    SplinePt p;
+    spline_point(sp, rs, p);
+    if (isnan(p.x) || isnan(p.y)) return false;
+    double cos_r, sin_r, rkappa, rdkappa;
+    spline_frame(p, cos_r, sin_r, rkappa, rdkappa);
+    const double rtheta = atan2(p.dy, p.dx);
+    if (isnan(rtheta) || isnan(rkappa) || isnan(rdkappa)) return false;
+    ref[0] = rs; ref[1] = p.x; ref[2] = p.y; ref[3] = rtheta; ref[4] = rkappa; ref[5] = rdkappa;
+
+    const double dx = ego.x - p.x, dy = ego.y - p.y;
+    const double cr = cos(rtheta), sr = sin(rtheta);
+    const double cross = cr * dy - sr * dx;
+    const double d = copysign(hypot(dx, dy), cross);
+    const double delta = ego.yaw - rtheta;
+    const double tan_d = tan(delta), cos_d = cos(delta);
+    const double omkd = 1.0 - rkappa * d;
+    const double d_p = omkd * tan_d;
+    const double krdp = rdkappa * d + rkappa * d_p;
+    const double kappa = ego.last_kappa;
+    const double d_pp = -krdp * tan_d + omkd / (cos_d * cos_d) * (kappa * omkd / cos_d - rkappa);
+    const double s_d = ego.v * cos_d / omkd;
+    const double dtp = omkd / cos_d * kappa - rkappa;
+    const double s_dd = (ego.a * cos_d - s_d * s_d * (d_p * dtp - krdp)) / omkd;
+    fr[0] = rs; fr[1] = s_d; fr[2] = s_dd;
+    fr[3] = d;
+    fr[4] = d_p * s_d;
+    fr[5] = d_pp * (s_d * s_d) + d_p * s_dd;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// lattice polynomials (reference: frenet_planner.py:586-701)
+// ---------------------------------------------------------------------------
+
+// terminal-speed grid (:410-413): target, target - d_t_s, ..., and a final 0.0
+FOT_HD double tv_value(const DevParams &P, const InstDesc &D, int itv)
+{
+    return itv <= D.n_down ? D.target_speed - (double)itv * P.d_t_s : 0.0;
+}
+
+FOT_HD void lon_coeffs(const double *fr, double tv, const TimeInfo &ti, LonInfo &L)
+{
+    L.a0 = fr[0]; L.a1 = fr[1]; L.a2 = fr[2] / 2.0;
+    const double b0 = tv - L.a1 - 2.0 * L.a2 * ti.T;
+    const double b1 = -2.0 * L.a2;
+    L.a3 = b0 * ti.qa[0] + b1 * ti.qa[1];
+    L.a4 = b0 * ti.qa[2] + b1 * ti.qa[3];
+    L.T = ti.T;
+}
+
+FOT_HD void lat_coeffs(const double *fr, double di, const TimeInfo &ti, double *q)
+{
+    const double T = ti.T;
+    q[0] = fr[3]; q[1] = fr[4]; q[2] = fr[5] / 2.0;
+    const double b0 = di - q[0] - q[1] * T - q[2] * T * T;
+    const double b1 = -q[1] - 2.0 * q[2] * T;
+    const double b2 = -2.0 * q[2];
+    q[3] = b0 * ti.qi[0] + b1 * ti.qi[1] + b2 * ti.qi[2];
+    q[4] = b0 * ti.qi[3] + b1 * ti.qi[4] + b2 * ti.qi[5];
+    q[5] = b0 * ti.qi[6] + b1 * ti.qi[7] + b2 * ti.qi[8];
+}
+
+FOT_HD void lon_eval(const LonInfo &L, double t, double &s, double &sd, double &sdd, double &sddd)
+{
+    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2;
+    s = L.a0 + L.a1 * t + L.a2 * t2 + L.a3 * t3 + L.a4 * t4;
+    sd = L.a1 + 2.0 * L.a2 * t + 3.0 * L.a3 * t2 + 4.0 * L.a4 * t3;
+    sdd = 2.0 * L.a2 + 6.0 * L.a3 * t + 12.0 * L.a4 * t2;
+    sddd = 6.0 * L.a3 + 24.0 * L.a4 * t;
+}
+
+FOT_HD void lat_eval(const double *q, double t, double &d, double &dd, double &ddd, double &dddd)
+{
+    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
+    d = q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5;
+    dd = q[1] + 2.0 * q[2] * t + 3.0 * q[3] * t2 + 4.0 * q[4] * t3 + 5.0 * q[5] * t4;
+    ddd = 2.0 * q[2] + 6.0 * q[3] * t + 12.0 * q[4] * t2 + 20.0 * q[5] * t3;
+    dddd = 6.0 * q[3] + 24.0 * q[4] * t + 60.0 * q[5] * t2;
+}
+
+// longitudinal state of sample k of a profile, brake padding included (:483-500)
+FOT_HD void lon_sample(const LonInfo &L, int k, double dt, double &s, double &sd, double &sdd, double &sddd)
+{
+    if (k < L.n_eval) {
+        lon_eval(L, (double)k * dt, s, sd, sdd, sddd);
+    } else {
+        double u0, u1, u2;
+        lon_eval(L, (double)(L.n_eval - 1) * dt, s, u0, u1, u2);
+        sd = 0.0; sdd = 0.0; sddd = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Frenet -> Cartesian of one sample
+// (reference: frenet_planner.py:792-799, coordinate_converter.py:128-158)
+// ---------------------------------------------------------------------------
+
+struct LonSample {
+    double s, sd, sdd, rx, ry, cos_r, sin_r, kr, dkr;
+};
+
+struct CartSample {
+    double x, y, cos_t, sin_t, kappa, v, a, omkd;
+};
+
+FOT_HD void frenet_to_cart(const LonSample &L, double d, double d_d, double d_dd, CartSample &o)
+{
+    const bool moving = fabs(L.sd) > 1e-3;
+    const double safe = moving ? L.sd : 1.0;
+    const double dp = moving ? d_d / safe : 0.0;
+    const double dpp = moving ? (d_dd - dp * L.sdd) / (safe * safe) : 0.0;
+    const double omkd = 1.0 - L.kr * d;
+    const double h = sqrt(dp * dp + omkd * omkd);
+    const double cos_d = omkd / h, sin_d = dp / h;      // cos/sin of atan2(dp, omkd)
+    const double tan_d = dp / omkd;
+    const double krdp = L.dkr * d + L.kr * dp;
+    const double kappa = (((dpp + krdp * tan_d) * cos_d * cos_d) / omkd + L.kr) * cos_d / omkd;
+    const double d_dot = dp * L.sd;
+    const double dtp = omkd / cos_d * kappa - L.kr;
+    o.x = L.rx - L.sin_r * d;
+    o.y = L.ry + L.cos_r * d;
+    o.cos_t = cos_d * L.cos_r - sin_d * L.sin_r;
+    o.sin_t = sin_d * L.cos_r + cos_d * L.sin_r;
+    o.kappa = kappa;
+    o.v = sqrt(omkd * omkd * L.sd * L.sd + d_dot * d_dot);
+    o.a = L.sdd * omkd / cos_d + L.sd * L.sd / cos_d * (dp * dtp - krdp);
+    o.omkd = omkd;
+}
+
+FOT_HD void load_lon_sample(const double *tab, int k, LonSample &L)
+{
+    L.s = tab[0 * FOT_MAX_NT + k];   L.sd = tab[1 * FOT_MAX_NT + k];    L.sdd = tab[2 * FOT_MAX_NT + k];
+    L.rx = tab[3 * FOT_MAX_NT + k];  L.ry = tab[4 * FOT_MAX_NT + k];
+    L.cos_r = tab[5 * FOT_MAX_NT + k]; L.sin_r = tab[6 * FOT_MAX_NT + k];
+    L.kr = tab[7 * FOT_MAX_NT + k];  L.dkr = tab[8 * FOT_MAX_NT + k];
+}
+
+// one entry of the longitudinal table: profile state + reference frame at s
+FOT_HD void make_lon_sample(const SplineView &sp, const LonInfo &L, int k, double dt, LonSample &o, double &sddd)
+{
+    lon_sample(L, k, dt, o.s, o.sd, o.sdd, sddd);
+    SplinePt p;
+    spline_point(sp, o.s, p);
+    o.rx = p.x; o.ry = p.y;
+    spline_frame(p, o.cos_r, o.sin_r, o.kr, o.dkr);
+}
+
+// ---------------------------------------------------------------------------
+// candidate evaluation: cost, truncation, kinematic checks
+// (reference: frenet_planner.py:703-734, 826-887, 932-984, 995-1033)
+// ---------------------------------------------------------------------------
+
+struct CandResult {
+    double cost, v_last, travel;
+    int status, keep;
+};
+
+// lateral state of sample k: polynomial up to n_eval-1, then held (brake padding)
+FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d, double &dd, double &ddd, double &dddd)
+{
+    if (k < n_eval) {
+        lat_eval(q, (double)k * dt, d, dd, ddd, dddd);
+    } else {
+        double u0, u1, u2;
+        lat_eval(q, (double)(n_eval - 1) * dt, d, u0, u1, u2);
+        dd = 0.0; ddd = 0.0; dddd = 0.0;
+    }
+}
+
+// Sink::put(k, circle, x, y) receives the collision points of the kept prefix.
+template <class Sink>
+FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const double *lon_tab,
+                               const double *q, Sink &sink, CandResult &out)
+{
+    const int n_t = L.n_t;
+    double Jp = 0.0, d_last = 0.0;
+    bool singular = false, seen_nan = false, finite_ok = true, nan_step = false;
+    bool f_speed = false, f_accel = false, f_curv = false, f_lat = false, f_road = false;
+    int first_nan = -1;
+    double max_step = -INFINITY;
+    double xp = 0.0, yp = 0.0, dprev = 0.0, sprev = 0.0, cprev = 1.0, snprev = 0.0;
+    double v_last = 0.0, s_last = 0.0, s_first = 0.0;
+
+    for (int k = 0; k < n_t; ++k) {
+        double d, d_d, d_dd, d_ddd;
+        lat_sample(q, k, L.n_eval, P.dt, d, d_d, d_dd, d_ddd);
+        Jp += d_ddd * d_ddd;
+        d_last = d;
+        LonSample ls;
+        load_lon_sample(lon_tab, k, ls);
+        CartSample c;
+        frenet_to_cart(ls, d, d_d, d_dd, c);
+        if (isfinite(c.omkd) && c.omkd <= 0.05) singular = true;        // SINGULARITY_EPS, any sample
+        if (!seen_nan && isnan(c.x)) { seen_nan = true; first_nan = k; }
+        if (!seen_nan) {
+            if (!(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa))) finite_ok = false;
+            if (k == 0) {
+                s_first = ls.s;
+            } else {
+                const double step = hypot(c.x - xp, c.y - yp);
+                if (isnan(step)) nan_step = true;
+                if (step > max_step) max_step = step;
+                if (c.v > D.lim_speed) f_speed = true;
+                if (fabs(c.a) > D.lim_accel) f_accel = true;
+                if (c.v > 0.5) {                                            // LOW_SPEED_CURVATURE_GATE
+                    if (fabs(c.kappa) > D.lim_curv) f_curv = true;
+                } else {
+                    const double dd = fabs(d - dprev);
+                    const double d_s = fabs(ls.s - sprev);
+                    if (dd > fmax(1.5 * d_s, 0.02)) f_curv = true;
+                    const double sn = c.sin_t * cprev - c.cos_t * snprev;   // sin/cos of the yaw step
+                    const double cs = c.cos_t * cprev + c.sin_t * snprev;
+                    const double dyaw = fabs(atan2(sn, cs));
+                    if (dyaw > fmax(D.lim_curv * step, 0.1)) f_curv = true;
+                }
+                if (c.v * c.v * fabs(c.kappa) > D.lim_lat) f_lat = true;
+                if (fabs(d) > P.max_road_width + 1e-9) f_road = true;
+            }
+            if (P.has_footprint) {
+                for (int ci = 0; ci < P.n_circ; ++ci)
+                    sink.put(k, ci, c.x + P.circ_off[ci] * c.cos_t, c.y + P.circ_off[ci] * c.sin_t);
+            } else {
+                sink.put(k, 0, c.x, c.y);
+            }
+            v_last = c.v; s_last = ls.s;
+            xp = c.x; yp = c.y; dprev = d; sprev = ls.s; cprev = c.cos_t; snprev = c.sin_t;
+        }
+    }
+
+    int keep = n_t;
+    if (seen_nan) keep = first_nan >= 2 ? first_nan : 0;
+    if (singular) keep = 0;
+
+    const double Jd = d_last * d_last;
+    const double dv = D.target_speed - L.sd_last;
+    const double Jt = (double)(n_t - 1) * P.dt;
+    const double lat = P.k_j * Jp + P.k_t * Jt + P.k_d * Jd;
+    const double lon = P.k_j * L.Js + P.k_t * Jt + P.k_s_dot * (dv * dv);
+    out.cost = P.k_lat * lat + P.k_lon * lon;
+
+    int st = ST_PENDING;
+    if (f_road) st = FOT_ST_ROAD;
+    if (f_lat) st = FOT_ST_LAT_ACCEL;
+    if (f_curv) st = FOT_ST_CURVATURE;
+    if (f_accel) st = FOT_ST_ACCEL;
+    if (f_speed) st = FOT_ST_SPEED;
+    if (keep == 0 || !finite_ok || (!nan_step && max_step > D.step_limit)) st = FOT_ST_DROPPED;
+    out.status = st;
+    out.keep = keep;
+    out.v_last = v_last;
+    out.travel = s_last - s_first;
+}
+
+// ---------------------------------------------------------------------------
+// collision (reference: frenet_planner.py:1035-1233)
+// ---------------------------------------------------------------------------
+
+// any of the n obstacle points within sqrt(sq) of (px, py)   (:1196-1198, :1231-1233)
+FOT_HD bool hits_row(const d2 *row, int n, double px, double py, double sq)
+{
+    bool hit = false;
+    for (int j = 0; j < n; ++j) {
+        const double dx = px - row[j].x, dy = py - row[j].y;
+        if (dx * dx + dy * dy <= sq) hit = true;
+    }
+    return hit;
+}
+
+// Source::get(k, circle, x, y) returns the stored collision points; Source::tindex(k) is
+// round(t_k/dt) (== k for lattice candidates).
+// stat: [n_static] points; rows: transposed dynamic obstacles [T][S*P].
+// Returns true when the candidate violates the (chance) constraint.
+template <class Source>
+FOT_HD bool collide_candidate(const DevParams &P, const InstDesc &D, const d2 *stat, const d2 *rows,
+                              int keep, const Source &src)
+{
+    const int n_circ = P.has_footprint ? P.n_circ : 1;
+    if (D.n_static > 0) {
+        for (int k = 0; k < keep; ++k)
+            for (int ci = 0; ci < n_circ; ++ci) {
+                double px, py;
+                src.get(k, ci, px, py);
+                if (hits_row(stat, D.n_static, px, py, P.sq_r)) return true;
+            }
+    }
+    if (D.dyn_mode == FOT_DYN_NONE || D.P <= 0 || D.T <= 0) return false;
+    const double sq = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    const int SP = D.S * D.P;
+    uint64_t hit_mask = 0;
+    int viol = 0;
+    for (int k = 0; k < keep; ++k) {
+        int row = src.tindex(k);                                            // clip(round(t/dt), 0, T-1)
+        row = row < 0 ? 0 : (row > D.T - 1 ? D.T - 1 : row);
+        const d2 *r = rows + (int64_t)row * SP;
+        for (int ci = 0; ci < n_circ; ++ci) {
+            double px, py;
+            src.get(k, ci, px, py);
+            for (int s = 0; s < D.S; ++s) {
+                if ((hit_mask >> s) & 1) continue;
+                if (hits_row(r + s * D.P, D.P, px, py, sq)) {
+                    hit_mask |= (uint64_t)1 << s;
+                    if (++viol > D.max_viol) return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// selection (reference: frenet_planner.py:307-324, 1235-1259)
+// ---------------------------------------------------------------------------
+
+FOT_HD int final_status(int status, double v_last, double travel, double max_stop)
+{
+    if (status == FOT_ST_OK && !isnan(max_stop)) {
+        const bool stops = fabs(v_last) <= 0.15;                             // STOP_SPEED_EPS
+        if (!(stops && travel <= max_stop + 1e-6)) return FOT_ST_STOP_DISTANCE;
+    }
+    return status;
+}
+
+// decode candidate index -> (longitudinal profile slot, lateral time info, lateral target)
+struct CandDecode {
+    int lon_slot;          // index into the instance's longitudinal profiles
+    int brake;             // 1: brake-ladder entry
+    int ti;                // horizon index or brake index
+    double di;             // lateral target offset
+};
+
+FOT_HD CandDecode decode_candidate(const DevParams &P, const InstDesc &D, const double *fr, int idx)
+{
+    CandDecode c;
+    if (idx < D.n_grid) {
+        const int per_ti = D.n_tv * P.n_di;
+        const int ti = idx / per_ti, rem = idx - ti * per_ti;
+        const int itv = rem / P.n_di, idi = rem - itv * P.n_di;
+        c.lon_slot = ti * D.n_tv + itv;
+        c.brake = 0; c.ti = ti;
+        c.di = (double)(idi - P.n_side) * P.d_road_w;
+    } else {
+        const int b = idx - D.n_grid;
+        c.lon_slot = P.n_ti * D.n_tv + b;
+        c.brake = 1; c.ti = b;
+        c.di = fr[3];
+    }
+    return c;
+}
+
+// the 15 FrenetPath values of sample k of one candidate (data_structures.py:164-178 order)
+FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const double *lon_tab, const double *q, int k,
+                         double *o /*[15]*/)
+{
+    double s, sd, sdd, sddd, d, d_d, d_dd, d_ddd;
+    lon_sample(L, k, P.dt, s, sd, sdd, sddd);
+    lat_sample(q, k, L.n_eval, P.dt, d, d_d, d_dd, d_ddd);
+    LonSample ls;
+    load_lon_sample(lon_tab, k, ls);
+    CartSample c;
+    frenet_to_cart(ls, d, d_d, d_dd, c);
+    o[0] = (double)k * P.dt;
+    o[1] = ls.s; o[2] = ls.sd; o[3] = ls.sdd; o[4] = sddd;
+    o[5] = d; o[6] = d_d; o[7] = d_dd; o[8] = d_ddd;
+    o[9] = c.x; o[10] = c.y; o[11] = atan2(c.sin_t, c.cos_t);
+    o[12] = c.v; o[13] = c.a; o[14] = c.kappa;
+}
+
+}  // namespace fot

@@ -1,0 +1,327 @@
+"""Host side of the MI355X Frenet planner.
+
+``BatchPlanner`` owns one libfot handle (one GPU) and plans many independent
+ego/scenario instances per call.  ``FrenetPlanner`` keeps the call surface of the
+reference class (src/planning/frenet_planner.py:125-304) on top of it, so it
+drops into ``IntegratedSimulator`` (integrated_simulator.py:342-366, 576-584,
+622-630, 732, 802) unchanged.  All planning arithmetic runs in the gfx950
+kernels; nothing here computes a trajectory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .batch import PackedBatch, PlanRequest
+from .data_structures import EgoVehicleState, FrenetPath, FrenetState
+from .params import (D_ROAD_W, D_T_S, DT, MAX_ACCEL, MAX_CURVATURE, MAX_ROAD_WIDTH, MAX_SPEED, MAX_T, MIN_T,
+                     N_S_SAMPLE, ROBOT_RADIUS, TARGET_SPEED, make_params)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _as_dp(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def spline_arrays(path) -> List[np.ndarray]:
+    """Knots and CubicSpline1D coefficients of a CubicSpline2D-like object
+    (reference attributes: .s, .sx.{a,b,c,d}, .sy.{a,b,c,d}; cubic_spline.py:30-45, 201-204)."""
+    s = np.ascontiguousarray(np.asarray(path.s, dtype=np.float64))
+    out = [s]
+    for sp1 in (path.sx, path.sy):
+        for name in "abcd":
+            out.append(np.ascontiguousarray(np.asarray(getattr(sp1, name), dtype=np.float64)))
+    n = len(s)
+    want = [n, n, n - 1, n, n - 1, n, n - 1, n, n - 1]
+    for arr, w in zip(out, want):
+        if arr.shape != (w,):
+            raise ValueError(f"spline coefficient array has shape {arr.shape}, expected ({w},)")
+    return out
+
+
+class BatchResult:
+    """Results of one batch: the raw ``fot_result`` records plus convenient views."""
+
+    def __init__(self, records, n: int, with_stop: Sequence[bool]):
+        self.records = records
+        self.n = n
+        self._with_stop = list(with_stop)
+
+    def __len__(self):
+        return self.n
+
+    def status(self, i: int) -> int:
+        return int(self.records[i].status)
+
+    def stats(self, i: int) -> Optional[Dict[str, int]]:
+        """``last_check_stats`` of instance i (None where the reference leaves it None)."""
+        r = self.records[i]
+        if not r.stats_valid:
+            return None
+        d = {_abi.STATUS_NAMES[k]: int(r.stats[k]) for k in range(7)}
+        if self._with_stop[i]:
+            d["stop_distance_error"] = int(r.stats[7])
+        return d
+
+    def path(self, i: int) -> Optional[FrenetPath]:
+        r = self.records[i]
+        if r.status != _abi.PLAN_OK:
+            return None
+        n = int(r.n_keep)
+        fp = FrenetPath()
+        for f in _abi.PATH_FIELDS:
+            setattr(fp, f, np.ctypeslib.as_array(getattr(r, f))[:n].tolist())
+        fp.cost = float(r.cost)
+        return fp
+
+
+class BatchPlanner:
+    """One libfot handle: planner parameters + reference path on one GPU."""
+
+    def __init__(self, reference_path=None, waypoints=None, device: int = -1, **planner_kwargs):
+        self._lib = _abi.lib()
+        fp = planner_kwargs.pop("footprint", None)
+        if fp is not None:
+            planner_kwargs["footprint_offsets"] = np.asarray(fp.offsets, dtype=float).tolist()
+            planner_kwargs["footprint_radius"] = float(fp.radius)
+        self.params = make_params(**planner_kwargs)
+        h = C.c_void_p()
+        _abi.check(None, self._lib.fot_create(C.byref(self.params), int(device), C.byref(h)))
+        self._h = h
+        if reference_path is not None:
+            self.set_path(reference_path)
+        elif waypoints is not None:
+            self.set_waypoints(*waypoints)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fot_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference path ---------------------------------------------------
+    def set_path(self, path):
+        arrs = spline_arrays(path)
+        _abi.check(self._h, self._lib.fot_set_path_coeffs(self._h, len(arrs[0]), *[_as_dp(a) for a in arrs]))
+
+    def set_waypoints(self, wx, wy):
+        wx = np.ascontiguousarray(wx, dtype=np.float64)
+        wy = np.ascontiguousarray(wy, dtype=np.float64)
+        if wx.shape != wy.shape or wx.ndim != 1:
+            raise ValueError("waypoints must be two 1-D arrays of equal length")
+        _abi.check(self._h, self._lib.fot_set_path_waypoints(self._h, len(wx), _as_dp(wx), _as_dp(wy)))
+
+    def path_coeffs(self) -> List[np.ndarray]:
+        n = C.c_int32(0)
+        _abi.check(self._h, self._lib.fot_get_path_coeffs(self._h, C.byref(n), *([None] * 9)))
+        k = n.value
+        out = [np.zeros(k), np.zeros(k), np.zeros(k - 1), np.zeros(k), np.zeros(k - 1),
+               np.zeros(k), np.zeros(k - 1), np.zeros(k), np.zeros(k - 1)]
+        _abi.check(self._h, self._lib.fot_get_path_coeffs(self._h, C.byref(n), *[_as_dp(a) for a in out]))
+        return out
+
+    def spline_eval(self, s):
+        s = np.ascontiguousarray(np.atleast_1d(s), dtype=np.float64)
+        out = [np.zeros_like(s) for _ in range(5)]
+        _abi.check(self._h, self._lib.fot_spline_eval(self._h, len(s), _as_dp(s), *[_as_dp(a) for a in out]))
+        return out      # x, y, yaw, curvature, curvature_rate
+
+    # -- planning ---------------------------------------------------------
+    def plan_packed(self, pb: PackedBatch) -> BatchResult:
+        out = (_abi.Result * max(pb.n, 1))()
+        _abi.check(self._h, self._lib.fot_plan_batch(self._h, C.byref(pb.c), out))
+        return BatchResult(out, pb.n, [not np.isnan(v) for v in pb.max_stop[: pb.n]])
+
+    def plan_batch(self, requests: Sequence[PlanRequest], obstacle_dtype=np.float64) -> BatchResult:
+        return self.plan_packed(PackedBatch(requests, obstacle_dtype))
+
+    def plan_packed_device(self, batch_struct: _abi.Batch, out_dev_ptr: int, stream: Optional[int] = None):
+        """Obstacles and results resident in HBM; enqueues on ``stream`` and returns immediately."""
+        _abi.check(self._h, self._lib.fot_plan_batch_device(self._h, C.byref(batch_struct), C.c_void_p(out_dev_ptr),
+                                                            C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        _abi.check(self._h, self._lib.fot_synchronize(self._h))
+
+    def candidates(self, inst: int = 0, cap: int = 1 << 16):
+        """Per-candidate (cost, status, keep, n_t) of an instance of the last plan call."""
+        cost = np.zeros(cap)
+        status = np.zeros(cap, np.int32)
+        keep = np.zeros(cap, np.int32)
+        nt = np.zeros(cap, np.int32)
+        n = self._lib.fot_debug_candidates(self._h, inst, cap, _as_dp(cost), status.ctypes.data_as(_ip),
+                                           keep.ctypes.data_as(_ip), nt.ctypes.data_as(_ip))
+        if n < 0:
+            _abi.check(self._h, n)
+        n = min(n, cap)
+        return cost[:n], status[:n], keep[:n], nt[:n]
+
+    def frenet_states(self, egos: Sequence[PlanRequest]):
+        n = len(egos)
+        arr = (_abi.Ego * max(n, 1))()
+        for i, r in enumerate(egos):
+            e = arr[i]
+            e.x, e.y, e.yaw, e.v, e.a, e.last_kappa = r.x, r.y, r.yaw, r.v, r.a, r.last_kappa
+            e.has_prev_s = 0 if r.prev_s is None else 1
+            e.prev_s = 0.0 if r.prev_s is None else r.prev_s
+        fr = np.zeros((max(n, 1), 6))
+        ref = np.zeros((max(n, 1), 6))
+        nps = np.zeros(max(n, 1))
+        ok = np.zeros(max(n, 1), np.int32)
+        _abi.check(self._h, self._lib.fot_frenet_state_batch(self._h, n, arr, _as_dp(fr), _as_dp(ref), _as_dp(nps),
+                                                             ok.ctypes.data_as(_ip)))
+        return fr[:n], ref[:n], nps[:n], ok[:n]
+
+    def paths_collision_free(self, paths: Sequence, static=None, dyn=None, dist=None) -> np.ndarray:
+        """_path_is_collision_free (frenet_planner.py:1035-1047) for FrenetPath-like objects."""
+        n = len(paths)
+        X = np.zeros((max(n, 1), _abi.MAX_NT)); Y = np.zeros_like(X); W = np.zeros_like(X); Tm = np.zeros_like(X)
+        ln = np.zeros(max(n, 1), np.int32)
+        for i, fp in enumerate(paths):
+            m = min(len(fp.x), len(fp.t))                        # frenet_planner.py:1146
+            if m > _abi.MAX_NT:
+                raise ValueError(f"path longer than {_abi.MAX_NT} samples")
+            ln[i] = m
+            X[i, :m] = np.asarray(fp.x[:m], float); Y[i, :m] = np.asarray(fp.y[:m], float)
+            Tm[i, :m] = np.asarray(fp.t[:m], float)
+            yaw = np.asarray(fp.yaw[:m], float) if fp.yaw is not None else np.zeros(0)
+            if len(yaw) < m:                                     # :1158-1161 hold the last value
+                yaw = np.concatenate([yaw, np.full(m - len(yaw), yaw[-1] if len(yaw) else 0.0)])
+            W[i, :m] = yaw
+        req = PlanRequest(0, 0, 0, 0, 0, static=static, dyn=dyn, dist=dist)
+        pb = PackedBatch([req], np.float64)
+        mode, S, P, T = (int(v) for v in pb.dyn_dims[0])
+        free = np.zeros(max(n, 1), np.int32)
+        st = pb.static_xy
+        _abi.check(self._h, self._lib.fot_check_collision_paths(
+            self._h, n, ln.ctypes.data_as(_ip), _as_dp(X), _as_dp(Y), _as_dp(W), _as_dp(Tm),
+            int(st.shape[0]), _as_dp(st) if st.size else None, mode, S, P, T,
+            _as_dp(pb.dyn_xy) if pb.dyn_xy.size else None, free.ctypes.data_as(_ip)))
+        return free[:n].astype(bool)
+
+
+class _NearestPointState:
+    """Stands in for ``planner.converter`` of the reference: carries the cached arc length
+    (CoordinateConverter._prev_s, coordinate_converter.py:221, 283); absent until the first search."""
+
+    def __init__(self, path):
+        self.reference_path = path
+
+
+class FrenetPlanner:
+    """Drop-in for the reference's FrenetPlanner (frenet_planner.py:125-304) backed by libfot."""
+
+    def __init__(self, reference_path, max_speed: float = MAX_SPEED, max_accel: float = MAX_ACCEL,
+                 max_curvature: float = MAX_CURVATURE, dt: float = DT, d_road_w: float = D_ROAD_W,
+                 max_road_width: float = MAX_ROAD_WIDTH, robot_radius: float = ROBOT_RADIUS,
+                 obstacle_radius: float = 0.3, min_t: float = MIN_T, max_t: float = MAX_T, d_t_s: float = D_T_S,
+                 n_s_sample: int = N_S_SAMPLE, **kwargs):
+        self.csp = reference_path
+        self.max_speed = max_speed
+        self.max_accel = max_accel
+        self.max_curvature = max_curvature
+        self.max_lat_accel = float(kwargs.get("max_lat_accel", 3.0))
+        self.dt = dt
+        self.d_road_w = d_road_w
+        self.max_road_width = max_road_width
+        self.robot_radius = robot_radius
+        self.obstacle_radius = obstacle_radius
+        self.min_t = min_t
+        self.max_t = max_t
+        self.d_t_s = d_t_s
+        self.n_s_sample = n_s_sample
+        self.k_j = kwargs.get("k_j", 0.1)
+        self.k_t = kwargs.get("k_t", 0.1)
+        self.k_d = kwargs.get("k_d", 1.0)
+        self.k_s_dot = kwargs.get("k_s_dot", 1.0)
+        self.k_lat = kwargs.get("k_lat", 1.0)
+        self.k_lon = kwargs.get("k_lon", 1.0)
+        self.chance_epsilon = float(kwargs.get("chance_epsilon", 0.0))
+        self.collision_margin_inflation = float(kwargs.get("collision_margin_inflation", 1.0))
+        self.footprint = kwargs.get("footprint", None)
+        self.converter = _NearestPointState(reference_path)
+        self._last_kappa = 0.0
+        self.last_check_stats = None
+        self._engine = BatchPlanner(
+            reference_path=reference_path, device=int(kwargs.get("device", -1)),
+            max_speed=max_speed, max_accel=max_accel, max_curvature=max_curvature, dt=dt, d_road_w=d_road_w,
+            max_road_width=max_road_width, robot_radius=robot_radius, obstacle_radius=obstacle_radius, min_t=min_t,
+            max_t=max_t, d_t_s=d_t_s, max_lat_accel=self.max_lat_accel, k_j=self.k_j, k_t=self.k_t, k_d=self.k_d,
+            k_s_dot=self.k_s_dot, k_lat=self.k_lat, k_lon=self.k_lon, chance_epsilon=self.chance_epsilon,
+            collision_margin_inflation=self.collision_margin_inflation, footprint=self.footprint)
+
+    @property
+    def engine(self) -> BatchPlanner:
+        return self._engine
+
+    def _request(self, ego_state, static_obstacles, dynamic_obstacles, target_speed, constraint_overrides,
+                 dynamic_obstacles_distribution, max_stop_distance) -> PlanRequest:
+        return PlanRequest(
+            x=float(ego_state.x), y=float(ego_state.y), yaw=float(ego_state.yaw), v=float(ego_state.v),
+            a=float(ego_state.a), target_speed=float(target_speed), last_kappa=float(self._last_kappa),
+            prev_s=getattr(self.converter, "_prev_s", None), overrides=constraint_overrides or None,
+            max_stop_distance=max_stop_distance, static=static_obstacles, dyn=dynamic_obstacles,
+            dist=dynamic_obstacles_distribution)
+
+    def plan(self, ego_state: EgoVehicleState, static_obstacles: np.ndarray,
+             dynamic_obstacles: Optional[np.ndarray] = None, target_speed: float = TARGET_SPEED,
+             constraint_overrides: Optional[Dict[str, float]] = None,
+             dynamic_obstacles_distribution: Optional[np.ndarray] = None,
+             max_stop_distance: Optional[float] = None) -> Optional[FrenetPath]:
+        """Same contract as the reference (frenet_planner.py:227-304): best path or None; never
+        raises on "no path"; updates last_check_stats, _last_kappa and the nearest-point cache."""
+        self.last_check_stats = None
+        req = self._request(ego_state, static_obstacles, dynamic_obstacles, target_speed, constraint_overrides,
+                            dynamic_obstacles_distribution, max_stop_distance)
+        res = self._engine.plan_batch([req])
+        rec = res.records[0]
+        if not np.isnan(rec.new_prev_s):
+            self.converter._prev_s = float(rec.new_prev_s)
+        self.last_check_stats = res.stats(0)
+        path = res.path(0)
+        if path is not None:
+            self._last_kappa = float(rec.new_last_kappa)
+        return path
+
+    def reset_ego_curvature(self):
+        self._last_kappa = 0.0
+
+    # -- stages the reference's tests reach into ---------------------------
+    def _cartesian_to_frenet_state(self, ego_state) -> Optional[FrenetState]:
+        req = PlanRequest(ego_state.x, ego_state.y, ego_state.yaw, ego_state.v, ego_state.a,
+                          last_kappa=self._last_kappa, prev_s=getattr(self.converter, "_prev_s", None))
+        fr, _ref, nps, ok = self._engine.frenet_states([req])
+        if not np.isnan(nps[0]):
+            self.converter._prev_s = float(nps[0])
+        if not ok[0]:
+            return None
+        return FrenetState(*[float(v) for v in fr[0]])
+
+    def _path_is_collision_free(self, fp, static_obstacles, dynamic_obstacles, dynamic_distribution) -> bool:
+        return bool(self._engine.paths_collision_free([fp], static_obstacles, dynamic_obstacles,
+                                                      dynamic_distribution)[0])
+
+    def _check_collision(self, fp, static_obstacles, dynamic_obstacles=None) -> bool:
+        return self._path_is_collision_free(fp, static_obstacles, dynamic_obstacles, None)
+
+    def _check_collision_distribution(self, fp, static_obstacles, dynamic_distribution, epsilon=None) -> bool:
+        if epsilon is not None and float(epsilon) != self.chance_epsilon:
+            raise ValueError("epsilon is fixed at construction (chance_epsilon)")
+        if dynamic_distribution is None or np.size(dynamic_distribution) == 0:
+            return self._path_is_collision_free(fp, static_obstacles, None, None)
+        return self._path_is_collision_free(fp, static_obstacles, None, dynamic_distribution)
+
+    def candidate_table(self):
+        """(cost, status, keep, n_t) per candidate of the last plan() call (diagnostic)."""
+        return self._engine.candidates(0)

@@ -1,0 +1,187 @@
+// fot_emu.cpp -- TEST-ONLY host emulation of the kernel pipeline.
+//
+// Runs the SAME arithmetic headers the gfx950 kernels are built from
+// (csrc/fot_math.hpp, csrc/fot_setup.hpp) with plain loops in place of the
+// launch grid, so that the planner logic can be checked against the oracle in
+// the build container, where there is no GPU.  It is compiled by
+// tests/test_emu_logic.py into tests/emu/_build/ and is never loaded by the
+// product (integrated_path_planning_amd/), which only ever drives libfot.so.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../integrated_path_planning_amd/csrc/fot_math.hpp"
+#include "../../integrated_path_planning_amd/csrc/fot_setup.hpp"
+
+using namespace fot;
+
+namespace {
+struct VecSink {
+    std::vector<d2> *pts; int n_total;
+    void put(int k, int ci, double x, double y) { d2 v; v.x = x; v.y = y; (*pts)[(size_t)ci * n_total + k] = v; }
+};
+struct VecSource {
+    const std::vector<d2> *pts; int n_total;
+    void get(int k, int ci, double &x, double &y) const { const d2 &v = (*pts)[(size_t)ci * n_total + k]; x = v.x; y = v.y; }
+    int tindex(int k) const { return k; }
+};
+}  // namespace
+
+extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const double *wx, const double *wy,
+                              const fot_batch *b, fot_result *out,
+                              int cand_cap, double *cand_cost, int32_t *cand_status, int32_t *cand_keep, char *errbuf)
+{
+    std::string err;
+    DevParams P;
+    int rc = build_dev_params(*params, P, err);
+    HostSpline hs;
+    if (rc == FOT_OK) rc = build_spline(n_knots, wx, wy, hs, err);
+    BatchLayout L;
+    if (rc == FOT_OK) rc = build_batch_layout(*params, P, *b, L, err);
+    if (rc != FOT_OK) { if (errbuf) std::strncpy(errbuf, err.c_str(), 255); return rc; }
+    SplineView sp;
+    sp.n = hs.n; sp.s = hs.s.data();
+    sp.ax = hs.ax.data(); sp.bx = hs.bx.data(); sp.cx = hs.cx.data(); sp.dx = hs.dx.data();
+    sp.ay = hs.ay.data(); sp.by = hs.by.data(); sp.cy = hs.cy.data(); sp.dy = hs.dy.data();
+
+    // --- obstacle preparation (k_prep_static / k_prep_dyn)
+    std::vector<d2> stat((size_t)L.n_static + 1), rows((size_t)L.n_dyn_points + 1);
+    auto coord = [&](const void *base, int64_t i) -> double {
+        return b->obstacle_dtype == FOT_F32 ? (double)((const float *)base)[i] : ((const double *)base)[i];
+    };
+    for (int64_t i = 0; i < L.n_static; ++i) { stat[i].x = coord(b->static_xy, 2 * i); stat[i].y = coord(b->static_xy, 2 * i + 1); }
+    for (int inst = 0; inst < L.n_inst; ++inst) {
+        const InstDesc &D = L.desc[inst];
+        if (D.dyn_mode == FOT_DYN_NONE) continue;
+        const int SP = D.S * D.P;
+        for (int64_t o = 0; o < (int64_t)SP * D.T; ++o) {
+            const int k = (int)(o / SP), spi = (int)(o - (int64_t)k * SP);
+            const int64_t in = D.dyn_off + (int64_t)spi * D.T + k;
+            rows[D.row_off + o].x = coord(b->dyn_xy, 2 * in);
+            rows[D.row_off + o].y = coord(b->dyn_xy, 2 * in + 1);
+        }
+    }
+
+    std::memset(out, 0, sizeof(fot_result) * (size_t)L.n_inst);
+    std::vector<LonInfo> lon_info((size_t)L.n_lon + 1);
+    std::vector<double> lon_tab((size_t)(L.n_lon + 1) * LON_FIELDS * FOT_MAX_NT, 0.0);
+    for (int inst = 0; inst < L.n_inst; ++inst) {
+        const InstDesc &D = L.desc[inst];
+        fot_result &R = out[inst];
+        // --- k_frenet_state (nlanes = 1)
+        InstState S;
+        const double x = D.ego.x, y = D.ego.y, s_end = sp.s[sp.n - 1];
+        double best_s = 0.0;
+        bool need_global = true;
+        if (D.ego.has_prev_s) {
+            const double s_min = fmax(0.0, D.ego.prev_s - 10.0), s_max = fmin(s_end, D.ego.prev_s + 10.0);
+            ScanBest bb = scan_samples(sp, x, y, s_min, s_max, 100, 0, 1, false);
+            best_s = bb.idx >= 0 ? linspace_at(s_min, s_max, 100, bb.idx) : 0.0;
+            need_global = (fabs(best_s - s_min) < 1e-3 && s_min > 0.0) || (fabs(best_s - s_max) < 1e-3 && s_max < s_end);
+        }
+        const int n_glob = global_search_count(sp);
+        if (need_global) {
+            ScanBest bb = scan_samples(sp, x, y, 0.0, s_end, n_glob, 0, 1, true);
+            best_s = linspace_at(0.0, s_end, n_glob, bb.idx >= 0 ? bb.idx : 0);
+        }
+        best_s = refine_nearest(sp, x, y, best_s);
+        S.new_prev_s = best_s;
+        bool ok = frenet_state_at(sp, D.ego, best_s, S.frenet0, S.ref0);
+        S.c2f_ok = ok;
+        S.n_brake = (ok && S.frenet0[1] > 0.1) ? P.n_brake : 0;
+        S.n_cand = ok ? D.n_grid + S.n_brake : 0;
+        if (!ok) {
+            R.status = FOT_PLAN_C2F_FAILED; R.best_index = -1; R.cost = INFINITY;
+            R.new_last_kappa = D.ego.last_kappa; R.new_prev_s = S.new_prev_s;
+            continue;
+        }
+        // --- k_lon_table
+        const int n_grid_lon = P.n_ti * D.n_tv;
+        for (int slot = 0; slot < n_grid_lon + S.n_brake; ++slot) {
+            LonInfo Li;
+            if (slot < n_grid_lon) {
+                const int ti = slot / D.n_tv, itv = slot - ti * D.n_tv;
+                lon_coeffs(S.frenet0, tv_value(P, D, itv), P.ti[ti], Li);
+                Li.n_t = P.ti[ti].n_t; Li.n_eval = Li.n_t;
+            } else {
+                const TimeInfo &tb = P.brake[slot - n_grid_lon];
+                lon_coeffs(S.frenet0, 0.0, tb, Li);
+                Li.n_t = P.n_total; Li.n_eval = tb.n_t;
+            }
+            double *tab = lon_tab.data() + (size_t)(D.lon_off + slot) * (LON_FIELDS * FOT_MAX_NT);
+            double js = 0.0, sd_last = 0.0;
+            for (int k = 0; k < Li.n_t; ++k) {
+                LonSample ls; double sddd;
+                make_lon_sample(sp, Li, k, P.dt, ls, sddd);
+                tab[0 * FOT_MAX_NT + k] = ls.s; tab[1 * FOT_MAX_NT + k] = ls.sd; tab[2 * FOT_MAX_NT + k] = ls.sdd;
+                tab[3 * FOT_MAX_NT + k] = ls.rx; tab[4 * FOT_MAX_NT + k] = ls.ry;
+                tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
+                tab[7 * FOT_MAX_NT + k] = ls.kr; tab[8 * FOT_MAX_NT + k] = ls.dkr; tab[9 * FOT_MAX_NT + k] = sddd;
+                js += sddd * sddd; sd_last = ls.sd;
+            }
+            Li.Js = js; Li.sd_last = sd_last;
+            lon_info[D.lon_off + slot] = Li;
+        }
+        // --- k_evaluate + k_collide + k_select
+        int cnt[8] = { 0 };
+        ScanBest best = { INFINITY, -1 };
+        int best_keep = 0;
+        std::vector<d2> pts((size_t)P.n_circ * P.n_total);
+        for (int idx = 0; idx < S.n_cand; ++idx) {
+            const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+            const LonInfo &Li = lon_info[D.lon_off + cd.lon_slot];
+            const double *tab = lon_tab.data() + (size_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+            double q[6];
+            lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+            VecSink sink = { &pts, P.n_total };
+            CandResult r;
+            evaluate_candidate(P, D, Li, tab, q, sink, r);
+            int st = r.status;
+            if (st == ST_PENDING) {
+                VecSource src = { &pts, P.n_total };
+                if (collide_candidate(P, D, stat.data() + D.static_off, rows.data() + D.row_off, r.keep, src))
+                    st = FOT_ST_COLLISION;
+            }
+            st = final_status(st, r.v_last, r.travel, D.max_stop);
+            if (st < 8) cnt[st]++;
+            if (idx < cand_cap && inst == 0) {
+                if (cand_cost) cand_cost[idx] = r.cost;
+                if (cand_status) cand_status[idx] = st;
+                if (cand_keep) cand_keep[idx] = r.keep;
+            }
+            if (st == FOT_ST_OK && r.cost < best.dist) { best.dist = r.cost; best.idx = idx; best_keep = r.keep; }
+        }
+        R.status = best.idx >= 0 ? FOT_PLAN_OK : FOT_PLAN_NO_PATH;
+        R.best_index = best.idx; R.n_cand = S.n_cand; R.cost = best.idx >= 0 ? best.dist : INFINITY;
+        for (int c = 0; c < 8; ++c) R.stats[c] = cnt[c];
+        R.stats_valid = 1; R.new_prev_s = S.new_prev_s; R.new_last_kappa = D.ego.last_kappa;
+        std::memcpy(R.frenet0, S.frenet0, sizeof(double) * 6);
+        std::memcpy(R.ref0, S.ref0, sizeof(double) * 6);
+        if (best.idx >= 0) {
+            const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
+            const LonInfo &Li = lon_info[D.lon_off + cd.lon_slot];
+            const double *tab = lon_tab.data() + (size_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+            double q[6];
+            lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+            R.n_keep = best_keep;
+            double *dst[15] = { R.t, R.s, R.s_d, R.s_dd, R.s_ddd, R.d, R.d_d, R.d_dd, R.d_ddd, R.x, R.y, R.yaw, R.v, R.a, R.c };
+            for (int k = 0; k < best_keep; ++k) {
+                double o[15];
+                final_sample(P, Li, tab, q, k, o);
+                for (int f = 0; f < 15; ++f) dst[f][k] = o[f];
+            }
+            if (best_keep > 1) R.new_last_kappa = R.c[1];
+        }
+    }
+    return FOT_OK;
+}
+
+extern "C" int emu_spline(int n, const double *wx, const double *wy, double *out9n)
+{
+    HostSpline hs; std::string err;
+    int rc = build_spline(n, wx, wy, hs, err);
+    if (rc) return rc;
+    const std::vector<double> *src[9] = { &hs.s, &hs.ax, &hs.bx, &hs.cx, &hs.dx, &hs.ay, &hs.by, &hs.cy, &hs.dy };
+    for (int f = 0; f < 9; ++f) for (int i = 0; i < n; ++i) out9n[f * n + i] = (*src[f])[i];
+    return 0;
+}

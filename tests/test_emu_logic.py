@@ -1,0 +1,105 @@
+"""Planner logic of the kernel headers, checked on the CPU.
+
+tests/emu/fot_emu.cpp runs csrc/fot_math.hpp + csrc/fot_setup.hpp (the code the
+gfx950 kernels are compiled from) with loops instead of a launch grid.  It is
+compared here with the reference's golden vectors, so arithmetic/logic errors
+surface without a GPU.  The GPU parity tests proper are tests/test_gpu_*.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, wrap_angle
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.batch import PackedBatch, PlanRequest
+from integrated_path_planning_amd.params import make_params
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "_build", "libfot_emu.so")
+CSRC = os.path.join(ROOT, "integrated_path_planning_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    srcs = [os.path.join(EMU_DIR, "fot_emu.cpp")] + [os.path.join(CSRC, f) for f in
+                                                      ("fot_math.hpp", "fot_setup.hpp", "fot_types.h")]
+    if not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", EMU_SO, srcs[0]],
+                       check=True)
+    L = C.CDLL(EMU_SO)
+    dp = C.POINTER(C.c_double)
+    L.emu_plan_batch.argtypes = [C.POINTER(_abi.Params), C.c_int, dp, dp, C.POINTER(_abi.Batch),
+                                 C.POINTER(_abi.Result), C.c_int, dp, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.c_char_p]
+    L.emu_spline.argtypes = [C.c_int, dp, dp, dp]
+    return L
+
+
+def request_from_golden(g):
+    m = g.meta
+    e = m["ego"]
+    return PlanRequest(x=e[0], y=e[1], yaw=e[2], v=e[3], a=e[4], target_speed=m["target_speed"],
+                       last_kappa=m["last_kappa"], prev_s=m["prev_s"], overrides=m["overrides"],
+                       max_stop_distance=m["max_stop"], static=g.static, dyn=g.dyn, dist=g.dist)
+
+
+def run_emu(emu, g):
+    params = make_params(**g.planner_kwargs())
+    pb = PackedBatch([request_from_golden(g)])
+    wx = np.ascontiguousarray(g["wx"]); wy = np.ascontiguousarray(g["wy"])
+    out = (_abi.Result * 1)()
+    cap = 4096
+    cost = np.zeros(cap); status = np.zeros(cap, np.int32); keep = np.zeros(cap, np.int32)
+    err = C.create_string_buffer(256)
+    dp = C.POINTER(C.c_double)
+    rc = emu.emu_plan_batch(C.byref(params), len(wx), wx.ctypes.data_as(dp), wy.ctypes.data_as(dp), C.byref(pb.c),
+                            out, cap, cost.ctypes.data_as(dp), status.ctypes.data_as(C.POINTER(C.c_int32)),
+                            keep.ctypes.data_as(C.POINTER(C.c_int32)), err)
+    assert rc == 0, err.value
+    n = out[0].n_cand
+    return out[0], cost[:n], status[:n], keep[:n]
+
+
+def test_native_spline_fit(emu, golden):
+    wx = np.ascontiguousarray(golden["wx"]); wy = np.ascontiguousarray(golden["wy"])
+    n = len(wx)
+    out = np.zeros(9 * n)
+    dp = C.POINTER(C.c_double)
+    assert emu.emu_spline(n, wx.ctypes.data_as(dp), wy.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    out = out.reshape(9, n)
+    for f, key in enumerate(["sp_s", "sp_ax", "sp_bx", "sp_cx", "sp_dx", "sp_ay", "sp_by", "sp_cy", "sp_dy"]):
+        want = golden[key]
+        np.testing.assert_allclose(out[f, :len(want)], want, rtol=1e-10, atol=1e-11, err_msg=key)
+
+
+def test_kernel_logic_matches_reference(emu, golden):
+    r, cost, status, keep = run_emu(emu, golden)
+    g = golden
+    np.testing.assert_allclose(np.array(r.frenet0[:]), g["frenet0"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(r.new_prev_s, float(g["prev_s_after"]), atol=1e-12)
+    assert r.n_cand == len(g["cand_cost"])
+    np.testing.assert_array_equal(keep, g["cand_keep"])
+    np.testing.assert_allclose(cost, g["cand_cost"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(status, g["cand_status"].astype(np.int32))
+    stats = g["stats"]
+    for i in range(8):
+        assert r.stats[i] == max(int(stats[i]), 0), _abi.STATUS_NAMES[i]
+    bi = int(g["best_index"])
+    assert r.best_index == bi
+    if bi < 0:
+        assert r.status == _abi.PLAN_NO_PATH
+        return
+    assert r.status == _abi.PLAN_OK and r.n_keep == len(g["best_x"])
+    np.testing.assert_allclose(r.cost, float(g["best_cost"]), rtol=1e-9)
+    for f in _abi.PATH_FIELDS:
+        got = np.array(getattr(r, f)[: r.n_keep])
+        want = g["best_" + f]
+        if f == "yaw":
+            np.testing.assert_allclose(wrap_angle(got - want), 0.0, atol=1e-9)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8, err_msg=f)
+    np.testing.assert_allclose(r.new_last_kappa, float(g["last_kappa_after"]), rtol=1e-8, atol=1e-9)

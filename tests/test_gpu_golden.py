@@ -1,0 +1,60 @@
+"""GPU parity: libfot (through the C ABI) against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+from helpers import TIGHT, request_from_golden, wrap_angle
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.planner import BatchPlanner
+
+pytestmark = pytest.mark.gpu
+
+
+def _planner(g):
+    kw = g.planner_kwargs()
+    return BatchPlanner(waypoints=(g["wx"], g["wy"]), **kw)
+
+
+def test_golden_case(golden):
+    g = golden
+    bp = _planner(g)
+    res = bp.plan_batch([request_from_golden(g)])
+    r = res.records[0]
+    np.testing.assert_allclose(np.array(r.frenet0[:]), g["frenet0"], rtol=TIGHT, atol=TIGHT)
+    np.testing.assert_allclose(np.array(r.ref0[:]), g["ref0"], rtol=TIGHT, atol=TIGHT)
+    np.testing.assert_allclose(r.new_prev_s, float(g["prev_s_after"]), atol=1e-9)
+
+    cost, status, keep, nt = bp.candidates(0)
+    assert len(cost) == len(g["cand_cost"]) == r.n_cand
+    np.testing.assert_array_equal(nt, g["cand_nt"])
+    np.testing.assert_array_equal(keep, g["cand_keep"])
+    np.testing.assert_allclose(cost, g["cand_cost"], rtol=TIGHT, atol=TIGHT)
+    np.testing.assert_array_equal(status, g["cand_status"].astype(np.int32))
+
+    stats = g["stats"]
+    want = {_abi.STATUS_NAMES[i]: int(stats[i]) for i in range(8) if stats[i] >= 0}
+    assert res.stats(0) == want
+    bi = int(g["best_index"])
+    assert r.best_index == bi
+    path = res.path(0)
+    if bi < 0:
+        assert path is None and r.status == _abi.PLAN_NO_PATH
+        assert r.new_last_kappa == g.meta["last_kappa"]
+        return
+    np.testing.assert_allclose(path.cost, float(g["best_cost"]), rtol=TIGHT)
+    for f in _abi.PATH_FIELDS:
+        got = np.array(getattr(path, f))
+        exp = g["best_" + f]
+        assert len(got) == len(exp), f
+        if f == "yaw":
+            np.testing.assert_allclose(wrap_angle(got - exp), 0.0, atol=TIGHT)
+        else:
+            np.testing.assert_allclose(got, exp, rtol=TIGHT, atol=TIGHT, err_msg=f)
+    np.testing.assert_allclose(r.new_last_kappa, float(g["last_kappa_after"]), rtol=TIGHT, atol=TIGHT)
+
+
+def test_spline_matches_reference(golden):
+    g = golden
+    bp = _planner(g)
+    got = bp.path_coeffs()
+    for arr, key in zip(got, ["sp_s", "sp_ax", "sp_bx", "sp_cx", "sp_dx", "sp_ay", "sp_by", "sp_cy", "sp_dy"]):
+        np.testing.assert_allclose(arr, g[key], rtol=1e-10, atol=1e-11, err_msg=key)
