@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate trajectories / second of the MI355X Frenet planner.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (obstacle preparation -> Frenet state ->
+lattice -> Frenet->Cartesian + checks -> collision -> argmin -> selected paths)
+over one batch of synthetic instances whose obstacle tensors are already
+resident in HBM.  Workload per GPU = BASELINE.json config 4: 256 independent ego
+instances, each a 2240-candidate lattice (5 s horizon, dt = 0.1 s) checked
+against a 20-sample x 30-pedestrian x 51-step prediction distribution (fp32).
+For N > 1 every rank plans its own 256 instances (weak scaling) and the selected
+path records are all-gathered with RCCL inside the step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra
+objects "roofline" (dominant kernel, measured with HIP events on its stream
+inside the timed region) and "cpu_baseline" (the CPU oracle on this host).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, MI355X_MICROARCH.md "HBM3E peak BW"
+VALU_FP64_PEAK_TF = 78.6       # fp64 vector peak = half the 157.3 TF fp32 vector peak
+# algorithmic HBM bytes and nominal flops per candidate of config 3/4/5
+B_ALG = 119.0
+F_ALG = 147.2e3
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--instances-per-gpu", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-instances", type=int, default=256,
+                    help="instances of the same workload timed on the CPU oracle (~53 ms each)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from integrated_path_planning_amd import _abi, synthetic as syn
+    from integrated_path_planning_amd.batch import PackedBatch
+    from integrated_path_planning_amd.planner import BatchPlanner
+    from helpers import request_from_instance
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    n_inst = args.instances_per_gpu
+    seeds = range(rank * n_inst, (rank + 1) * n_inst)
+    kw = syn.CONFIG3_PLANNER
+    reqs = [request_from_instance(syn.config3_instance(s)) for s in seeds]
+    pb = PackedBatch(reqs, obstacle_dtype=np.float32)
+    bp = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **kw)
+
+    # obstacle tensors + result records resident in HBM (torch = device memory + streams only)
+    dyn_dev = torch.from_numpy(pb.dyn_xy).to(dev)
+    static_dev = torch.from_numpy(pb.static_xy).to(dev) if pb.static_xy.size else None
+    out_dev = torch.zeros(n_inst * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * n_inst * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev) if world > 1 else None
+    bstruct = pb.with_device_obstacles(static_dev.data_ptr() if static_dev is not None else None, dyn_dev.data_ptr())
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out_dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    bp.profile(True)
+    bp.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = bp.profile_read(reset=True)
+    bp.profile(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # candidates actually generated (from the result records)
+    recs_host = out_dev.cpu().numpy()
+    recs = (_abi.Result * n_inst).from_buffer_copy(recs_host.tobytes())
+    cand_local = sum(int(r.n_cand) for r in recs)
+    cand_total = torch.tensor([cand_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(cand_total)
+    cand_total = int(cand_total.item())
+    value = cand_total * args.steps / elapsed
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events on its stream, inside the timed region)
+    dom = max(prof, key=lambda k: prof[k]["total_ms"])
+    dom_ms = prof[dom]["total_ms"] / max(prof[dom]["launches"], 1)
+    alg_bytes = B_ALG * cand_local                       # per launch: one launch = this rank's whole batch
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
+                "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes}
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    valu = {"kernel": dom, "bound": "valu_fp64", "achieved": F_ALG * cand_local / (dom_ms * 1e-3) / 1e12,
+            "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s"}
+    valu["frac"] = valu["achieved"] / valu["peak"]
+    kernels = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items() if v["launches"]}
+
+    # ---- parity spot check against the oracle (checker only, outside the timed region)
+    from oracle import oracle as orc
+    from helpers import assert_record_matches_oracle, oracle_plan_for_request
+    oparams = orc.make_params(**kw)
+    osp = orc.Spline(syn.STRAIGHT_WX, syn.STRAIGHT_WY)
+    n_check = min(4, n_inst)
+    for i in range(n_check):
+        assert_record_matches_oracle(recs[i], oracle_plan_for_request(orc, oparams, osp, reqs[i]), label=f"inst {i}")
+
+    # ---- CPU baseline: the oracle (a C port of the reference algorithm), single thread, bounded sample
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        n_cpu = min(args.cpu_instances, n_inst)
+        t1 = time.perf_counter()
+        n_c = 0
+        for i in range(n_cpu):
+            n_c += oracle_plan_for_request(orc, oparams, osp, reqs[i]).n_cand
+        dt_cpu = time.perf_counter() - t1
+        cpu = {"value": n_c / dt_cpu, "unit": "candidates/s", "cores": 1, "kind": "port",
+               "sample": f"first {n_cpu} instances of the same batch, oracle/fot_oracle.c single thread, "
+                         f"{dt_cpu:.1f} s; host has {os.cpu_count()} logical cores"}
+
+    # ---- plan-step latency for one ego through the host-pointer API (H2D + kernels + D2H)
+    latency = None
+    host_api = None
+    if not args.no_latency and world == 1:
+        latency = {}
+        for name, pk, mk in (("config2", syn.CONFIG2_PLANNER, syn.config2_instance),
+                             ("config3", syn.CONFIG3_PLANNER, syn.config3_instance)):
+            p1 = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **pk)
+            packed = [PackedBatch([request_from_instance(mk(s))], np.float32) for s in range(8)]
+            for b in packed:
+                p1.plan_packed(b)
+            ts = []
+            for it in range(400):
+                t1 = time.perf_counter()
+                p1.plan_packed(packed[it % 8])
+                ts.append(time.perf_counter() - t1)
+            ts = np.array(ts) * 1e3
+            latency[name] = {"p50_ms": float(np.percentile(ts, 50)), "p95_ms": float(np.percentile(ts, 95)),
+                             "calls": len(ts)}
+            p1.close()
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            bp.plan_packed(pb)
+            ts.append(time.perf_counter() - t1)
+        host_api = {"candidates_per_s": cand_local / float(np.median(ts)),
+                    "note": "fot_plan_batch with pageable host buffers: H2D of the obstacle tensors and D2H of the records included"}
+
+    line = {
+        "metric": "candidate trajectories/sec", "value": value, "unit": "candidates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "config4: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "
+                               "20-sample x 30-pedestrian x 51-step fp32 prediction distribution, eps=0" % n_inst,
+                   "instances_per_gpu": n_inst, "candidates_per_step": cand_total,
+                   "parallelism": "instances sharded over %d GPU(s), RCCL all-gather of %d-byte path records"
+                                  % (world, _abi.RESULT_BYTES)},
+        "roofline": roofline, "roofline_valu": valu, "kernel_ms": kernels,
+        "cpu_baseline": cpu, "latency": latency, "host_api": host_api,
+        "parity": {"instances_checked_against_oracle": n_check, "ok": True},
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,16 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
                               int32_t mode, int32_t S, int32_t P, int32_t T, const double *dyn,
                               int32_t *free_out);
 
+/* ---- measurement (no reference counterpart: the reference times plan() with perf_counter,
+ *      integrated_simulator.py:575-585) ----
+ * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the
+ * stream it is launched on.  fot_profile_read waits for the recorded work, then returns, per
+ * kernel, the number of launches and the summed device time in ms since the last reset. */
+#define FOT_PROFILE_KERNELS 7
+int fot_profile_enable(fot_handle *h, int on);
+int fot_profile_read(fot_handle *h, int reset, int32_t *launches, double *total_ms);
+const char *fot_profile_kernel_name(int index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,13 @@ struct fot_handle {
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
     BatchLayout last;                        // layout of the most recent plan call
     bool last_valid = false;
+    // profiling: event pairs around kernel launches
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_pool;       // all events ever created
+    size_t prof_used = 0;                    // events handed out since the last read
+    std::vector<int> prof_kernel;            // kernel id of pair i (events 2i, 2i+1)
+    int32_t prof_launches[FOT_PROFILE_KERNELS] = { 0 };
+    double prof_ms[FOT_PROFILE_KERNELS] = { 0 };
     std::string err;
 };
 
@@ -122,6 +129,46 @@ int upload_spline(fot_handle *h)
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_prep_static", "k_prep_dyn", "k_frenet_state",
+                                                        "k_lon_table", "k_evaluate", "k_collide", "k_select" };
+
+// accumulate finished event pairs into the per-kernel totals (waits for them)
+int prof_drain(fot_handle *h)
+{
+    for (size_t i = 0; i < h->prof_kernel.size(); ++i) {
+        hipEvent_t a = h->prof_pool[2 * i], b = h->prof_pool[2 * i + 1];
+        HIP_TRY(h, hipEventSynchronize(b));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, a, b));
+        h->prof_launches[h->prof_kernel[i]] += 1;
+        h->prof_ms[h->prof_kernel[i]] += (double)ms;
+    }
+    h->prof_kernel.clear();
+    h->prof_used = 0;
+    return FOT_OK;
+}
+
+// brackets one launch with events when profiling is on
+struct ProfScope {
+    fot_handle *h; hipStream_t st; hipEvent_t stop = nullptr; bool active = false;
+    ProfScope(fot_handle *h_, int kernel, hipStream_t st_) : h(h_), st(st_)
+    {
+        if (!h->prof_on) return;
+        while (h->prof_pool.size() < h->prof_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            h->prof_pool.push_back(e);
+        }
+        hipEvent_t start = h->prof_pool[h->prof_used];
+        stop = h->prof_pool[h->prof_used + 1];
+        if (hipEventRecord(start, st) != hipSuccess) return;
+        h->prof_used += 2;
+        h->prof_kernel.push_back(kernel);
+        active = true;
+    }
+    ~ProfScope() { if (active) (void)hipEventRecord(stop, st); }
+};
 
 // Stage descriptors, size the workspace and enqueue the whole pipeline on `st`.
 // d_static / d_dyn are device pointers to the caller's obstacle coordinates, d_out a device fot_result[n_inst].
@@ -179,19 +226,40 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     ca.cost = h->dCost.as<double>(); ca.v_last = h->dVlast.as<double>(); ca.travel = h->dTravel.as<double>();
     ca.status = h->dStatus.as<uint8_t>(); ca.keep = h->dKeep.as<uint8_t>();
 
-    LAUNCH_TRY(h, launch_prep_static(d_static, b.obstacle_dtype, h->dStat.as<d2>(), L.n_static, st));
-    LAUNCH_TRY(h, launch_prep_dyn(d_desc, L.n_inst, L.max_dyn_points, d_dyn, b.obstacle_dtype, h->dRows.as<d2>(), st));
-    LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, h->dState.as<InstState>(), L.n_inst, st));
-    LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
-                                   h->dLonTab.as<double>(), L.n_inst, L.max_lon, st));
-    LAUNCH_TRY(h, launch_evaluate(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
-                                  h->dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
-                                  h->dPts.as<d2>(), st));
-    if (L.n_static > 0 || L.n_dyn_points > 0)
+    if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
+    if (L.n_static > 0) {
+        ProfScope ps(h, 0, st);
+        LAUNCH_TRY(h, launch_prep_static(d_static, b.obstacle_dtype, h->dStat.as<d2>(), L.n_static, st));
+    }
+    if (L.n_dyn_points > 0) {
+        ProfScope ps(h, 1, st);
+        LAUNCH_TRY(h, launch_prep_dyn(d_desc, L.n_inst, L.max_dyn_points, d_dyn, b.obstacle_dtype, h->dRows.as<d2>(), st));
+    }
+    {
+        ProfScope ps(h, 2, st);
+        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, h->dState.as<InstState>(), L.n_inst, st));
+    }
+    {
+        ProfScope ps(h, 3, st);
+        LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
+                                       h->dLonTab.as<double>(), L.n_inst, L.max_lon, st));
+    }
+    {
+        ProfScope ps(h, 4, st);
+        LAUNCH_TRY(h, launch_evaluate(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
+                                      h->dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
+                                      h->dPts.as<d2>(), st));
+    }
+    if (L.n_static > 0 || L.n_dyn_points > 0) {
+        ProfScope ps(h, 5, st);
         LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, h->dStat.as<d2>(),
                                      h->dRows.as<d2>(), h->dPts.as<d2>(), ca, st));
-    LAUNCH_TRY(h, launch_select(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
-                                h->dLonTab.as<double>(), ca, d_out, L.n_inst, st));
+    }
+    {
+        ProfScope ps(h, 6, st);
+        LAUNCH_TRY(h, launch_select(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
+                                    h->dLonTab.as<double>(), ca, d_out, L.n_inst, st));
+    }
     h->last_valid = true;
     return FOT_OK;
 }
@@ -247,6 +315,7 @@ void fot_destroy(fot_handle *h)
                        &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     h->staging.release();
+    for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->staging_done) (void)hipEventDestroy(h->staging_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -323,6 +392,33 @@ int fot_plan_batch_device(fot_handle *h, const fot_batch *batch, fot_result *out
     if (!batch) return fail(h, FOT_ERR_INVALID, "batch is NULL");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     return enqueue_plan(h, *batch, batch->static_xy, batch->dyn_xy, out_dev, st);
+}
+
+int fot_profile_enable(fot_handle *h, int on)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!on && h->prof_on) { int r = prof_drain(h); if (r != FOT_OK) return r; }
+    h->prof_on = on != 0;
+    return FOT_OK;
+}
+
+int fot_profile_read(fot_handle *h, int reset, int32_t *launches, double *total_ms)
+{
+    if (!h) return FOT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int r = prof_drain(h);
+    if (r != FOT_OK) return r;
+    for (int k = 0; k < FOT_PROFILE_KERNELS; ++k) {
+        if (launches) launches[k] = h->prof_launches[k];
+        if (total_ms) total_ms[k] = h->prof_ms[k];
+        if (reset) { h->prof_launches[k] = 0; h->prof_ms[k] = 0.0; }
+    }
+    return FOT_OK;
+}
+
+const char *fot_profile_kernel_name(int index)
+{
+    return index >= 0 && index < FOT_PROFILE_KERNELS ? kKernelNames[index] : "";
 }
 
 int fot_synchronize(fot_handle *h)

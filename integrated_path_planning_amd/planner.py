@@ -154,6 +154,20 @@ class BatchPlanner:
     def synchronize(self):
         _abi.check(self._h, self._lib.fot_synchronize(self._h))
 
+    def profile(self, on: bool):
+        """Bracket every kernel launch with HIP events on its stream (fot_profile_enable)."""
+        _abi.check(self._h, self._lib.fot_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> Dict[str, Dict[str, float]]:
+        """Per kernel: launches and summed device ms since the last reset (waits for the work)."""
+        n = _abi.PROFILE_KERNELS
+        launches = np.zeros(n, np.int32)
+        ms = np.zeros(n)
+        _abi.check(self._h, self._lib.fot_profile_read(self._h, 1 if reset else 0, launches.ctypes.data_as(_ip),
+                                                       _as_dp(ms)))
+        return {self._lib.fot_profile_kernel_name(k).decode(): {"launches": int(launches[k]), "total_ms": float(ms[k])}
+                for k in range(n)}
+
     def candidates(self, inst: int = 0, cap: int = 1 << 16):
         """Per-candidate (cost, status, keep, n_t) of an instance of the last plan call."""
         cost = np.zeros(cap)
