@@ -69,7 +69,7 @@ struct fot_handle {
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
     DevBuf dState, dLonInfo, dLonTab;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dPts;
-    DevBuf dStat, dRows;                     // prepared obstacles
+    DevBuf dStat, dRows, dStat32, dRows32;   // prepared obstacles: exact double2 + local-frame float2
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
     BatchLayout last;                        // layout of the most recent plan call
@@ -211,6 +211,8 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     HIP_TRY(h, h->dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
     HIP_TRY(h, h->dStat.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_static, 1)));
     HIP_TRY(h, h->dRows.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_dyn_points, 1)));
+    HIP_TRY(h, h->dStat32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_static32, 4)));
+    HIP_TRY(h, h->dRows32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_rows32, 4)));
 
     HIP_TRY(h, hipMemcpyAsync(h->dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipEventRecord(h->staging_done, st));
@@ -229,11 +231,13 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
     if (L.n_static > 0) {
         ProfScope ps(h, 0, st);
-        LAUNCH_TRY(h, launch_prep_static(d_static, b.obstacle_dtype, h->dStat.as<d2>(), L.n_static, st));
+        LAUNCH_TRY(h, launch_prep_static(d_desc, L.n_inst, L.max_static4, d_static, b.obstacle_dtype,
+                                         h->dStat.as<d2>(), h->dStat32.as<f2>(), st));
     }
     if (L.n_dyn_points > 0) {
         ProfScope ps(h, 1, st);
-        LAUNCH_TRY(h, launch_prep_dyn(d_desc, L.n_inst, L.max_dyn_points, d_dyn, b.obstacle_dtype, h->dRows.as<d2>(), st));
+        LAUNCH_TRY(h, launch_prep_dyn(d_desc, L.n_inst, L.max_rows32, d_dyn, b.obstacle_dtype, h->dRows.as<d2>(),
+                                      h->dRows32.as<f2>(), st));
     }
     {
         ProfScope ps(h, 2, st);
@@ -253,7 +257,8 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     if (L.n_static > 0 || L.n_dyn_points > 0) {
         ProfScope ps(h, 5, st);
         LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, h->dStat.as<d2>(),
-                                     h->dRows.as<d2>(), h->dPts.as<d2>(), ca, st));
+                                     h->dStat32.as<f2>(), h->dRows.as<d2>(), h->dRows32.as<f2>(), h->dPts.as<d2>(),
+                                     ca, st));
     }
     {
         ProfScope ps(h, 6, st);
@@ -311,7 +316,7 @@ void fot_destroy(fot_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dMeta, &h->dState, &h->dLonInfo, &h->dLonTab, &h->dCost, &h->dVlast,
-                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dPts, &h->dStat, &h->dRows, &h->dUserStatic,
+                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dPts, &h->dStat, &h->dRows, &h->dStat32, &h->dRows32, &h->dUserStatic,
                        &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     h->staging.release();
@@ -569,6 +574,8 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
     HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
     HIP_TRY(h, h->dStat.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_static, 1)));
     HIP_TRY(h, h->dRows.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_dyn_points, 1)));
+    HIP_TRY(h, h->dStat32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_static32, 4)));
+    HIP_TRY(h, h->dRows32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_rows32, 4)));
     HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc)));
     HIP_TRY(h, h->dTmpB.ensure(sizeof(d2) * pts.size()));
     HIP_TRY(h, h->dTmpC.ensure(sizeof(int32_t) * (tidx.size() + np)));
@@ -580,8 +587,10 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
     HIP_TRY(h, hipMemcpyAsync(h->dTmpC.p, tidx.data(), sizeof(int32_t) * tidx.size(), hipMemcpyHostToDevice, st));
     int32_t *d_len = h->dTmpC.as<int32_t>() + tidx.size();
     HIP_TRY(h, hipMemcpyAsync(d_len, len, sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
-    LAUNCH_TRY(h, launch_prep_static(h->dUserStatic.p, FOT_F64, h->dStat.as<d2>(), L.n_static, st));
-    LAUNCH_TRY(h, launch_prep_dyn(h->dTmpA.as<InstDesc>(), 1, L.max_dyn_points, h->dUserDyn.p, FOT_F64, h->dRows.as<d2>(), st));
+    LAUNCH_TRY(h, launch_prep_static(h->dTmpA.as<InstDesc>(), 1, L.max_static4, h->dUserStatic.p, FOT_F64,
+                                     h->dStat.as<d2>(), h->dStat32.as<f2>(), st));
+    LAUNCH_TRY(h, launch_prep_dyn(h->dTmpA.as<InstDesc>(), 1, L.max_rows32, h->dUserDyn.p, FOT_F64, h->dRows.as<d2>(),
+                                  h->dRows32.as<f2>(), st));
     LAUNCH_TRY(h, launch_collide_ext(h->dP.as<DevParams>(), h->dTmpA.as<InstDesc>(), n_paths, d_len, h->dTmpB.as<d2>(),
                                      h->dTmpC.as<int32_t>(), h->dStat.as<d2>(), h->dRows.as<d2>(),
                                      h->dTmpD.as<int32_t>(), st));

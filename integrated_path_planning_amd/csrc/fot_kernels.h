@@ -13,9 +13,10 @@ struct CandArrays {
 };
 
 // every launcher returns 0 or the hipError_t of the launch
-int launch_prep_static(const void *src, int dtype, d2 *dst, int64_t n, hipStream_t st);
-int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_points, const void *src, int dtype, d2 *rows,
-                    hipStream_t st);
+int launch_prep_static(const InstDesc *desc, int n_inst, int max_static4, const void *src, int dtype, d2 *stat,
+                       f2 *stat32, hipStream_t st);
+int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_rows32, const void *src, int dtype, d2 *rows,
+                    f2 *rows32, hipStream_t st);
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         hipStream_t st);
 int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
@@ -24,7 +25,8 @@ int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *s
                     const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
                     CandArrays c, d2 *pts, hipStream_t st);
 int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
-                   int n_waves, const d2 *stat, const d2 *rows, const d2 *pts, CandArrays c, hipStream_t st);
+                   int n_waves, const d2 *stat, const f2 *stat32, const d2 *rows, const f2 *rows32, const d2 *pts,
+                   CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                   const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);

@@ -21,33 +21,53 @@ namespace fot {
 // obstacle preparation
 // ---------------------------------------------------------------------------
 
+// static points of instance blockIdx.y: exact double2 copy + float32 copy relative to the ego position,
+// padded to a multiple of 4 with FAR32
 template <typename T>
-__global__ void k_prep_static(const T *__restrict__ src, d2 *__restrict__ dst, int64_t n)
+__global__ void k_prep_static(const InstDesc *__restrict__ desc, const T *__restrict__ src,
+                              d2 *__restrict__ stat, f2 *__restrict__ stat32)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    d2 o;
-    o.x = (double)src[2 * i];
-    o.y = (double)src[2 * i + 1];
-    dst[i] = o;
+    const InstDesc &D = desc[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.n_static4) return;
+    f2 q; q.x = FAR32; q.y = FAR32;
+    if (j < D.n_static) {
+        d2 o;
+        o.x = (double)src[2 * (D.static_off + j)];
+        o.y = (double)src[2 * (D.static_off + j) + 1];
+        stat[D.static_off + j] = o;
+        q.x = (float)(o.x - D.ego.x);
+        q.y = (float)(o.y - D.ego.y);
+    }
+    stat32[D.static32_off + j] = q;
 }
 
-// [S][P][T][2] -> rows[T][S*P]; blockIdx.y = instance
+// [S][P][T][2] -> exact rows[T][S*P] (double2) and local-frame rows32[T][S][P4] (float2, FAR32 padded);
+// blockIdx.y = instance
 template <typename T>
-__global__ void k_prep_dyn(const InstDesc *__restrict__ desc, const T *__restrict__ src, d2 *__restrict__ rows)
+__global__ void k_prep_dyn(const InstDesc *__restrict__ desc, const T *__restrict__ src, d2 *__restrict__ rows,
+                           f2 *__restrict__ rows32)
 {
     const InstDesc &D = desc[blockIdx.y];
     if (D.dyn_mode == FOT_DYN_NONE) return;
-    const int SP = D.S * D.P;
-    const int64_t total = (int64_t)SP * D.T;
-    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // output index k*SP + sp
-    if (o >= total) return;
-    const int k = (int)(o / SP), sp = (int)(o - (int64_t)k * SP);
-    const int64_t in = D.dyn_off + (int64_t)sp * D.T + k;
-    d2 v;
-    v.x = (double)src[2 * in];
-    v.y = (double)src[2 * in + 1];
-    rows[D.row_off + o] = v;
+    const int SP4 = D.S * D.P4;
+    const int64_t total = (int64_t)SP4 * D.T;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into rows32: (k*S + s)*P4 + p
+    if (e >= total) return;
+    const int k = (int)(e / SP4);
+    const int rem = (int)(e - (int64_t)k * SP4);
+    const int sidx = rem / D.P4, p = rem - sidx * D.P4;
+    f2 q; q.x = FAR32; q.y = FAR32;
+    if (p < D.P) {
+        const int64_t in = D.dyn_off + ((int64_t)sidx * D.P + p) * D.T + k;
+        d2 v;
+        v.x = (double)src[2 * in];
+        v.y = (double)src[2 * in + 1];
+        rows[D.row_off + (int64_t)k * (D.S * D.P) + sidx * D.P + p] = v;
+        q.x = (float)(v.x - D.ego.x);
+        q.y = (float)(v.y - D.ego.y);
+    }
+    rows32[D.row32_off + e] = q;
 }
 
 // ---------------------------------------------------------------------------
@@ -205,7 +225,8 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
            uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep, d2 *__restrict__ pts)
 {
-    const int wave = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    // wave index through readfirstlane: everything derived from it (instance, descriptor, rows) is wave-uniform -> SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const DevParams &P = *Pp;
@@ -241,26 +262,75 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 // collision
 // ---------------------------------------------------------------------------
 
+// One wave = 64 candidates of one instance, lane = candidate.  Time steps, prediction samples and
+// obstacle points are walked wave-uniformly (obstacle rows come in through scalar loads); each lane
+// keeps the float32 minimum squared distance of the current row and only rows that come within the
+// conservative threshold are re-checked in float64, so the decision is the reference's.
 __global__ void __launch_bounds__(256)
 k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
           const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
-          const d2 *__restrict__ stat, const d2 *__restrict__ rows, const d2 *__restrict__ pts,
+          const d2 *__restrict__ stat, const f2 *__restrict__ stat32, const d2 *__restrict__ rows,
+          const f2 *__restrict__ rows32, const d2 *__restrict__ pts,
           uint8_t *__restrict__ cand_status, const uint8_t *__restrict__ cand_keep)
 {
-    const int wave = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    // wave index through readfirstlane: everything derived from it (instance, descriptor, rows) is wave-uniform -> SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const DevParams &P = *Pp;
     const int inst = wave_inst[wave];
     const InstDesc &D = desc[inst];
-    if (D.n_static == 0 && D.dyn_mode == FOT_DYN_NONE) return;
+    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE && D.P > 0 && D.T > 0;
+    if (D.n_static == 0 && !dyn_on) return;
     const int64_t slot = (int64_t)D.cand_off + wave_base[wave] + lane;
-    if (cand_status[slot] != ST_PENDING) return;
-    ScratchSource src;
-    src.base = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
-    src.n_total = P.n_total;
-    if (collide_candidate(P, D, stat + D.static_off, rows + D.row_off, (int)cand_keep[slot], src))
-        cand_status[slot] = FOT_ST_COLLISION;
+    const bool pending = cand_status[slot] == ST_PENDING;
+    const int keep = pending ? (int)cand_keep[slot] : 0;
+    int kmax = keep;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, WAVE));
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    if (kmax == 0) return;
+
+    const int n_circ = P.has_footprint ? P.n_circ : 1;
+    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    const double ox0 = D.ego.x, oy0 = D.ego.y;
+    const d2 *my_pts = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
+    const d2 *st64 = stat + D.static_off;
+    const f2 *st32 = stat32 + D.static32_off;
+    const d2 *r64 = rows + D.row_off;
+    const f2 *r32 = rows32 + D.row32_off;
+    const int S = D.S, Pn = D.P, P4 = D.P4, SP = D.S * D.P, T = D.T;
+    const int n_static = D.n_static, n_static4 = D.n_static4, max_viol = D.max_viol;
+
+    bool collided = false;
+    uint64_t hit_mask = 0;
+    int viol = 0;
+    for (int k = 0; k < kmax; ++k) {
+        const bool act = !collided && k < keep;
+        if (!__any(act)) break;                                   // keep is fixed: no lane can become active later
+        const int row = k < T - 1 ? k : T - 1;
+        for (int ci = 0; ci < n_circ; ++ci) {
+            const d2 p = my_pts[((int64_t)ci * P.n_total + k) * WAVE];
+            const float fx = (float)(p.x - ox0), fy = (float)(p.y - oy0);
+            if (n_static > 0) {
+                const bool maybe = act && !collided && min_sqdist32(st32, n_static4, fx, fy) <= filter_threshold(P.sq_r, fx, fy);
+                if (maybe && hits_row(st64, n_static, p.x, p.y, P.sq_r)) collided = true;
+            }
+            if (!dyn_on) continue;
+            const float thr = filter_threshold(sq_dyn, fx, fy);
+            for (int s = 0; s < S; ++s) {
+                const float m = min_sqdist32(r32 + ((int64_t)row * S + s) * P4, P4, fx, fy);
+                const bool maybe = act && !collided && !((hit_mask >> s) & 1) && m <= thr;
+                if (__any(maybe)) {
+                    if (maybe && hits_row(r64 + (int64_t)row * SP + s * Pn, Pn, p.x, p.y, sq_dyn)) {
+                        hit_mask |= (uint64_t)1 << s;
+                        if (++viol > max_viol) collided = true;
+                    }
+                }
+            }
+        }
+    }
+    if (pending && collided) cand_status[slot] = FOT_ST_COLLISION;
 }
 
 // ---------------------------------------------------------------------------
@@ -399,25 +469,26 @@ __global__ void k_collide_ext(const DevParams *__restrict__ Pp, const InstDesc *
 
 #define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-int launch_prep_static(const void *src, int dtype, d2 *dst, int64_t n, hipStream_t st)
+int launch_prep_static(const InstDesc *desc, int n_inst, int max_static4, const void *src, int dtype, d2 *stat,
+                       f2 *stat32, hipStream_t st)
 {
-    if (n <= 0) return 0;
-    const int bs = 256;
-    const unsigned grid = (unsigned)((n + bs - 1) / bs);
-    if (dtype == FOT_F32) k_prep_static<float><<<grid, bs, 0, st>>>((const float *)src, dst, n);
-    else k_prep_static<double><<<grid, bs, 0, st>>>((const double *)src, dst, n);
+    if (max_static4 <= 0 || n_inst <= 0) return 0;
+    const int bs = 64;
+    dim3 grid((unsigned)((max_static4 + bs - 1) / bs), (unsigned)n_inst);
+    if (dtype == FOT_F32) k_prep_static<float><<<grid, bs, 0, st>>>(desc, (const float *)src, stat, stat32);
+    else k_prep_static<double><<<grid, bs, 0, st>>>(desc, (const double *)src, stat, stat32);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_points, const void *src, int dtype, d2 *rows,
-                    hipStream_t st)
+int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_rows32, const void *src, int dtype, d2 *rows,
+                    f2 *rows32, hipStream_t st)
 {
-    if (max_points <= 0 || n_inst <= 0) return 0;
+    if (max_rows32 <= 0 || n_inst <= 0) return 0;
     const int bs = 256;
-    dim3 grid((unsigned)((max_points + bs - 1) / bs), (unsigned)n_inst);
-    if (dtype == FOT_F32) k_prep_dyn<float><<<grid, bs, 0, st>>>(desc, (const float *)src, rows);
-    else k_prep_dyn<double><<<grid, bs, 0, st>>>(desc, (const double *)src, rows);
+    dim3 grid((unsigned)((max_rows32 + bs - 1) / bs), (unsigned)n_inst);
+    if (dtype == FOT_F32) k_prep_dyn<float><<<grid, bs, 0, st>>>(desc, (const float *)src, rows, rows32);
+    else k_prep_dyn<double><<<grid, bs, 0, st>>>(desc, (const double *)src, rows, rows32);
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -454,12 +525,13 @@ int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *s
 }
 
 int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
-                   int n_waves, const d2 *stat, const d2 *rows, const d2 *pts, CandArrays c, hipStream_t st)
+                   int n_waves, const d2 *stat, const f2 *stat32, const d2 *rows, const f2 *rows32, const d2 *pts,
+                   CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
     const int wpb = 256 / WAVE;
-    k_collide<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, wave_inst, wave_base, n_waves, stat, rows, pts,
-                                                        c.status, c.keep);
+    k_collide<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, wave_inst, wave_base, n_waves, stat, stat32, rows,
+                                                        rows32, pts, c.status, c.keep);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -423,6 +423,77 @@ FOT_HD bool hits_row(const d2 *row, int n, double px, double py, double sq)
     return hit;
 }
 
+// ---- float32 broad phase -------------------------------------------------------------------
+// Obstacles and path points are also kept in float32 relative to the instance origin (the ego
+// position).  min_sqdist32 gives the smallest float32 squared distance of a row; a pair can only
+// pass the exact float64 test (dx*dx + dy*dy <= sq) if its float32 value is <= filter_threshold(),
+// so rows above the threshold are skipped and rows below it are re-checked exactly.  The decision
+// is therefore always the float64 one of the reference.
+
+// smallest float32 squared distance from (px, py) to n4 points (n4 % 4 == 0, FAR32 padded)
+FOT_HD float min_sqdist32(const f2 *r, int n4, float px, float py)
+{
+    float m = INFINITY;
+    for (int j = 0; j < n4; j += 4) {
+        const float dx0 = px - r[j].x, dy0 = py - r[j].y;
+        const float dx1 = px - r[j + 1].x, dy1 = py - r[j + 1].y;
+        const float dx2 = px - r[j + 2].x, dy2 = py - r[j + 2].y;
+        const float dx3 = px - r[j + 3].x, dy3 = py - r[j + 3].y;
+        const float t0 = fmaf(dy0, dy0, dx0 * dx0), t1 = fmaf(dy1, dy1, dx1 * dx1);
+        const float t2 = fmaf(dy2, dy2, dx2 * dx2), t3 = fmaf(dy3, dy3, dx3 * dx3);
+        m = fminf(fminf(m, t0), t1);
+        m = fminf(fminf(m, t2), t3);
+    }
+    return m;
+}
+
+// Upper bound of the float32 squared distance of any pair whose float64 squared distance is <= sq.
+// Rounding the two points to float32 moves each coordinate difference by at most
+// 2^-24 (2|p| + R + |d|); with |d| <= R = sqrt(sq) the squared distance moves by less than
+// 4 (R+1) e, e = 2^-23 (|px| + |py| + 2R + 6); the three float32 roundings of the sum add 2^-22 relative.
+FOT_HD float filter_threshold(double sq, float px, float py)
+{
+    const float r = sqrtf((float)sq) + 1.0f;
+    const float e = (fabsf(px) + fabsf(py) + 2.0f * r + 4.0f) * 1.1920929e-7f;
+    return ((float)sq + 4.0f * r * e) * 1.000002f + 1e-30f;
+}
+
+// per-candidate collision check with the float32 broad phase (same result as collide_candidate)
+template <class Source>
+FOT_HD bool collide_candidate_filtered(const DevParams &P, const InstDesc &D, const d2 *stat, const f2 *stat32,
+                                       const d2 *rows, const f2 *rows32, int keep, const Source &src)
+{
+    const int n_circ = P.has_footprint ? P.n_circ : 1;
+    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE && D.P > 0 && D.T > 0;
+    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    const int SP = D.S * D.P;
+    uint64_t hit_mask = 0;
+    int viol = 0;
+    for (int k = 0; k < keep; ++k) {
+        int row = src.tindex(k);
+        row = row < 0 ? 0 : (row > D.T - 1 ? D.T - 1 : row);
+        for (int ci = 0; ci < n_circ; ++ci) {
+            double px, py;
+            src.get(k, ci, px, py);
+            const float fx = (float)(px - D.ego.x), fy = (float)(py - D.ego.y);
+            if (D.n_static > 0 && min_sqdist32(stat32, D.n_static4, fx, fy) <= filter_threshold(P.sq_r, fx, fy)
+                && hits_row(stat, D.n_static, px, py, P.sq_r))
+                return true;
+            if (!dyn_on) continue;
+            const float thr = filter_threshold(sq_dyn, fx, fy);
+            for (int s = 0; s < D.S; ++s) {
+                if ((hit_mask >> s) & 1) continue;
+                if (min_sqdist32(rows32 + ((int64_t)row * D.S + s) * D.P4, D.P4, fx, fy) > thr) continue;
+                if (hits_row(rows + (int64_t)row * SP + s * D.P, D.P, px, py, sq_dyn)) {
+                    hit_mask |= (uint64_t)1 << s;
+                    if (++viol > D.max_viol) return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
 // Source::get(k, circle, x, y) returns the stored collision points; Source::tindex(k) is
 // round(t_k/dt) (== k for lattice candidates).
 // stat: [n_static] points; rows: transposed dynamic obstacles [T][S*P].

@@ -176,6 +176,10 @@ struct BatchLayout {
     int64_t n_dyn_points = 0;     // dynamic points in the batch (== transposed rows size)
     int64_t max_dyn_points = 0;   // of one instance
     int64_t dyn_src_points = 0;   // extent of the caller's dyn_xy that is referenced
+    int64_t n_rows32 = 0;         // float2 entries of the padded float32 rows
+    int64_t max_rows32 = 0;       // of one instance
+    int64_t n_static32 = 0;       // float2 entries of the padded float32 static points
+    int max_static4 = 0;          // of one instance
 };
 
 inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fot_batch &b, BatchLayout &L,
@@ -231,6 +235,10 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
             D.static_off = lo;
             D.n_static = (int32_t)(hi - lo);
             if (hi > L.n_static) L.n_static = hi;
+            D.n_static4 = (D.n_static + 3) & ~3;
+            D.static32_off = L.n_static32;
+            L.n_static32 += D.n_static4;
+            if (D.n_static4 > L.max_static4) L.max_static4 = D.n_static4;
         }
         D.dyn_mode = FOT_DYN_NONE;
         if (b.dyn_off && b.dyn_dims) {
@@ -251,6 +259,11 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
                 L.n_dyn_points += pts;
                 if (pts > L.max_dyn_points) L.max_dyn_points = pts;
                 if (D.dyn_off + pts > L.dyn_src_points) L.dyn_src_points = D.dyn_off + pts;
+                D.P4 = (Pn + 3) & ~3;
+                D.row32_off = L.n_rows32;
+                const int64_t e32 = (int64_t)T * S * D.P4;
+                L.n_rows32 += e32;
+                if (e32 > L.max_rows32) L.max_rows32 = e32;
                 D.max_viol = mode == FOT_DYN_DISTRIBUTION ? (int)std::floor(hp.chance_epsilon * (double)S) : 0;
             }
         }

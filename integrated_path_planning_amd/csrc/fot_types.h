@@ -17,6 +17,8 @@ constexpr int LON_FIELDS = 10;           // s, s_d, s_dd, rx, ry, cos_r, sin_r, 
 constexpr int ST_PENDING = FOT_ST_OK;    // passed the kinematic checks, collision check outstanding
 
 struct d2 { double x, y; };
+struct f2 { float x, y; };
+constexpr float FAR32 = 1.0e18f;         // padding obstacle of the float32 broad-phase rows
 
 // one time horizon: quartic / quintic boundary-value inverses (frenet_planner.py:586-617)
 struct TimeInfo {
@@ -69,7 +71,12 @@ struct InstDesc {
     int32_t dyn_mode, S, P, T;
     int64_t dyn_off;                     // points into the caller's dyn_xy
     int64_t row_off;                     // points into the transposed obstacle rows
+    int64_t row32_off;                   // float2 entries into the local-frame float32 rows [T][S][P4]
+    int64_t static32_off;                // float2 entries into the local-frame float32 static points
+    int32_t P4;                          // P rounded up to a multiple of 4 (FAR32 padding)
+    int32_t n_static4;                   // n_static rounded up to a multiple of 4
     int32_t max_viol;                    // floor(eps*S)
+    int32_t _pad;
 };
 
 // device-produced per-instance state

@@ -46,12 +46,18 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
 
     // --- obstacle preparation (k_prep_static / k_prep_dyn)
     std::vector<d2> stat((size_t)L.n_static + 1), rows((size_t)L.n_dyn_points + 1);
+    f2 far; far.x = FAR32; far.y = FAR32;
+    std::vector<f2> stat32((size_t)L.n_static32 + 4, far), rows32((size_t)L.n_rows32 + 4, far);
     auto coord = [&](const void *base, int64_t i) -> double {
         return b->obstacle_dtype == FOT_F32 ? (double)((const float *)base)[i] : ((const double *)base)[i];
     };
     for (int64_t i = 0; i < L.n_static; ++i) { stat[i].x = coord(b->static_xy, 2 * i); stat[i].y = coord(b->static_xy, 2 * i + 1); }
     for (int inst = 0; inst < L.n_inst; ++inst) {
         const InstDesc &D = L.desc[inst];
+        for (int j = 0; j < D.n_static; ++j) {
+            stat32[D.static32_off + j].x = (float)(stat[D.static_off + j].x - D.ego.x);
+            stat32[D.static32_off + j].y = (float)(stat[D.static_off + j].y - D.ego.y);
+        }
         if (D.dyn_mode == FOT_DYN_NONE) continue;
         const int SP = D.S * D.P;
         for (int64_t o = 0; o < (int64_t)SP * D.T; ++o) {
@@ -59,6 +65,10 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             const int64_t in = D.dyn_off + (int64_t)spi * D.T + k;
             rows[D.row_off + o].x = coord(b->dyn_xy, 2 * in);
             rows[D.row_off + o].y = coord(b->dyn_xy, 2 * in + 1);
+            const int sidx = spi / D.P, p = spi - sidx * D.P;
+            f2 &q = rows32[D.row32_off + ((int64_t)k * D.S + sidx) * D.P4 + p];
+            q.x = (float)(rows[D.row_off + o].x - D.ego.x);
+            q.y = (float)(rows[D.row_off + o].y - D.ego.y);
         }
     }
 
@@ -139,8 +149,11 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             int st = r.status;
             if (st == ST_PENDING) {
                 VecSource src = { &pts, P.n_total };
-                if (collide_candidate(P, D, stat.data() + D.static_off, rows.data() + D.row_off, r.keep, src))
-                    st = FOT_ST_COLLISION;
+                const bool hit = collide_candidate_filtered(P, D, stat.data() + D.static_off, stat32.data() + D.static32_off,
+                                                            rows.data() + D.row_off, rows32.data() + D.row32_off, r.keep, src);
+                if (hit != collide_candidate(P, D, stat.data() + D.static_off, rows.data() + D.row_off, r.keep, src))
+                    return -100;                       // broad phase disagrees with the exact check
+                if (hit) st = FOT_ST_COLLISION;
             }
             st = final_status(st, r.v_last, r.travel, D.max_stop);
             if (st < 8) cnt[st]++;
