@@ -82,7 +82,7 @@ SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_se
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
            "fot_check_collision_paths", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
-PROFILE_KERNELS = 7
+PROFILE_KERNELS = 6
 
 _lib = None
 

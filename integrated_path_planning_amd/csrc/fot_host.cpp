@@ -69,7 +69,7 @@ struct fot_handle {
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
     DevBuf dState, dLonInfo, dLonTab;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dPts;
-    DevBuf dStat, dRows, dStat32, dRows32;   // prepared obstacles: exact double2 + local-frame float2
+    DevBuf dWaveBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: wave boxes + culled entry lists
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
     BatchLayout last;                        // layout of the most recent plan call
@@ -130,8 +130,8 @@ int upload_spline(fot_handle *h)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_prep_static", "k_prep_dyn", "k_frenet_state",
-                                                        "k_lon_table", "k_evaluate", "k_collide", "k_select" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_lon_table", "k_evaluate", "k_cull",
+                                                        "k_collide", "k_select" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -209,10 +209,12 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     HIP_TRY(h, h->dStatus.ensure(slots));
     HIP_TRY(h, h->dKeep.ensure(slots));
     HIP_TRY(h, h->dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
-    HIP_TRY(h, h->dStat.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_static, 1)));
-    HIP_TRY(h, h->dRows.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_dyn_points, 1)));
-    HIP_TRY(h, h->dStat32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_static32, 4)));
-    HIP_TRY(h, h->dRows32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_rows32, 4)));
+    HIP_TRY(h, h->dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
+    const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
+    HIP_TRY(h, h->dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
+    HIP_TRY(h, h->dEnt32.ensure(sizeof(f2) * n_ent));
+    HIP_TRY(h, h->dEnt64.ensure(sizeof(d2) * n_ent));
+    HIP_TRY(h, h->dEntSid.ensure(n_ent));
 
     HIP_TRY(h, hipMemcpyAsync(h->dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipEventRecord(h->staging_done, st));
@@ -229,39 +231,35 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     ca.status = h->dStatus.as<uint8_t>(); ca.keep = h->dKeep.as<uint8_t>();
 
     if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
-    if (L.n_static > 0) {
-        ProfScope ps(h, 0, st);
-        LAUNCH_TRY(h, launch_prep_static(d_desc, L.n_inst, L.max_static4, d_static, b.obstacle_dtype,
-                                         h->dStat.as<d2>(), h->dStat32.as<f2>(), st));
-    }
-    if (L.n_dyn_points > 0) {
-        ProfScope ps(h, 1, st);
-        LAUNCH_TRY(h, launch_prep_dyn(d_desc, L.n_inst, L.max_rows32, d_dyn, b.obstacle_dtype, h->dRows.as<d2>(),
-                                      h->dRows32.as<f2>(), st));
-    }
+    EntryArrays ea;
+    ea.cnt = h->dEntCnt.as<int32_t>(); ea.e32 = h->dEnt32.as<f2>(); ea.e64 = h->dEnt64.as<d2>();
+    ea.sid = h->dEntSid.as<uint8_t>();
     {
-        ProfScope ps(h, 2, st);
+        ProfScope ps(h, 0, st);
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, h->dState.as<InstState>(), L.n_inst, st));
     }
     {
-        ProfScope ps(h, 3, st);
+        ProfScope ps(h, 1, st);
         LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
                                        h->dLonTab.as<double>(), L.n_inst, L.max_lon, st));
     }
     {
-        ProfScope ps(h, 4, st);
+        ProfScope ps(h, 2, st);
         LAUNCH_TRY(h, launch_evaluate(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
                                       h->dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
-                                      h->dPts.as<d2>(), st));
+                                      h->dPts.as<d2>(), h->dWaveBox.as<float>(), st));
     }
-    if (L.n_static > 0 || L.n_dyn_points > 0) {
-        ProfScope ps(h, 5, st);
-        LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, h->dStat.as<d2>(),
-                                     h->dStat32.as<f2>(), h->dRows.as<d2>(), h->dRows32.as<f2>(), h->dPts.as<d2>(),
-                                     ca, st));
+    if (L.any_obstacles) {
+        {
+            ProfScope ps(h, 3, st);
+            LAUNCH_TRY(h, launch_cull(dP, d_desc, L.n_inst, P.n_total, h->dWaveBox.as<float>(), d_static, d_dyn,
+                                      b.obstacle_dtype, ea, st));
+        }
+        ProfScope ps(h, 4, st);
+        LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, ea, h->dPts.as<d2>(), ca, st));
     }
     {
-        ProfScope ps(h, 6, st);
+        ProfScope ps(h, 5, st);
         LAUNCH_TRY(h, launch_select(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
                                     h->dLonTab.as<double>(), ca, d_out, L.n_inst, st));
     }
@@ -316,7 +314,7 @@ void fot_destroy(fot_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dMeta, &h->dState, &h->dLonInfo, &h->dLonTab, &h->dCost, &h->dVlast,
-                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dPts, &h->dStat, &h->dRows, &h->dStat32, &h->dRows32, &h->dUserStatic,
+                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dPts, &h->dWaveBox, &h->dEntCnt, &h->dEnt32, &h->dEnt64, &h->dEntSid, &h->dUserStatic,
                        &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     h->staging.release();
@@ -572,10 +570,12 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
     const size_t st_bytes = sizeof(double) * 2 * (size_t)L.n_static, dy_bytes = sizeof(double) * 2 * (size_t)L.dyn_src_points;
     HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
     HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
-    HIP_TRY(h, h->dStat.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_static, 1)));
-    HIP_TRY(h, h->dRows.ensure(sizeof(d2) * (size_t)std::max<int64_t>(L.n_dyn_points, 1)));
-    HIP_TRY(h, h->dStat32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_static32, 4)));
-    HIP_TRY(h, h->dRows32.ensure(sizeof(f2) * (size_t)std::max<int64_t>(L.n_rows32, 4)));
+    HIP_TRY(h, h->dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
+    const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
+    HIP_TRY(h, h->dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
+    HIP_TRY(h, h->dEnt32.ensure(sizeof(f2) * n_ent));
+    HIP_TRY(h, h->dEnt64.ensure(sizeof(d2) * n_ent));
+    HIP_TRY(h, h->dEntSid.ensure(n_ent));
     HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc)));
     HIP_TRY(h, h->dTmpB.ensure(sizeof(d2) * pts.size()));
     HIP_TRY(h, h->dTmpC.ensure(sizeof(int32_t) * (tidx.size() + np)));
@@ -587,12 +587,8 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
     HIP_TRY(h, hipMemcpyAsync(h->dTmpC.p, tidx.data(), sizeof(int32_t) * tidx.size(), hipMemcpyHostToDevice, st));
     int32_t *d_len = h->dTmpC.as<int32_t>() + tidx.size();
     HIP_TRY(h, hipMemcpyAsync(d_len, len, sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
-    LAUNCH_TRY(h, launch_prep_static(h->dTmpA.as<InstDesc>(), 1, L.max_static4, h->dUserStatic.p, FOT_F64,
-                                     h->dStat.as<d2>(), h->dStat32.as<f2>(), st));
-    LAUNCH_TRY(h, launch_prep_dyn(h->dTmpA.as<InstDesc>(), 1, L.max_rows32, h->dUserDyn.p, FOT_F64, h->dRows.as<d2>(),
-                                  h->dRows32.as<f2>(), st));
     LAUNCH_TRY(h, launch_collide_ext(h->dP.as<DevParams>(), h->dTmpA.as<InstDesc>(), n_paths, d_len, h->dTmpB.as<d2>(),
-                                     h->dTmpC.as<int32_t>(), h->dStat.as<d2>(), h->dRows.as<d2>(),
+                                     h->dTmpC.as<int32_t>(), h->dUserStatic.as<double>(), h->dUserDyn.as<double>(),
                                      h->dTmpD.as<int32_t>(), st));
     HIP_TRY(h, hipMemcpyAsync(free_out, h->dTmpD.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));

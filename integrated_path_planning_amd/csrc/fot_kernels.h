@@ -12,25 +12,31 @@ struct CandArrays {
     uint8_t *status, *keep;
 };
 
+// broad-phase entry lists in HBM: per instance n_total * ent_cap slots
+struct EntryArrays {
+    int32_t *cnt;      // [n_inst][n_total] entries of each time step (multiple of 8)
+    f2 *e32;           // instance-local float32 coordinates
+    d2 *e64;           // exact coordinates
+    uint8_t *sid;      // prediction sample of the entry, SID_STATIC for static obstacles
+};
+
 // every launcher returns 0 or the hipError_t of the launch
-int launch_prep_static(const InstDesc *desc, int n_inst, int max_static4, const void *src, int dtype, d2 *stat,
-                       f2 *stat32, hipStream_t st);
-int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_rows32, const void *src, int dtype, d2 *rows,
-                    f2 *rows32, hipStream_t st);
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         hipStream_t st);
 int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
                      LonInfo *lon_info, double *lon_tab, int n_inst, int max_lon, hipStream_t st);
 int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                     const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
-                    CandArrays c, d2 *pts, hipStream_t st);
+                    CandArrays c, d2 *pts, float *wave_box, hipStream_t st);
+int launch_cull(const DevParams *P, const InstDesc *desc, int n_inst, int n_total, const float *wave_box,
+                const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, hipStream_t st);
 int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
-                   int n_waves, const d2 *stat, const f2 *stat32, const d2 *rows, const f2 *rows32, const d2 *pts,
-                   CandArrays c, hipStream_t st);
+                   int n_waves, EntryArrays e, const d2 *pts, CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                   const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
 int launch_collide_ext(const DevParams *P, const InstDesc *desc, int n_paths, const int32_t *len, const d2 *pts,
-                       const int32_t *tidx, const d2 *stat, const d2 *rows, int32_t *free_out, hipStream_t st);
+                       const int32_t *tidx, const double *static_xy, const double *dyn_xy, int32_t *free_out,
+                       hipStream_t st);
 
 }  // namespace fot

@@ -1,74 +1,23 @@
 // fot_kernels.hip -- gfx950 kernels of the Frenet optimal-trajectory planner.
 //
-// Pipeline of one fot_plan_batch (all float64, one launch each over the whole batch):
-//   k_prep_static / k_prep_dyn : caller's obstacle tensors -> double2, dynamic ones transposed to
-//                                [T][S*P] rows so that one time step is one contiguous, wave-uniform row
-//   k_frenet_state   : 1 wave / instance   nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
-//   k_lon_table      : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t)
-//   k_evaluate       : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks,
-//                      collision points to scratch in [wave][circle][k][lane] order (coalesced 1 KiB stores)
-//   k_collide        : 1 lane / candidate that survived: static + time-indexed dynamic (chance-constrained)
-//   k_select         : 1 wave / instance: stop-distance filter, rejection histogram, first-minimum argmin
-//                      (shuffle reduction, lowest index wins ties), selected path written out
+// Pipeline of one fot_plan_batch (one launch each over the whole batch; every decision in float64):
+//   k_frenet_state : 1 wave / instance: nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
+//   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t)
+//   k_evaluate     : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks;
+//                    collision points to scratch in [wave][circle][k][lane] order (coalesced 1 KiB stores)
+//                    and, per wave and time step, the float32 bounding box of those points (DPP/shuffle reduce)
+//   k_cull         : 1 wave / (instance, time step): merges the wave boxes, then compacts the obstacles of that
+//                    time row that lie inside the grown box into an entry list (ballot + popcount prefix)
+//   k_collide      : 1 lane / surviving candidate: walks the entry lists wave-uniformly (scalar loads,
+//                    software-prefetched), float32 broad phase, exact float64 re-check of near chunks
+//   k_select       : 1 wave / instance: stop-distance filter, rejection histogram, first-minimum argmin
+//                    (shuffle reduction, lowest index wins ties), selected path written out
 #include <hip/hip_runtime.h>
 
 #include "fot_math.hpp"
 #include "fot_kernels.h"
 
 namespace fot {
-
-// ---------------------------------------------------------------------------
-// obstacle preparation
-// ---------------------------------------------------------------------------
-
-// static points of instance blockIdx.y: exact double2 copy + float32 copy relative to the ego position,
-// padded to a multiple of 4 with FAR32
-template <typename T>
-__global__ void k_prep_static(const InstDesc *__restrict__ desc, const T *__restrict__ src,
-                              d2 *__restrict__ stat, f2 *__restrict__ stat32)
-{
-    const InstDesc &D = desc[blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= D.n_static4) return;
-    f2 q; q.x = FAR32; q.y = FAR32;
-    if (j < D.n_static) {
-        d2 o;
-        o.x = (double)src[2 * (D.static_off + j)];
-        o.y = (double)src[2 * (D.static_off + j) + 1];
-        stat[D.static_off + j] = o;
-        q.x = (float)(o.x - D.ego.x);
-        q.y = (float)(o.y - D.ego.y);
-    }
-    stat32[D.static32_off + j] = q;
-}
-
-// [S][P][T][2] -> exact rows[T][S*P] (double2) and local-frame rows32[T][S][P4] (float2, FAR32 padded);
-// blockIdx.y = instance
-template <typename T>
-__global__ void k_prep_dyn(const InstDesc *__restrict__ desc, const T *__restrict__ src, d2 *__restrict__ rows,
-                           f2 *__restrict__ rows32)
-{
-    const InstDesc &D = desc[blockIdx.y];
-    if (D.dyn_mode == FOT_DYN_NONE) return;
-    const int SP4 = D.S * D.P4;
-    const int64_t total = (int64_t)SP4 * D.T;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into rows32: (k*S + s)*P4 + p
-    if (e >= total) return;
-    const int k = (int)(e / SP4);
-    const int rem = (int)(e - (int64_t)k * SP4);
-    const int sidx = rem / D.P4, p = rem - sidx * D.P4;
-    f2 q; q.x = FAR32; q.y = FAR32;
-    if (p < D.P) {
-        const int64_t in = D.dyn_off + ((int64_t)sidx * D.P + p) * D.T + k;
-        d2 v;
-        v.x = (double)src[2 * in];
-        v.y = (double)src[2 * in + 1];
-        rows[D.row_off + (int64_t)k * (D.S * D.P) + sidx * D.P + p] = v;
-        q.x = (float)(v.x - D.ego.x);
-        q.y = (float)(v.y - D.ego.y);
-    }
-    rows32[D.row32_off + e] = q;
-}
 
 // ---------------------------------------------------------------------------
 // ego -> Frenet state
@@ -199,11 +148,32 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__r
 
 struct ScratchSink {
     d2 *base;          // this wave's scratch + lane
-    int n_total;
+    float *wbox;       // this wave's boxes [n_total][4]
+    double ox, oy;     // instance origin
+    int n_total, lane;
+    Box32 cur;         // this lane's points of the current time step
     __device__ __forceinline__ void put(int k, int ci, double x, double y)
     {
         d2 v; v.x = x; v.y = y;
         base[((int64_t)ci * n_total + k) * WAVE] = v;
+        box_add(cur, (float)(x - ox), (float)(y - oy));
+    }
+    // every lane of the wave arrives here once per time step
+    __device__ __forceinline__ void row_done(int k)
+    {
+        Box32 b = cur;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Box32 o;
+            o.x0 = __shfl_xor(b.x0, off, WAVE); o.y0 = __shfl_xor(b.y0, off, WAVE);
+            o.x1 = __shfl_xor(b.x1, off, WAVE); o.y1 = __shfl_xor(b.y1, off, WAVE);
+            box_merge(b, o);
+        }
+        if (lane == 0) {
+            float4 w; w.x = b.x0; w.y = b.y0; w.z = b.x1; w.w = b.y1;
+            *(float4 *)(wbox + 4 * k) = w;
+        }
+        cur = box_empty();
     }
 };
 
@@ -223,9 +193,10 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
            const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
            const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
-           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep, d2 *__restrict__ pts)
+           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep, d2 *__restrict__ pts,
+           float *__restrict__ wave_box)
 {
-    // wave index through readfirstlane: everything derived from it (instance, descriptor, rows) is wave-uniform -> SGPRs
+    // wave index through readfirstlane: everything derived from it (instance, descriptor) is wave-uniform -> SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -235,12 +206,21 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const InstState &S = state[inst];
     const int idx = wave_base[wave] + lane;                    // candidate index inside the instance
     const int64_t slot = (int64_t)D.cand_off + idx;
-    if (!S.c2f_ok || idx >= S.n_cand) {
-        cand_status[slot] = 255;                               // padding lane: never counted
+    float *wbox = wave_box + (int64_t)wave * P.n_total * 4;
+    const bool live = S.c2f_ok && idx < S.n_cand;
+    if (!__any(live)) {                                        // whole wave idle: empty boxes, padding status
+        for (int k = lane; k < P.n_total; k += WAVE) {
+            float4 w; w.x = INFINITY; w.y = INFINITY; w.z = -INFINITY; w.w = -INFINITY;
+            *(float4 *)(wbox + 4 * k) = w;
+        }
+        cand_status[slot] = 255;
         cand_keep[slot] = 0;
         return;
     }
-    const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+    // padding lanes of a partially filled wave evaluate candidate 0 (results discarded) so that the wave
+    // stays converged for the cross-lane box reduction
+    const int eidx = live ? idx : 0;
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, eidx);
     const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
     const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
     double q[6];
@@ -248,40 +228,123 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 
     ScratchSink sink;
     sink.base = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
-    sink.n_total = P.n_total;
+    sink.wbox = wbox;
+    sink.ox = D.ego.x; sink.oy = D.ego.y;
+    sink.n_total = P.n_total; sink.lane = lane;
+    sink.cur = box_empty();
     CandResult r;
-    evaluate_candidate(P, D, L, tab, q, sink, r);
-    cand_cost[slot] = r.cost;
-    cand_vlast[slot] = r.v_last;
-    cand_travel[slot] = r.travel;
-    cand_status[slot] = (uint8_t)r.status;
-    cand_keep[slot] = (uint8_t)r.keep;
+    evaluate_candidate(P, D, L, tab, q, P.n_total, sink, r);
+    if (live) {
+        cand_cost[slot] = r.cost;
+        cand_vlast[slot] = r.v_last;
+        cand_travel[slot] = r.travel;
+        cand_status[slot] = (uint8_t)r.status;
+        cand_keep[slot] = (uint8_t)r.keep;
+    } else {
+        cand_status[slot] = 255;                               // padding lane: never counted
+        cand_keep[slot] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
-// collision
+// collision: cull + collide
 // ---------------------------------------------------------------------------
 
-// One wave = 64 candidates of one instance, lane = candidate.  Time steps, prediction samples and
-// obstacle points are walked wave-uniformly (obstacle rows come in through scalar loads); each lane
-// keeps the float32 minimum squared distance of the current row and only rows that come within the
-// conservative threshold are re-checked in float64, so the decision is the reference's.
+// One wave per (time step k = blockIdx.x, instance = blockIdx.y).  Entries of k: static obstacles first,
+// then the dynamic obstacles of time row min(k, T-1) in (sample, pedestrian) order, compacted to those inside
+// the candidates' bounding box of k grown by the collision radius, FAR32-padded to a multiple of 8.
+template <typename T>
+__global__ void __launch_bounds__(WAVE)
+k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const float *__restrict__ wave_box,
+       const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
+       int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid)
+{
+    const DevParams &P = *Pp;
+    const int inst = blockIdx.y, k = blockIdx.x;
+    const InstDesc &D = desc[inst];
+    if (D.ent_cap == 0) return;
+    const int lane = threadIdx.x;
+    // box of time step k over all waves of the instance
+    Box32 b = box_empty();
+    for (int w = lane; w < D.n_waves; w += WAVE) {
+        const float4 v = *(const float4 *)(wave_box + ((int64_t)(D.wave0 + w) * P.n_total + k) * 4);
+        Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
+        box_merge(b, o);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Box32 o;
+        o.x0 = __shfl_xor(b.x0, off, WAVE); o.y0 = __shfl_xor(b.y0, off, WAVE);
+        o.x1 = __shfl_xor(b.x1, off, WAVE); o.y1 = __shfl_xor(b.y1, off, WAVE);
+        box_merge(b, o);
+    }
+    const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
+    int count = 0;
+    if (b.x0 <= b.x1) {
+        const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+        const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, b);
+        const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
+        const int n_dyn = dyn_on ? D.S * D.P : 0;
+        const int total = D.n_static + n_dyn;
+        const int row = k < D.T - 1 ? k : D.T - 1;
+        for (int i0 = 0; i0 < total; i0 += WAVE) {
+            const int i = i0 + lane;
+            bool inside = false;
+            d2 o; o.x = 0.0; o.y = 0.0;
+            int sid = SID_STATIC;
+            if (i < total) {
+                if (i < D.n_static) {
+                    const int64_t in = D.static_off + i;
+                    o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
+                } else {
+                    const int j = i - D.n_static;                 // j = s*P + p
+                    const int64_t in = D.dyn_off + (int64_t)j * D.T + row;
+                    o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
+                    sid = j / D.P;
+                }
+                inside = cull_inside(b, margin, (float)(o.x - D.ego.x), (float)(o.y - D.ego.y));
+            }
+            const unsigned long long mask = __ballot(inside);
+            if (inside) {
+                const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+                f2 q; q.x = (float)(o.x - D.ego.x); q.y = (float)(o.y - D.ego.y);
+                ent32[base + pos] = q;
+                ent64[base + pos] = o;
+                ent_sid[base + pos] = (uint8_t)sid;
+            }
+            count += __popcll(mask);
+        }
+        const int padded = (count + ENT_CHUNK - 1) & ~(ENT_CHUNK - 1);
+        if (lane < padded - count) {
+            f2 q; q.x = FAR32; q.y = FAR32;
+            d2 o; o.x = INFINITY; o.y = INFINITY;
+            ent32[base + count + lane] = q;
+            ent64[base + count + lane] = o;
+            ent_sid[base + count + lane] = SID_STATIC;
+        }
+        count = padded;
+    }
+    if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = count;
+}
+
+// One wave = 64 candidates of one instance, lane = candidate.  Time steps and entry chunks are walked
+// wave-uniformly: a chunk (8 obstacles = 64 B) comes in through one scalar load that is issued one
+// chunk ahead of its use; each lane keeps the float32 minimum squared distance of the chunk and only chunks
+// that come within the conservative threshold are re-checked in float64, so the decision is the reference's.
 __global__ void __launch_bounds__(256)
 k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
           const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
-          const d2 *__restrict__ stat, const f2 *__restrict__ stat32, const d2 *__restrict__ rows,
-          const f2 *__restrict__ rows32, const d2 *__restrict__ pts,
+          const int32_t *__restrict__ ent_cnt, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
+          const uint8_t *__restrict__ ent_sid, const d2 *__restrict__ pts,
           uint8_t *__restrict__ cand_status, const uint8_t *__restrict__ cand_keep)
 {
-    // wave index through readfirstlane: everything derived from it (instance, descriptor, rows) is wave-uniform -> SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const DevParams &P = *Pp;
     const int inst = wave_inst[wave];
     const InstDesc &D = desc[inst];
-    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE && D.P > 0 && D.T > 0;
-    if (D.n_static == 0 && !dyn_on) return;
+    if (D.ent_cap == 0) return;
     const int64_t slot = (int64_t)D.cand_off + wave_base[wave] + lane;
     const bool pending = cand_status[slot] == ST_PENDING;
     const int keep = pending ? (int)cand_keep[slot] : 0;
@@ -293,14 +356,11 @@ k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
 
     const int n_circ = P.has_footprint ? P.n_circ : 1;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     const double ox0 = D.ego.x, oy0 = D.ego.y;
     const d2 *my_pts = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
-    const d2 *st64 = stat + D.static_off;
-    const f2 *st32 = stat32 + D.static32_off;
-    const d2 *r64 = rows + D.row_off;
-    const f2 *r32 = rows32 + D.row32_off;
-    const int S = D.S, Pn = D.P, P4 = D.P4, SP = D.S * D.P, T = D.T;
-    const int n_static = D.n_static, n_static4 = D.n_static4, max_viol = D.max_viol;
+    const int32_t *cnt = ent_cnt + (int64_t)inst * P.n_total;
+    const int ent_cap = D.ent_cap, max_viol = D.max_viol, n_total = P.n_total;
 
     bool collided = false;
     uint64_t hit_mask = 0;
@@ -308,25 +368,26 @@ k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
     for (int k = 0; k < kmax; ++k) {
         const bool act = !collided && k < keep;
         if (!__any(act)) break;                                   // keep is fixed: no lane can become active later
-        const int row = k < T - 1 ? k : T - 1;
+        const int n = cnt[k];
+        if (n == 0) continue;
+        const int64_t base = D.ent_off + (int64_t)k * ent_cap;
+        const f2x8 *chunks = (const f2x8 *)(ent32 + base);
         for (int ci = 0; ci < n_circ; ++ci) {
-            const d2 p = my_pts[((int64_t)ci * P.n_total + k) * WAVE];
+            const d2 p = my_pts[((int64_t)ci * n_total + k) * WAVE];
             const float fx = (float)(p.x - ox0), fy = (float)(p.y - oy0);
-            if (n_static > 0) {
-                const bool maybe = act && !collided && min_sqdist32(st32, n_static4, fx, fy) <= filter_threshold(P.sq_r, fx, fy);
-                if (maybe && hits_row(st64, n_static, p.x, p.y, P.sq_r)) collided = true;
-            }
-            if (!dyn_on) continue;
-            const float thr = filter_threshold(sq_dyn, fx, fy);
-            for (int s = 0; s < S; ++s) {
-                const float m = min_sqdist32(r32 + ((int64_t)row * S + s) * P4, P4, fx, fy);
-                const bool maybe = act && !collided && !((hit_mask >> s) & 1) && m <= thr;
+            const float thr = filter_threshold(sq_max, fx, fy);
+            const int n_chunks = n / ENT_CHUNK;
+            f2x8 cur = chunks[0];
+            for (int c = 0; c < n_chunks; ++c) {
+                const f2x8 nxt = chunks[c + 1 < n_chunks ? c + 1 : c];     // scalar prefetch of the next chunk
+                const float m = min_sqdist32_8(cur, fx, fy);
+                const bool maybe = act && !collided && m <= thr;
                 if (__any(maybe)) {
-                    if (maybe && hits_row(r64 + (int64_t)row * SP + s * Pn, Pn, p.x, p.y, sq_dyn)) {
-                        hit_mask |= (uint64_t)1 << s;
-                        if (++viol > max_viol) collided = true;
-                    }
+                    if (maybe)
+                        exact_chunk(ent64 + base + c * ENT_CHUNK, ent_sid + base + c * ENT_CHUNK, p.x, p.y, P.sq_r, sq_dyn,
+                                    max_viol, hit_mask, viol, collided);
                 }
+                cur = nxt;
             }
         }
     }
@@ -435,7 +496,8 @@ __global__ void k_spline_eval(SplineView sp, int n, const double *__restrict__ s
     out[4 * (int64_t)n + i] = dkappa;
 }
 
-// external-path collision check: one lane per path, points read from a [n_circ][FOT_MAX_NT][n_paths] array
+// external-path collision check: one lane per path, points read from a [n_circ][FOT_MAX_NT][n_paths] array,
+// obstacles straight from the caller's layout (exact float64 test, no broad phase)
 struct ExtSource {
     const d2 *base;
     const int32_t *tidx;   // [FOT_MAX_NT][n_paths], this path's column
@@ -450,7 +512,8 @@ struct ExtSource {
 
 __global__ void k_collide_ext(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int n_paths,
                               const int32_t *__restrict__ len, const d2 *__restrict__ pts,
-                              const int32_t *__restrict__ tidx, const d2 *__restrict__ stat, const d2 *__restrict__ rows, int32_t *__restrict__ free_out)
+                              const int32_t *__restrict__ tidx, const double *__restrict__ static_xy,
+                              const double *__restrict__ dyn_xy, int32_t *__restrict__ free_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_paths) return;
@@ -459,7 +522,9 @@ __global__ void k_collide_ext(const DevParams *__restrict__ Pp, const InstDesc *
     src.tidx = tidx + i;
     src.stride_k = n_paths;
     src.stride_c = (int64_t)FOT_MAX_NT * n_paths;
-    const bool hit = len[i] > 0 && collide_candidate(*Pp, desc[0], stat, rows, len[i], src);
+    ObstacleView obs;
+    obs.stat = static_xy; obs.dyn = dyn_xy; obs.dtype = FOT_F64;
+    const bool hit = len[i] > 0 && collide_candidate(*Pp, desc[0], obs, len[i], src);
     free_out[i] = hit ? 0 : 1;
 }
 
@@ -468,30 +533,6 @@ __global__ void k_collide_ext(const DevParams *__restrict__ Pp, const InstDesc *
 // ---------------------------------------------------------------------------
 
 #define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
-
-int launch_prep_static(const InstDesc *desc, int n_inst, int max_static4, const void *src, int dtype, d2 *stat,
-                       f2 *stat32, hipStream_t st)
-{
-    if (max_static4 <= 0 || n_inst <= 0) return 0;
-    const int bs = 64;
-    dim3 grid((unsigned)((max_static4 + bs - 1) / bs), (unsigned)n_inst);
-    if (dtype == FOT_F32) k_prep_static<float><<<grid, bs, 0, st>>>(desc, (const float *)src, stat, stat32);
-    else k_prep_static<double><<<grid, bs, 0, st>>>(desc, (const double *)src, stat, stat32);
-    FOT_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_prep_dyn(const InstDesc *desc, int n_inst, int64_t max_rows32, const void *src, int dtype, d2 *rows,
-                    f2 *rows32, hipStream_t st)
-{
-    if (max_rows32 <= 0 || n_inst <= 0) return 0;
-    const int bs = 256;
-    dim3 grid((unsigned)((max_rows32 + bs - 1) / bs), (unsigned)n_inst);
-    if (dtype == FOT_F32) k_prep_dyn<float><<<grid, bs, 0, st>>>(desc, (const float *)src, rows, rows32);
-    else k_prep_dyn<double><<<grid, bs, 0, st>>>(desc, (const double *)src, rows, rows32);
-    FOT_LAUNCH_CHECK();
-    return 0;
-}
 
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         hipStream_t st)
@@ -514,24 +555,39 @@ int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, co
 
 int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                     const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
-                    CandArrays c, d2 *pts, hipStream_t st)
+                    CandArrays c, d2 *pts, float *wave_box, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
     const int wpb = 256 / WAVE;
     k_evaluate<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, state, lon_info, lon_tab, wave_inst, wave_base,
-                                                         n_waves, c.cost, c.v_last, c.travel, c.status, c.keep, pts);
+                                                         n_waves, c.cost, c.v_last, c.travel, c.status, c.keep, pts,
+                                                         wave_box);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_cull(const DevParams *P, const InstDesc *desc, int n_inst, int n_total, const float *wave_box,
+                const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, hipStream_t st)
+{
+    if (n_inst <= 0 || n_total <= 0) return 0;
+    dim3 grid((unsigned)n_total, (unsigned)n_inst);
+    if (dtype == FOT_F32)
+        k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, wave_box, (const float *)static_xy, (const float *)dyn_xy,
+                                             e.cnt, e.e32, e.e64, e.sid);
+    else
+        k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, wave_box, (const double *)static_xy, (const double *)dyn_xy,
+                                              e.cnt, e.e32, e.e64, e.sid);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
-                   int n_waves, const d2 *stat, const f2 *stat32, const d2 *rows, const f2 *rows32, const d2 *pts,
-                   CandArrays c, hipStream_t st)
+                   int n_waves, EntryArrays e, const d2 *pts, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
     const int wpb = 256 / WAVE;
-    k_collide<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, wave_inst, wave_base, n_waves, stat, stat32, rows,
-                                                        rows32, pts, c.status, c.keep);
+    k_collide<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, wave_inst, wave_base, n_waves, e.cnt, e.e32, e.e64,
+                                                        e.sid, pts, c.status, c.keep);
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -555,10 +611,11 @@ int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipSt
 }
 
 int launch_collide_ext(const DevParams *P, const InstDesc *desc, int n_paths, const int32_t *len, const d2 *pts,
-                       const int32_t *tidx, const d2 *stat, const d2 *rows, int32_t *free_out, hipStream_t st)
+                       const int32_t *tidx, const double *static_xy, const double *dyn_xy, int32_t *free_out,
+                       hipStream_t st)
 {
     if (n_paths <= 0) return 0;
-    k_collide_ext<<<(n_paths + 63) / 64, 64, 0, st>>>(P, desc, n_paths, len, pts, tidx, stat, rows, free_out);
+    k_collide_ext<<<(n_paths + 63) / 64, 64, 0, st>>>(P, desc, n_paths, len, pts, tidx, static_xy, dyn_xy, free_out);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -324,10 +324,12 @@ FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d,
     }
 }
 
-// Sink::put(k, circle, x, y) receives the collision points of the kept prefix.
+// Sink::put(k, circle, x, y) receives the collision points of the kept prefix; Sink::row_done(k) is
+// called once per time step by EVERY lane of the wave (n_loop is wave-uniform, >= n_t), so that it
+// may use cross-lane operations.
 template <class Sink>
 FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const double *lon_tab,
-                               const double *q, Sink &sink, CandResult &out)
+                               const double *q, int n_loop, Sink &sink, CandResult &out)
 {
     const int n_t = L.n_t;
     double Jp = 0.0, d_last = 0.0;
@@ -338,7 +340,8 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
     double xp = 0.0, yp = 0.0, dprev = 0.0, sprev = 0.0, cprev = 1.0, snprev = 0.0;
     double v_last = 0.0, s_last = 0.0, s_first = 0.0;
 
-    for (int k = 0; k < n_t; ++k) {
+    for (int k = 0; k < n_loop; ++k) {
+      if (k < n_t) {
         double d, d_d, d_dd, d_ddd;
         lat_sample(q, k, L.n_eval, P.dt, d, d_d, d_dd, d_ddd);
         Jp += d_ddd * d_ddd;
@@ -382,6 +385,8 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
             v_last = c.v; s_last = ls.s;
             xp = c.x; yp = c.y; dprev = d; sprev = ls.s; cprev = c.cos_t; snprev = c.sin_t;
         }
+      }
+      sink.row_done(k);
     }
 
     int keep = n_t;
@@ -412,39 +417,122 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
 // collision (reference: frenet_planner.py:1035-1233)
 // ---------------------------------------------------------------------------
 
-// any of the n obstacle points within sqrt(sq) of (px, py)   (:1196-1198, :1231-1233)
-FOT_HD bool hits_row(const d2 *row, int n, double px, double py, double sq)
-{
-    bool hit = false;
-    for (int j = 0; j < n; ++j) {
-        const double dx = px - row[j].x, dy = py - row[j].y;
-        if (dx * dx + dy * dy <= sq) hit = true;
+// obstacles of one instance in the caller's layout: static [n][2], dynamic [S][P][T][2]
+struct ObstacleView {
+    const void *stat;
+    const void *dyn;
+    int dtype;                         // FOT_F32 | FOT_F64
+    FOT_HD d2 at(const void *base, int64_t i) const
+    {
+        d2 o;
+        if (dtype == FOT_F32) { o.x = (double)((const float *)base)[2 * i]; o.y = (double)((const float *)base)[2 * i + 1]; }
+        else { o.x = ((const double *)base)[2 * i]; o.y = ((const double *)base)[2 * i + 1]; }
+        return o;
     }
-    return hit;
+    FOT_HD d2 static_at(int j) const { return at(stat, j); }
+    FOT_HD d2 dyn_at(int s, int p, int row, int P, int T) const { return at(dyn, ((int64_t)s * P + p) * T + row); }
+};
+
+FOT_HD bool within(const d2 &o, double px, double py, double sq)       // (:1196-1198, :1231-1233)
+{
+    const double dx = px - o.x, dy = py - o.y;
+    return dx * dx + dy * dy <= sq;
 }
 
-// ---- float32 broad phase -------------------------------------------------------------------
-// Obstacles and path points are also kept in float32 relative to the instance origin (the ego
-// position).  min_sqdist32 gives the smallest float32 squared distance of a row; a pair can only
-// pass the exact float64 test (dx*dx + dy*dy <= sq) if its float32 value is <= filter_threshold(),
-// so rows above the threshold are skipped and rows below it are re-checked exactly.  The decision
-// is therefore always the float64 one of the reference.
-
-// smallest float32 squared distance from (px, py) to n4 points (n4 % 4 == 0, FAR32 padded)
-FOT_HD float min_sqdist32(const f2 *r, int n4, float px, float py)
+// Exact per-candidate check, straight from the definition.  Source::get(k, circle, x, y) returns the
+// collision points; Source::tindex(k) is round(t_k/dt) (== k for lattice candidates).
+// Returns true when the candidate violates the (chance) constraint.
+template <class Source>
+FOT_HD bool collide_candidate(const DevParams &P, const InstDesc &D, const ObstacleView &obs, int keep, const Source &src)
 {
-    float m = INFINITY;
-    for (int j = 0; j < n4; j += 4) {
-        const float dx0 = px - r[j].x, dy0 = py - r[j].y;
-        const float dx1 = px - r[j + 1].x, dy1 = py - r[j + 1].y;
-        const float dx2 = px - r[j + 2].x, dy2 = py - r[j + 2].y;
-        const float dx3 = px - r[j + 3].x, dy3 = py - r[j + 3].y;
-        const float t0 = fmaf(dy0, dy0, dx0 * dx0), t1 = fmaf(dy1, dy1, dx1 * dx1);
-        const float t2 = fmaf(dy2, dy2, dx2 * dx2), t3 = fmaf(dy3, dy3, dx3 * dx3);
-        m = fminf(fminf(m, t0), t1);
-        m = fminf(fminf(m, t2), t3);
+    const int n_circ = P.has_footprint ? P.n_circ : 1;
+    for (int k = 0; k < keep && D.n_static > 0; ++k)
+        for (int ci = 0; ci < n_circ; ++ci) {
+            double px, py;
+            src.get(k, ci, px, py);
+            for (int j = 0; j < D.n_static; ++j)
+                if (within(obs.static_at(j), px, py, P.sq_r)) return true;
+        }
+    if (D.dyn_mode == FOT_DYN_NONE || D.P <= 0 || D.T <= 0) return false;
+    const double sq = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    uint64_t hit_mask = 0;
+    int viol = 0;
+    for (int k = 0; k < keep; ++k) {
+        int row = src.tindex(k);                                            // clip(round(t/dt), 0, T-1)
+        row = row < 0 ? 0 : (row > D.T - 1 ? D.T - 1 : row);
+        for (int ci = 0; ci < n_circ; ++ci) {
+            double px, py;
+            src.get(k, ci, px, py);
+            for (int s = 0; s < D.S; ++s) {
+                if ((hit_mask >> s) & 1) continue;
+                bool hit = false;
+                for (int p = 0; p < D.P; ++p)
+                    if (within(obs.dyn_at(s, p, row, D.P, D.T), px, py, sq)) hit = true;
+                if (hit) {
+                    hit_mask |= (uint64_t)1 << s;
+                    if (++viol > D.max_viol) return true;
+                }
+            }
+        }
     }
-    return m;
+    return false;
+}
+
+// ---- broad phase ------------------------------------------------------------------------------
+// Two conservative reductions in front of the exact test, neither of which can change a decision:
+//  1. per (instance, time step k): the float32 bounding box of every candidate's collision points
+//     at k.  Only obstacles (of the time row of k) inside that box grown by the collision radius can
+//     touch any candidate at k; they are compacted into an entry list (k_cull).
+//  2. per entry chunk: float32 squared distances in the instance-local frame against
+//     filter_threshold(); only chunks that come within the threshold are re-checked in float64.
+
+struct Box32 {
+    float x0, y0, x1, y1;                                                   // empty when x0 > x1
+};
+
+FOT_HD Box32 box_empty()
+{
+    Box32 b; b.x0 = INFINITY; b.y0 = INFINITY; b.x1 = -INFINITY; b.y1 = -INFINITY; return b;
+}
+
+FOT_HD void box_add(Box32 &b, float x, float y)
+{
+    b.x0 = fminf(b.x0, x); b.y0 = fminf(b.y0, y); b.x1 = fmaxf(b.x1, x); b.y1 = fmaxf(b.y1, y);
+}
+
+FOT_HD void box_merge(Box32 &b, const Box32 &o)
+{
+    b.x0 = fminf(b.x0, o.x0); b.y0 = fminf(b.y0, o.y0); b.x1 = fmaxf(b.x1, o.x1); b.y1 = fmaxf(b.y1, o.y1);
+}
+
+// growth of the box: collision radius + float32 rounding of both points + slack
+FOT_HD float cull_margin(double max_sq, const Box32 &b)
+{
+    return sqrtf((float)max_sq) * 1.000001f + 1e-3f
+           + 2.4e-7f * (fabsf(b.x0) + fabsf(b.x1) + fabsf(b.y0) + fabsf(b.y1));
+}
+
+FOT_HD bool cull_inside(const Box32 &b, float m, float fx, float fy)
+{
+    return fx >= b.x0 - m && fx <= b.x1 + m && fy >= b.y0 - m && fy <= b.y1 + m;
+}
+
+constexpr int ENT_CHUNK = 8;                                                // entries per broad-phase chunk
+constexpr int SID_STATIC = 255;                                             // entry is a static obstacle
+struct alignas(64) f2x8 { f2 v[ENT_CHUNK]; };
+
+// smallest float32 squared distance from (fx, fy) to the 8 entries of a chunk (FAR32 padded)
+FOT_HD float min_sqdist32_8(const f2x8 &c, float fx, float fy)
+{
+    float t[ENT_CHUNK];
+    for (int j = 0; j < ENT_CHUNK; ++j) {
+        const float dx = fx - c.v[j].x, dy = fy - c.v[j].y;
+        t[j] = fmaf(dy, dy, dx * dx);
+    }
+    float m = fminf(fminf(t[0], t[1]), t[2]);
+    m = fminf(fminf(m, t[3]), t[4]);
+    m = fminf(fminf(m, t[5]), t[6]);
+    return fminf(m, t[7]);
 }
 
 // Upper bound of the float32 squared distance of any pair whose float64 squared distance is <= sq.
@@ -458,81 +546,48 @@ FOT_HD float filter_threshold(double sq, float px, float py)
     return ((float)sq + 4.0f * r * e) * 1.000002f + 1e-30f;
 }
 
-// per-candidate collision check with the float32 broad phase (same result as collide_candidate)
+// exact float64 test of one chunk (the reference's test); updates the per-sample hit state
+FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py, double sq_static, double sq_dyn,
+                        int max_viol, uint64_t &hit_mask, int &viol, bool &collided)
+{
+    for (int j = 0; j < ENT_CHUNK; ++j) {
+        const int s = sid[j];
+        if (s == SID_STATIC) {
+            if (within(e64[j], px, py, sq_static)) collided = true;         // static obstacles are hard constraints
+        } else if (!((hit_mask >> s) & 1) && within(e64[j], px, py, sq_dyn)) {
+            hit_mask |= (uint64_t)1 << s;
+            if (++viol > max_viol) collided = true;
+        }
+    }
+}
+
+// per-candidate check against the culled entry lists (same decision as collide_candidate)
+// cnt[k]: entries of time step k (multiple of 8); entry arrays hold D.ent_cap slots per k
 template <class Source>
-FOT_HD bool collide_candidate_filtered(const DevParams &P, const InstDesc &D, const d2 *stat, const f2 *stat32,
-                                       const d2 *rows, const f2 *rows32, int keep, const Source &src)
+FOT_HD bool collide_entries(const DevParams &P, const InstDesc &D, const int32_t *cnt, const f2 *e32, const d2 *e64,
+                            const uint8_t *sid, int keep, const Source &src)
 {
     const int n_circ = P.has_footprint ? P.n_circ : 1;
-    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE && D.P > 0 && D.T > 0;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    const int SP = D.S * D.P;
+    const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     uint64_t hit_mask = 0;
     int viol = 0;
-    for (int k = 0; k < keep; ++k) {
-        int row = src.tindex(k);
-        row = row < 0 ? 0 : (row > D.T - 1 ? D.T - 1 : row);
-        for (int ci = 0; ci < n_circ; ++ci) {
+    bool collided = false;
+    for (int k = 0; k < keep && !collided; ++k) {
+        const int n = cnt[k];
+        const int64_t base = (int64_t)k * D.ent_cap;
+        for (int ci = 0; ci < n_circ && !collided; ++ci) {
             double px, py;
             src.get(k, ci, px, py);
             const float fx = (float)(px - D.ego.x), fy = (float)(py - D.ego.y);
-            if (D.n_static > 0 && min_sqdist32(stat32, D.n_static4, fx, fy) <= filter_threshold(P.sq_r, fx, fy)
-                && hits_row(stat, D.n_static, px, py, P.sq_r))
-                return true;
-            if (!dyn_on) continue;
-            const float thr = filter_threshold(sq_dyn, fx, fy);
-            for (int s = 0; s < D.S; ++s) {
-                if ((hit_mask >> s) & 1) continue;
-                if (min_sqdist32(rows32 + ((int64_t)row * D.S + s) * D.P4, D.P4, fx, fy) > thr) continue;
-                if (hits_row(rows + (int64_t)row * SP + s * D.P, D.P, px, py, sq_dyn)) {
-                    hit_mask |= (uint64_t)1 << s;
-                    if (++viol > D.max_viol) return true;
-                }
+            const float thr = filter_threshold(sq_max, fx, fy);
+            for (int c = 0; c < n && !collided; c += ENT_CHUNK) {
+                if (min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy) > thr) continue;
+                exact_chunk(e64 + base + c, sid + base + c, px, py, P.sq_r, sq_dyn, D.max_viol, hit_mask, viol, collided);
             }
         }
     }
-    return false;
-}
-
-// Source::get(k, circle, x, y) returns the stored collision points; Source::tindex(k) is
-// round(t_k/dt) (== k for lattice candidates).
-// stat: [n_static] points; rows: transposed dynamic obstacles [T][S*P].
-// Returns true when the candidate violates the (chance) constraint.
-template <class Source>
-FOT_HD bool collide_candidate(const DevParams &P, const InstDesc &D, const d2 *stat, const d2 *rows,
-                              int keep, const Source &src)
-{
-    const int n_circ = P.has_footprint ? P.n_circ : 1;
-    if (D.n_static > 0) {
-        for (int k = 0; k < keep; ++k)
-            for (int ci = 0; ci < n_circ; ++ci) {
-                double px, py;
-                src.get(k, ci, px, py);
-                if (hits_row(stat, D.n_static, px, py, P.sq_r)) return true;
-            }
-    }
-    if (D.dyn_mode == FOT_DYN_NONE || D.P <= 0 || D.T <= 0) return false;
-    const double sq = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    const int SP = D.S * D.P;
-    uint64_t hit_mask = 0;
-    int viol = 0;
-    for (int k = 0; k < keep; ++k) {
-        int row = src.tindex(k);                                            // clip(round(t/dt), 0, T-1)
-        row = row < 0 ? 0 : (row > D.T - 1 ? D.T - 1 : row);
-        const d2 *r = rows + (int64_t)row * SP;
-        for (int ci = 0; ci < n_circ; ++ci) {
-            double px, py;
-            src.get(k, ci, px, py);
-            for (int s = 0; s < D.S; ++s) {
-                if ((hit_mask >> s) & 1) continue;
-                if (hits_row(r + s * D.P, D.P, px, py, sq)) {
-                    hit_mask |= (uint64_t)1 << s;
-                    if (++viol > D.max_viol) return true;
-                }
-            }
-        }
-    }
-    return false;
+    return collided;
 }
 
 // ---------------------------------------------------------------------------

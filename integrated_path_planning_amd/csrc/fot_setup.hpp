@@ -172,14 +172,10 @@ struct BatchLayout {
     int64_t n_slots = 0;          // candidate slots (64 per wave)
     int64_t n_lon = 0;            // longitudinal profile slots
     int max_lon = 0;              // max profiles of one instance
-    int64_t n_static = 0;         // static points in the batch
-    int64_t n_dyn_points = 0;     // dynamic points in the batch (== transposed rows size)
-    int64_t max_dyn_points = 0;   // of one instance
-    int64_t dyn_src_points = 0;   // extent of the caller's dyn_xy that is referenced
-    int64_t n_rows32 = 0;         // float2 entries of the padded float32 rows
-    int64_t max_rows32 = 0;       // of one instance
-    int64_t n_static32 = 0;       // float2 entries of the padded float32 static points
-    int max_static4 = 0;          // of one instance
+    int64_t n_static = 0;         // extent of the caller's static_xy that is referenced (points)
+    int64_t dyn_src_points = 0;   // extent of the caller's dyn_xy that is referenced (points)
+    int64_t n_entries = 0;        // broad-phase entry slots in the batch (n_total * ent_cap per instance)
+    bool any_obstacles = false;
 };
 
 inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fot_batch &b, BatchLayout &L,
@@ -222,6 +218,8 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         const int n_waves_i = (D.n_cand_max + WAVE - 1) / WAVE;
         if (L.n_slots + (int64_t)n_waves_i * WAVE > 0x7fffffffLL) { err = "batch too large"; return FOT_ERR_UNSUPPORTED; }
         D.cand_off = (int32_t)L.n_slots;
+        D.wave0 = (int32_t)L.wave_inst.size();
+        D.n_waves = n_waves_i;
         for (int w = 0; w < n_waves_i; ++w) { L.wave_inst.push_back(i); L.wave_base.push_back(w * WAVE); }
         L.n_slots += (int64_t)n_waves_i * WAVE;
         const int n_lon_i = P.n_ti * D.n_tv + P.n_brake;
@@ -235,10 +233,6 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
             D.static_off = lo;
             D.n_static = (int32_t)(hi - lo);
             if (hi > L.n_static) L.n_static = hi;
-            D.n_static4 = (D.n_static + 3) & ~3;
-            D.static32_off = L.n_static32;
-            L.n_static32 += D.n_static4;
-            if (D.n_static4 > L.max_static4) L.max_static4 = D.n_static4;
         }
         D.dyn_mode = FOT_DYN_NONE;
         if (b.dyn_off && b.dyn_dims) {
@@ -254,22 +248,22 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
                 if (b.dyn_off[i] < 0) { err = "dyn_off < 0"; return FOT_ERR_INVALID; }
                 D.dyn_mode = mode; D.S = S; D.P = Pn; D.T = T;
                 D.dyn_off = b.dyn_off[i];
-                D.row_off = L.n_dyn_points;
                 const int64_t pts = (int64_t)S * Pn * T;
-                L.n_dyn_points += pts;
-                if (pts > L.max_dyn_points) L.max_dyn_points = pts;
                 if (D.dyn_off + pts > L.dyn_src_points) L.dyn_src_points = D.dyn_off + pts;
-                D.P4 = (Pn + 3) & ~3;
-                D.row32_off = L.n_rows32;
-                const int64_t e32 = (int64_t)T * S * D.P4;
-                L.n_rows32 += e32;
-                if (e32 > L.max_rows32) L.max_rows32 = e32;
                 D.max_viol = mode == FOT_DYN_DISTRIBUTION ? (int)std::floor(hp.chance_epsilon * (double)S) : 0;
             }
         }
+        const int64_t per_k = (int64_t)D.n_static + (D.dyn_mode != FOT_DYN_NONE ? (int64_t)D.S * D.P : 0);
+        if (per_k > 0) {
+            if (per_k > (1 << 24)) { err = "too many obstacle points in one instance"; return FOT_ERR_UNSUPPORTED; }
+            D.ent_cap = (int32_t)((per_k + 7) & ~(int64_t)7);
+            D.ent_off = L.n_entries;
+            L.n_entries += (int64_t)D.ent_cap * P.n_total;
+            L.any_obstacles = true;
+        }
     }
     L.n_waves = (int)L.wave_inst.size();
-    if ((L.n_static > 0 && !b.static_xy) || (L.n_dyn_points > 0 && !b.dyn_xy)) {
+    if ((L.n_static > 0 && !b.static_xy) || (L.dyn_src_points > 0 && !b.dyn_xy)) {
         err = "obstacle offsets given without coordinates";
         return FOT_ERR_INVALID;
     }

@@ -67,16 +67,14 @@ struct InstDesc {
     int32_t n_cand_max;                  // n_grid + n_brake
     int32_t lon_off;                     // first longitudinal-profile slot
     int32_t n_static;
-    int64_t static_off;                  // points into static_xy
+    int64_t static_off;                  // points into the caller's static_xy
     int32_t dyn_mode, S, P, T;
     int64_t dyn_off;                     // points into the caller's dyn_xy
-    int64_t row_off;                     // points into the transposed obstacle rows
-    int64_t row32_off;                   // float2 entries into the local-frame float32 rows [T][S][P4]
-    int64_t static32_off;                // float2 entries into the local-frame float32 static points
-    int32_t P4;                          // P rounded up to a multiple of 4 (FAR32 padding)
-    int32_t n_static4;                   // n_static rounded up to a multiple of 4
+    int64_t ent_off;                     // first broad-phase entry slot of this instance
+    int32_t ent_cap;                     // entry slots per time step (multiple of 8): S*P + n_static rounded up
+    int32_t wave0;                       // first wave of this instance
+    int32_t n_waves;                     // waves of this instance
     int32_t max_viol;                    // floor(eps*S)
-    int32_t _pad;
 };
 
 // device-produced per-instance state
