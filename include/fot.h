@@ -177,6 +177,11 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
 int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
                          int32_t *status, int32_t *keep, int32_t *n_t);
 
+/* All 15 FrenetPath arrays of candidate `index` of instance `inst` of the most recent plan call, BEFORE
+ * truncation (what _generate_frenet_paths + _calc_global_paths produce, frenet_planner.py:376-503, 736-889):
+ * arrays[15][FOT_MAX_NT] in fot_result field order, *n_t = generated samples. */
+int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double *arrays, int32_t *n_t);
+
 /* FrenetPlanner._path_is_collision_free (frenet_planner.py:1035-1233) for n_paths externally
  * supplied paths against ONE obstacle set.  x, y, yaw, t: [n_paths][FOT_MAX_NT] host, len[n_paths];
  * static_xy [n_static][2] double host; dyn [S][P][T][2] double host with mode as in dyn_dims.
@@ -186,6 +191,19 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
                               int32_t n_static, const double *static_xy,
                               int32_t mode, int32_t S, int32_t P, int32_t T, const double *dyn,
                               int32_t *free_out);
+
+/* FrenetPlanner._check_paths (frenet_planner.py:891-993) followed by _apply_stop_distance_filter (:307-324)
+ * for n_paths externally supplied paths: arrays [n_paths][FOT_MAX_NT] host (yaw, d, s may be NULL = zeros),
+ * len[n_paths], flags[n_paths] (bit0: x/y/yaw/s/d all present -> low-speed curvature rules apply, :1017-1022;
+ * bit1: d present -> road-corridor test applies; NULL = both), overrides may be NULL, max_stop_distance NaN = None,
+ * obstacle set as in fot_check_collision_paths.  status_out[n_paths]: FOT_ST_* (FOT_ST_OK = 'ok', FOT_ST_DROPPED =
+ * silently skipped). */
+int fot_check_paths(fot_handle *h, int32_t n_paths, const int32_t *len, const int32_t *flags,
+                    const double *x, const double *y, const double *yaw, const double *v, const double *a,
+                    const double *c, const double *d, const double *s, const double *t,
+                    const fot_overrides *overrides, double max_stop_distance,
+                    int32_t n_static, const double *static_xy,
+                    int32_t mode, int32_t S, int32_t P, int32_t T, const double *dyn, int32_t *status_out);
 
 /* ---- measurement (no reference counterpart: the reference times plan() with perf_counter,
  *      integrated_simulator.py:575-585) ----

@@ -81,7 +81,7 @@ LIB_PATH = os.path.join(_HERE, "libfot.so")
 SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_set_path_waypoints",
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
-           "fot_check_collision_paths", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
+           "fot_debug_candidate_path", "fot_check_collision_paths", "fot_check_paths", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 6
 
 _lib = None
@@ -123,6 +123,9 @@ def lib():
     L.fot_debug_candidates.argtypes = [vp, C.c_int32, C.c_int32, dp, ip, ip, ip]
     L.fot_check_collision_paths.argtypes = [vp, C.c_int32, ip, dp, dp, dp, dp, C.c_int32, dp,
                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip]
+    L.fot_debug_candidate_path.argtypes = [vp, C.c_int32, C.c_int32, dp, ip]
+    L.fot_check_paths.argtypes = [vp, C.c_int32, ip, ip] + [dp] * 9 + [C.POINTER(Overrides), C.c_double, C.c_int32, dp,
+                                                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip]
     L.fot_profile_enable.argtypes = [vp, C.c_int]
     L.fot_profile_read.argtypes = [vp, C.c_int, ip, dp]
     L.fot_profile_kernel_name.argtypes = [C.c_int]

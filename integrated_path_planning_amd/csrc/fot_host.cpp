@@ -516,25 +516,53 @@ int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
     return n;
 }
 
-int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len,
-                              const double *x, const double *y, const double *yaw, const double *t,
-                              int32_t n_static, const double *static_xy,
-                              int32_t mode, int32_t S, int32_t Pn, int32_t T, const double *dyn,
-                              int32_t *free_out)
+int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double *arrays, int32_t *n_t)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->last_valid) return fail(h, FOT_ERR_INVALID, "no completed plan call on this handle");
+    const BatchLayout &L = h->last;
+    if (inst < 0 || inst >= L.n_inst) return fail(h, FOT_ERR_INVALID, "instance index out of range");
+    if (!arrays) return fail(h, FOT_ERR_INVALID, "arrays is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, h->dTmpA.ensure(sizeof(double) * 15 * FOT_MAX_NT));
+    HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * 2));
+    HIP_TRY(h, hipMemsetAsync(h->dTmpA.p, 0, sizeof(double) * 15 * FOT_MAX_NT, h->stream));
+    LAUNCH_TRY(h, launch_debug_path(h->dP.as<DevParams>(), (const InstDesc *)h->dMeta.p, h->dState.as<InstState>(),
+                                    h->dLonInfo.as<LonInfo>(), h->dLonTab.as<double>(), inst, index,
+                                    h->dTmpA.as<double>(), h->dTmpD.as<int32_t>(), h->stream));
+    int32_t meta[2] = { 0, 0 };
+    HIP_TRY(h, hipMemcpyAsync(arrays, h->dTmpA.p, sizeof(double) * 15 * FOT_MAX_NT, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(meta, h->dTmpD.p, sizeof(meta), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!meta[1]) return fail(h, FOT_ERR_INVALID, "candidate index out of range");
+    if (n_t) *n_t = meta[0];
+    return FOT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// shared body of fot_check_collision_paths (mode 0) and fot_check_paths (mode 1)
+int check_ext(fot_handle *h, int mode, int32_t n_paths, const int32_t *len, const int32_t *flags,
+              const double *const arr[9], const fot_overrides *ov, double max_stop,
+              int32_t n_static, const double *static_xy, int32_t dmode, int32_t S, int32_t Pn, int32_t T,
+              const double *dyn, int32_t *status_out)
 {
     if (!h) return FOT_ERR_INVALID;
     if (n_paths <= 0) return FOT_OK;
-    if (!len || !x || !y || !t || !free_out) return fail(h, FOT_ERR_INVALID, "NULL path array");
+    if (!len || !status_out) return fail(h, FOT_ERR_INVALID, "NULL path array");
     const DevParams &P = h->P;
-    if (P.has_footprint && !yaw) return fail(h, FOT_ERR_INVALID, "yaw is required with a multi-circle footprint");
-    // one single-instance batch carries the obstacle set
+    // one single-instance batch carries limits + obstacle set
     fot_ego ego = {};
     double target = 0.0;
     int32_t soff[2] = { 0, n_static > 0 ? n_static : 0 };
     int64_t doff[1] = { 0 };
-    int32_t dims[4] = { mode, S, Pn, T };
+    int32_t dims[4] = { dmode, S, Pn, T };
     fot_batch b = {};
     b.n_inst = 1; b.obstacle_dtype = FOT_F64; b.ego = &ego; b.target_speed = &target;
+    b.overrides = ov; b.max_stop_distance = &max_stop;
     b.static_xy = static_xy; b.static_off = soff; b.dyn_xy = dyn; b.dyn_off = doff; b.dyn_dims = dims;
     BatchLayout L;
     std::string err;
@@ -542,57 +570,69 @@ int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len
     if (rc != FOT_OK) return fail(h, rc, err);
     h->last_valid = false;
 
-    // collision points [n_circ][FOT_MAX_NT][n_paths] and time indices [FOT_MAX_NT][n_paths]
-    // (footprint expansion: frenet_planner.py:1152-1170; time index: :1226)
-    const size_t np = (size_t)n_paths;
-    std::vector<d2> pts((size_t)P.n_circ * FOT_MAX_NT * np);
-    std::vector<int32_t> tidx((size_t)FOT_MAX_NT * np, 0);
-    for (int i = 0; i < n_paths; ++i) {
+    const size_t np = (size_t)n_paths, plane = np * FOT_MAX_NT;
+    std::vector<double> flat(9 * plane, 0.0);
+    for (int i = 0; i < n_paths; ++i)
         if (len[i] < 0 || len[i] > FOT_MAX_NT) return fail(h, FOT_ERR_INVALID, "path length out of range");
-        for (int k = 0; k < len[i]; ++k) {
-            const size_t src = (size_t)i * FOT_MAX_NT + k;
-            tidx[(size_t)k * np + i] = (int32_t)std::nearbyint(t[src] / P.dt);
-            for (int c = 0; c < P.n_circ; ++c) {
-                d2 v;
-                if (P.has_footprint) {
-                    v.x = x[src] + P.circ_off[c] * std::cos(yaw[src]);
-                    v.y = y[src] + P.circ_off[c] * std::sin(yaw[src]);
-                } else {
-                    v.x = x[src]; v.y = y[src];
-                }
-                pts[((size_t)c * FOT_MAX_NT + k) * np + i] = v;
-            }
-        }
-    }
+    for (int f = 0; f < 9; ++f)
+        if (arr[f]) std::memcpy(flat.data() + f * plane, arr[f], sizeof(double) * plane);
+    std::vector<int32_t> meta(2 * np, 3);
+    std::memcpy(meta.data(), len, sizeof(int32_t) * np);
+    if (flags) std::memcpy(meta.data() + np, flags, sizeof(int32_t) * np);
+
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
     HIP_TRY(h, hipStreamSynchronize(st));
     const size_t st_bytes = sizeof(double) * 2 * (size_t)L.n_static, dy_bytes = sizeof(double) * 2 * (size_t)L.dyn_src_points;
     HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
     HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
-    HIP_TRY(h, h->dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
-    const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
-    HIP_TRY(h, h->dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
-    HIP_TRY(h, h->dEnt32.ensure(sizeof(f2) * n_ent));
-    HIP_TRY(h, h->dEnt64.ensure(sizeof(d2) * n_ent));
-    HIP_TRY(h, h->dEntSid.ensure(n_ent));
     HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc)));
-    HIP_TRY(h, h->dTmpB.ensure(sizeof(d2) * pts.size()));
-    HIP_TRY(h, h->dTmpC.ensure(sizeof(int32_t) * (tidx.size() + np)));
+    HIP_TRY(h, h->dTmpB.ensure(sizeof(double) * flat.size()));
+    HIP_TRY(h, h->dTmpC.ensure(sizeof(int32_t) * meta.size()));
     HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * np));
     if (st_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserStatic.p, static_xy, st_bytes, hipMemcpyHostToDevice, st));
     if (dy_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserDyn.p, dyn, dy_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, L.desc.data(), sizeof(InstDesc), hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(h->dTmpB.p, pts.data(), sizeof(d2) * pts.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(h->dTmpC.p, tidx.data(), sizeof(int32_t) * tidx.size(), hipMemcpyHostToDevice, st));
-    int32_t *d_len = h->dTmpC.as<int32_t>() + tidx.size();
-    HIP_TRY(h, hipMemcpyAsync(d_len, len, sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
-    LAUNCH_TRY(h, launch_collide_ext(h->dP.as<DevParams>(), h->dTmpA.as<InstDesc>(), n_paths, d_len, h->dTmpB.as<d2>(),
-                                     h->dTmpC.as<int32_t>(), h->dUserStatic.as<double>(), h->dUserDyn.as<double>(),
-                                     h->dTmpD.as<int32_t>(), st));
-    HIP_TRY(h, hipMemcpyAsync(free_out, h->dTmpD.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpB.p, flat.data(), sizeof(double) * flat.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->dTmpC.p, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, st));
+    LAUNCH_TRY(h, launch_check_ext(h->dP.as<DevParams>(), h->dTmpA.as<InstDesc>(), n_paths, mode, h->dTmpC.as<int32_t>(),
+                                   h->dTmpC.as<int32_t>() + np, h->dTmpB.as<double>(), h->dUserStatic.as<double>(),
+                                   h->dUserDyn.as<double>(), h->dTmpD.as<int32_t>(), st));
+    HIP_TRY(h, hipMemcpyAsync(status_out, h->dTmpD.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     return FOT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fot_check_collision_paths(fot_handle *h, int32_t n_paths, const int32_t *len,
+                              const double *x, const double *y, const double *yaw, const double *t,
+                              int32_t n_static, const double *static_xy,
+                              int32_t mode, int32_t S, int32_t Pn, int32_t T, const double *dyn,
+                              int32_t *free_out)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n_paths > 0 && (!x || !y || !t)) return fail(h, FOT_ERR_INVALID, "NULL path array");
+    if (n_paths > 0 && h->P.has_footprint && !yaw)
+        return fail(h, FOT_ERR_INVALID, "yaw is required with a multi-circle footprint");
+    const double *arr[9] = { x, y, yaw, nullptr, nullptr, nullptr, nullptr, nullptr, t };
+    return check_ext(h, 0, n_paths, len, nullptr, arr, nullptr, NAN, n_static, static_xy, mode, S, Pn, T, dyn, free_out);
+}
+
+int fot_check_paths(fot_handle *h, int32_t n_paths, const int32_t *len, const int32_t *flags,
+                    const double *x, const double *y, const double *yaw, const double *v, const double *a,
+                    const double *c, const double *d, const double *s, const double *t,
+                    const fot_overrides *overrides, double max_stop_distance,
+                    int32_t n_static, const double *static_xy,
+                    int32_t mode, int32_t S, int32_t Pn, int32_t T, const double *dyn, int32_t *status_out)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n_paths > 0 && (!x || !y || !v || !a || !c || !t)) return fail(h, FOT_ERR_INVALID, "NULL path array");
+    const double *arr[9] = { x, y, yaw, v, a, c, d, s, t };
+    return check_ext(h, 1, n_paths, len, flags, arr, overrides, max_stop_distance, n_static, static_xy, mode, S, Pn, T,
+                     dyn, status_out);
 }
 
 }  // extern "C"

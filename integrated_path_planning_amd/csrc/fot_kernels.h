@@ -34,9 +34,11 @@ int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave
                    int n_waves, EntryArrays e, const d2 *pts, CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                   const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
+int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+                      const double *lon_tab, int inst, int idx, double *out, int32_t *meta, hipStream_t st);
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
-int launch_collide_ext(const DevParams *P, const InstDesc *desc, int n_paths, const int32_t *len, const d2 *pts,
-                       const int32_t *tidx, const double *static_xy, const double *dyn_xy, int32_t *free_out,
-                       hipStream_t st);
+int launch_check_ext(const DevParams *P, const InstDesc *desc, int n_paths, int mode, const int32_t *len,
+                     const int32_t *flags, const double *arrays, const double *static_xy, const double *dyn_xy,
+                     int32_t *status_out, hipStream_t st);
 
 }  // namespace fot

@@ -478,6 +478,33 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
 }
 
 // ---------------------------------------------------------------------------
+// one candidate's full (untruncated) arrays, for fot_debug_candidate_path
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(WAVE)
+k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+             const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab, int inst, int idx,
+             double *__restrict__ out /* [15][FOT_MAX_NT] */, int32_t *__restrict__ meta /* n_t, valid */)
+{
+    const DevParams &P = *Pp;
+    const InstDesc &D = desc[inst];
+    const InstState &S = state[inst];
+    const int lane = threadIdx.x;
+    if (!S.c2f_ok || idx < 0 || idx >= S.n_cand) { if (lane == 0) { meta[0] = 0; meta[1] = 0; } return; }
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+    const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
+    const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+    double q[6];
+    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+    if (lane < L.n_t) {
+        double o[15];
+        final_sample(P, L, tab, q, lane, o);
+        for (int f = 0; f < 15; ++f) out[f * FOT_MAX_NT + lane] = o[f];
+    }
+    if (lane == 0) { meta[0] = L.n_t; meta[1] = 1; }
+}
+
+// ---------------------------------------------------------------------------
 // spline evaluation (fot_spline_eval)
 // ---------------------------------------------------------------------------
 
@@ -496,36 +523,64 @@ __global__ void k_spline_eval(SplineView sp, int n, const double *__restrict__ s
     out[4 * (int64_t)n + i] = dkappa;
 }
 
-// external-path collision check: one lane per path, points read from a [n_circ][FOT_MAX_NT][n_paths] array,
-// obstacles straight from the caller's layout (exact float64 test, no broad phase)
-struct ExtSource {
-    const d2 *base;
-    const int32_t *tidx;   // [FOT_MAX_NT][n_paths], this path's column
-    int64_t stride_k, stride_c;
-    __device__ __forceinline__ int tindex(int k) const { return tidx[k * stride_k]; }
-    __device__ __forceinline__ void get(int k, int ci, double &x, double &y) const
+// external paths (fot_check_collision_paths / fot_check_paths): one lane per path, arrays [n_paths][FOT_MAX_NT]
+// in the caller's row-major layout, obstacles straight from the caller's layout (exact float64 test)
+struct PathArraySource {
+    const double *x, *y, *yaw, *t;      // this path's rows
+    double dt;
+    const double *circ_off;
+    int has_footprint;
+    __device__ __forceinline__ int tindex(int k) const { return (int)nearbyint(t[k] / dt); }
+    __device__ __forceinline__ void get(int k, int ci, double &px, double &py) const
     {
-        const d2 v = base[ci * stride_c + k * stride_k];
-        x = v.x; y = v.y;
+        if (has_footprint) {                 // frenet_planner.py:1162-1167
+            px = x[k] + circ_off[ci] * cos(yaw[k]);
+            py = y[k] + circ_off[ci] * sin(yaw[k]);
+        } else {
+            px = x[k]; py = y[k];
+        }
     }
 };
 
-__global__ void k_collide_ext(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int n_paths,
-                              const int32_t *__restrict__ len, const d2 *__restrict__ pts,
-                              const int32_t *__restrict__ tidx, const double *__restrict__ static_xy,
-                              const double *__restrict__ dyn_xy, int32_t *__restrict__ free_out)
+// mode 0: collision only (status_out = 1 free / 0 hit); mode 1: _check_paths categories (FOT_ST_*)
+__global__ void k_check_ext(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int n_paths, int mode,
+                            const int32_t *__restrict__ len, const int32_t *__restrict__ flags,
+                            const double *__restrict__ arrays /* [9][n_paths][FOT_MAX_NT]: x y yaw v a c d s t */,
+                            const double *__restrict__ static_xy, const double *__restrict__ dyn_xy,
+                            int32_t *__restrict__ status_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_paths) return;
-    ExtSource src;
-    src.base = pts + i;
-    src.tidx = tidx + i;
-    src.stride_k = n_paths;
-    src.stride_c = (int64_t)FOT_MAX_NT * n_paths;
+    const DevParams &P = *Pp;
+    const InstDesc &D = desc[0];
+    const int64_t plane = (int64_t)n_paths * FOT_MAX_NT;
+    const double *row = arrays + (int64_t)i * FOT_MAX_NT;
+    const double *ax = row, *ay = row + plane, *ayaw = row + 2 * plane, *av = row + 3 * plane, *aa = row + 4 * plane,
+                 *ac = row + 5 * plane, *ad = row + 6 * plane, *as = row + 7 * plane, *at = row + 8 * plane;
+    const int n = len[i];
+    PathArraySource src;
+    src.x = ax; src.y = ay; src.yaw = ayaw; src.t = at; src.dt = P.dt;
+    src.circ_off = P.circ_off; src.has_footprint = P.has_footprint;
     ObstacleView obs;
     obs.stat = static_xy; obs.dyn = dyn_xy; obs.dtype = FOT_F64;
-    const bool hit = len[i] > 0 && collide_candidate(*Pp, desc[0], obs, len[i], src);
-    free_out[i] = hit ? 0 : 1;
+    if (mode == 0) {
+        const bool hit = n > 0 && collide_candidate(P, D, obs, n, src);
+        status_out[i] = hit ? 0 : 1;
+        return;
+    }
+    const bool has_geo = flags[i] & 1, has_d = flags[i] & 2;
+    CheckAcc acc;
+    check_init(acc);
+    for (int k = 0; k < n; ++k) {
+        PathSample ps;
+        ps.x = ax[k]; ps.y = ay[k]; ps.cos_t = cos(ayaw[k]); ps.sin_t = sin(ayaw[k]);
+        ps.kappa = ac[k]; ps.v = av[k]; ps.a = aa[k]; ps.d = ad[k]; ps.s = as[k];
+        check_sample(P, D, acc, k, ps, has_geo, has_d);
+    }
+    int st = check_status(D, acc, n);
+    if (st == ST_PENDING && n > 0 && collide_candidate(P, D, obs, n, src)) st = FOT_ST_COLLISION;
+    if (n > 0) st = final_status(st, av[n - 1], as[n - 1] - as[0], D.max_stop);
+    status_out[i] = st;
 }
 
 // ---------------------------------------------------------------------------
@@ -602,6 +657,14 @@ int launch_select(const DevParams *P, const InstDesc *desc, const InstState *sta
     return 0;
 }
 
+int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+                      const double *lon_tab, int inst, int idx, double *out, int32_t *meta, hipStream_t st)
+{
+    k_debug_path<<<1, WAVE, 0, st>>>(P, desc, state, lon_info, lon_tab, inst, idx, out, meta);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st)
 {
     if (n <= 0) return 0;
@@ -610,12 +673,13 @@ int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipSt
     return 0;
 }
 
-int launch_collide_ext(const DevParams *P, const InstDesc *desc, int n_paths, const int32_t *len, const d2 *pts,
-                       const int32_t *tidx, const double *static_xy, const double *dyn_xy, int32_t *free_out,
-                       hipStream_t st)
+int launch_check_ext(const DevParams *P, const InstDesc *desc, int n_paths, int mode, const int32_t *len,
+                     const int32_t *flags, const double *arrays, const double *static_xy, const double *dyn_xy,
+                     int32_t *status_out, hipStream_t st)
 {
     if (n_paths <= 0) return 0;
-    k_collide_ext<<<(n_paths + 63) / 64, 64, 0, st>>>(P, desc, n_paths, len, pts, tidx, static_xy, dyn_xy, free_out);
+    k_check_ext<<<(n_paths + 63) / 64, 64, 0, st>>>(P, desc, n_paths, mode, len, flags, arrays, static_xy, dyn_xy,
+                                                    status_out);
     FOT_LAUNCH_CHECK();
     return 0;
 }

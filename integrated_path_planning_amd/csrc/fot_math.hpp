@@ -312,6 +312,69 @@ struct CandResult {
     int status, keep;
 };
 
+// Running state of the per-candidate checks of _check_paths (frenet_planner.py:932-984) over the
+// kept prefix of a path.  One sample at a time, so the lattice kernel and the external-path entry
+// (fot_check_paths) share the exact same tests.
+struct PathSample {
+    double x, y, cos_t, sin_t, kappa, v, a, d, s;
+};
+
+struct CheckAcc {
+    bool finite_ok, nan_step, f_speed, f_accel, f_curv, f_lat, f_road;
+    double max_step;
+    PathSample prev;
+};
+
+FOT_HD void check_init(CheckAcc &c)
+{
+    c.finite_ok = true; c.nan_step = false;
+    c.f_speed = c.f_accel = c.f_curv = c.f_lat = c.f_road = false;
+    c.max_step = -INFINITY;
+    c.prev.x = c.prev.y = c.prev.kappa = c.prev.v = c.prev.a = c.prev.d = c.prev.s = 0.0;
+    c.prev.cos_t = 1.0; c.prev.sin_t = 0.0;
+}
+
+// k = index of the sample inside the path; has_geo / has_d: the low-speed rules and the road test
+// only apply when the caller's path carries the arrays they read (:1013-1022, :982)
+FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int k, const PathSample &p,
+                         bool has_geo, bool has_d)
+{
+    if (!(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa))) c.finite_ok = false;        // :944-946
+    if (k > 0) {
+        const double step = hypot(p.x - c.prev.x, p.y - c.prev.y);                            // :953-956
+        if (isnan(step)) c.nan_step = true;
+        if (step > c.max_step) c.max_step = step;
+        if (p.v > D.lim_speed) c.f_speed = true;                                              // :964
+        if (fabs(p.a) > D.lim_accel) c.f_accel = true;                                        // :966
+        if (p.v > 0.5) {                                                                       // LOW_SPEED_CURVATURE_GATE
+            if (fabs(p.kappa) > D.lim_curv) c.f_curv = true;
+        } else if (has_geo) {
+            const double dd = fabs(p.d - c.prev.d);
+            const double d_s = fabs(p.s - c.prev.s);
+            if (dd > fmax(1.5 * d_s, 0.02)) c.f_curv = true;                                  // lateral slip
+            const double sn = p.sin_t * c.prev.cos_t - p.cos_t * c.prev.sin_t;                // sin/cos of the yaw step
+            const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
+            const double dyaw = fabs(atan2(sn, cs));
+            if (dyaw > fmax(D.lim_curv * step, 0.1)) c.f_curv = true;                         // yaw-step cap
+        }
+        if (p.v * p.v * fabs(p.kappa) > D.lim_lat) c.f_lat = true;                            // :975
+        if (has_d && fabs(p.d) > P.max_road_width + 1e-9) c.f_road = true;                    // :982
+    }
+    c.prev = p;
+}
+
+// first failing category in the reference's order; ST_PENDING = collision check outstanding
+FOT_HD int check_status(const InstDesc &D, const CheckAcc &c, int keep)
+{
+    if (keep == 0 || !c.finite_ok || (!c.nan_step && c.max_step > D.step_limit)) return FOT_ST_DROPPED;
+    if (c.f_speed) return FOT_ST_SPEED;
+    if (c.f_accel) return FOT_ST_ACCEL;
+    if (c.f_curv) return FOT_ST_CURVATURE;
+    if (c.f_lat) return FOT_ST_LAT_ACCEL;
+    if (c.f_road) return FOT_ST_ROAD;
+    return ST_PENDING;
+}
+
 // lateral state of sample k: polynomial up to n_eval-1, then held (brake padding)
 FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d, double &dd, double &ddd, double &dddd)
 {
@@ -333,12 +396,11 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
 {
     const int n_t = L.n_t;
     double Jp = 0.0, d_last = 0.0;
-    bool singular = false, seen_nan = false, finite_ok = true, nan_step = false;
-    bool f_speed = false, f_accel = false, f_curv = false, f_lat = false, f_road = false;
+    bool singular = false, seen_nan = false;
     int first_nan = -1;
-    double max_step = -INFINITY;
-    double xp = 0.0, yp = 0.0, dprev = 0.0, sprev = 0.0, cprev = 1.0, snprev = 0.0;
     double v_last = 0.0, s_last = 0.0, s_first = 0.0;
+    CheckAcc acc;
+    check_init(acc);
 
     for (int k = 0; k < n_loop; ++k) {
       if (k < n_t) {
@@ -353,29 +415,11 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
         if (isfinite(c.omkd) && c.omkd <= 0.05) singular = true;        // SINGULARITY_EPS, any sample
         if (!seen_nan && isnan(c.x)) { seen_nan = true; first_nan = k; }
         if (!seen_nan) {
-            if (!(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa))) finite_ok = false;
-            if (k == 0) {
-                s_first = ls.s;
-            } else {
-                const double step = hypot(c.x - xp, c.y - yp);
-                if (isnan(step)) nan_step = true;
-                if (step > max_step) max_step = step;
-                if (c.v > D.lim_speed) f_speed = true;
-                if (fabs(c.a) > D.lim_accel) f_accel = true;
-                if (c.v > 0.5) {                                            // LOW_SPEED_CURVATURE_GATE
-                    if (fabs(c.kappa) > D.lim_curv) f_curv = true;
-                } else {
-                    const double dd = fabs(d - dprev);
-                    const double d_s = fabs(ls.s - sprev);
-                    if (dd > fmax(1.5 * d_s, 0.02)) f_curv = true;
-                    const double sn = c.sin_t * cprev - c.cos_t * snprev;   // sin/cos of the yaw step
-                    const double cs = c.cos_t * cprev + c.sin_t * snprev;
-                    const double dyaw = fabs(atan2(sn, cs));
-                    if (dyaw > fmax(D.lim_curv * step, 0.1)) f_curv = true;
-                }
-                if (c.v * c.v * fabs(c.kappa) > D.lim_lat) f_lat = true;
-                if (fabs(d) > P.max_road_width + 1e-9) f_road = true;
-            }
+            PathSample ps;
+            ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
+            ps.v = c.v; ps.a = c.a; ps.d = d; ps.s = ls.s;
+            check_sample(P, D, acc, k, ps, true, true);
+            if (k == 0) s_first = ls.s;
             if (P.has_footprint) {
                 for (int ci = 0; ci < P.n_circ; ++ci)
                     sink.put(k, ci, c.x + P.circ_off[ci] * c.cos_t, c.y + P.circ_off[ci] * c.sin_t);
@@ -383,7 +427,6 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
                 sink.put(k, 0, c.x, c.y);
             }
             v_last = c.v; s_last = ls.s;
-            xp = c.x; yp = c.y; dprev = d; sprev = ls.s; cprev = c.cos_t; snprev = c.sin_t;
         }
       }
       sink.row_done(k);
@@ -400,13 +443,7 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
     const double lon = P.k_j * L.Js + P.k_t * Jt + P.k_s_dot * (dv * dv);
     out.cost = P.k_lat * lat + P.k_lon * lon;
 
-    int st = ST_PENDING;
-    if (f_road) st = FOT_ST_ROAD;
-    if (f_lat) st = FOT_ST_LAT_ACCEL;
-    if (f_curv) st = FOT_ST_CURVATURE;
-    if (f_accel) st = FOT_ST_ACCEL;
-    if (f_speed) st = FOT_ST_SPEED;
-    if (keep == 0 || !finite_ok || (!nan_step && max_step > D.step_limit)) st = FOT_ST_DROPPED;
+    const int st = check_status(D, acc, keep);
     out.status = st;
     out.keep = keep;
     out.v_last = v_last;

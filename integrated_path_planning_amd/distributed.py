@@ -1,0 +1,107 @@
+"""Instance sharding over GPUs: one process per GPU, contiguous shards, one all-gather.
+
+Each ego/scenario instance is planned independently, so the
+only exchange is an all-gather of the fixed-size ``fot_result`` records of the
+selected paths.  With backend "nccl" that is RCCL over xGMI; the same code runs
+on "gloo" for the CPU tests of the sharding/gather logic.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+
+
+def shard_bounds(n_total: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced shards: the first ``n_total % world`` ranks get one extra instance."""
+    if world < 1 or n_total < 0:
+        raise ValueError("world >= 1 and n_total >= 0 required")
+    base, extra = divmod(n_total, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def max_shard(n_total: int, world: int) -> int:
+    return -(-n_total // world) if n_total else 0
+
+
+def all_gather_records(local, n_total: int, world: int, rank: int, group=None):
+    """All-gather result records.
+
+    ``local``: uint8 torch tensor with this rank's records (``(hi-lo) * RESULT_BYTES`` bytes, device or CPU).
+    Returns a uint8 tensor of ``n_total * RESULT_BYTES`` bytes in global instance order on the same device.
+    Shards are padded to the largest shard so that one equal-count all-gather suffices.
+    """
+    import torch
+    import torch.distributed as dist
+
+    rb = _abi.RESULT_BYTES
+    bounds = shard_bounds(n_total, world)
+    lo, hi = bounds[rank]
+    if local.numel() != (hi - lo) * rb:
+        raise ValueError(f"rank {rank}: expected {(hi - lo) * rb} bytes, got {local.numel()}")
+    if world == 1:
+        return local
+    m = max_shard(n_total, world)
+    if hi - lo == m:
+        send = local
+    else:
+        send = torch.zeros(m * rb, dtype=torch.uint8, device=local.device)
+        send[: (hi - lo) * rb] = local
+    gathered = torch.empty(world * m * rb, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(gathered, send, group=group)
+    if n_total == world * m:
+        return gathered
+    parts = [gathered[r * m * rb: r * m * rb + (b[1] - b[0]) * rb] for r, b in enumerate(bounds)]
+    return torch.cat(parts)
+
+
+def records_from_bytes(buf: np.ndarray, n: int):
+    """uint8 array -> ctypes array of ``fot_result``."""
+    return (_abi.Result * n).from_buffer_copy(np.ascontiguousarray(buf[: n * _abi.RESULT_BYTES]).tobytes())
+
+
+class ShardedPlanner:
+    """Plans this rank's shard on its GPU and all-gathers the selected paths.
+
+    ``torch`` provides device memory, the stream and the collective; the planning itself is libfot.
+    """
+
+    def __init__(self, waypoints, device_index: int, world: int, rank: int, group=None, **planner_kwargs):
+        import torch
+        from .planner import BatchPlanner
+
+        self.torch = torch
+        self.world, self.rank, self.group = world, rank, group
+        self.device = torch.device("cuda", device_index)
+        self.planner = BatchPlanner(waypoints=waypoints, device=device_index, **planner_kwargs)
+        self._keep = None
+
+    def plan(self, requests: Sequence, obstacle_dtype=np.float32):
+        """``requests``: the GLOBAL list of PlanRequest (every rank passes the same list).
+        Returns (records of all instances in global order, uint8 tensor they live in)."""
+        from .batch import PackedBatch
+
+        torch = self.torch
+        n_total = len(requests)
+        lo, hi = shard_bounds(n_total, self.world)[self.rank]
+        pb = PackedBatch(requests[lo:hi], obstacle_dtype)
+        dyn = torch.from_numpy(pb.dyn_xy).to(self.device) if pb.dyn_xy.size else None
+        st = torch.from_numpy(pb.static_xy).to(self.device) if pb.static_xy.size else None
+        out = torch.zeros(max(hi - lo, 1) * _abi.RESULT_BYTES, dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        if hi > lo:
+            self.planner.plan_packed_device(
+                pb.with_device_obstacles(st.data_ptr() if st is not None else None,
+                                         dyn.data_ptr() if dyn is not None else None),
+                out.data_ptr(), stream.cuda_stream)
+        self._keep = (pb, dyn, st)                       # inputs must outlive the enqueued work
+        full = all_gather_records(out[: (hi - lo) * _abi.RESULT_BYTES], n_total, self.world, self.rank, self.group)
+        host = full.cpu().numpy()
+        return records_from_bytes(host, n_total), full

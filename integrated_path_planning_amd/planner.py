@@ -181,6 +181,16 @@ class BatchPlanner:
         n = min(n, cap)
         return cost[:n], status[:n], keep[:n], nt[:n]
 
+    def candidate_path(self, index: int, inst: int = 0) -> FrenetPath:
+        """Candidate ``index`` of the last plan call as generated + converted, before truncation."""
+        arr = np.zeros((15, _abi.MAX_NT))
+        nt = C.c_int32(0)
+        _abi.check(self._h, self._lib.fot_debug_candidate_path(self._h, inst, int(index), _as_dp(arr), C.byref(nt)))
+        fp = FrenetPath()
+        for k, f in enumerate(_abi.PATH_FIELDS):
+            setattr(fp, f, arr[k, : nt.value].tolist())
+        return fp
+
     def frenet_states(self, egos: Sequence[PlanRequest]):
         n = len(egos)
         arr = (_abi.Ego * max(n, 1))()
@@ -197,32 +207,73 @@ class BatchPlanner:
                                                              ok.ctypes.data_as(_ip)))
         return fr[:n], ref[:n], nps[:n], ok[:n]
 
-    def paths_collision_free(self, paths: Sequence, static=None, dyn=None, dist=None) -> np.ndarray:
-        """_path_is_collision_free (frenet_planner.py:1035-1047) for FrenetPath-like objects."""
+    @staticmethod
+    def _pack_paths(paths: Sequence, fields: Sequence[str]):
+        """FrenetPath-like objects -> {field: [n, MAX_NT]} arrays, lengths, presence flags."""
         n = len(paths)
-        X = np.zeros((max(n, 1), _abi.MAX_NT)); Y = np.zeros_like(X); W = np.zeros_like(X); Tm = np.zeros_like(X)
+        arrs = {f: np.zeros((max(n, 1), _abi.MAX_NT)) for f in fields}
         ln = np.zeros(max(n, 1), np.int32)
+        flags = np.zeros(max(n, 1), np.int32)
         for i, fp in enumerate(paths):
             m = min(len(fp.x), len(fp.t))                        # frenet_planner.py:1146
             if m > _abi.MAX_NT:
                 raise ValueError(f"path longer than {_abi.MAX_NT} samples")
             ln[i] = m
-            X[i, :m] = np.asarray(fp.x[:m], float); Y[i, :m] = np.asarray(fp.y[:m], float)
-            Tm[i, :m] = np.asarray(fp.t[:m], float)
-            yaw = np.asarray(fp.yaw[:m], float) if fp.yaw is not None else np.zeros(0)
-            if len(yaw) < m:                                     # :1158-1161 hold the last value
-                yaw = np.concatenate([yaw, np.full(m - len(yaw), yaw[-1] if len(yaw) else 0.0)])
-            W[i, :m] = yaw
+            present = {}
+            for f in fields:
+                v = getattr(fp, f, None)
+                v = np.zeros(0) if v is None else np.asarray(v, dtype=float)
+                present[f] = len(v) >= m and m > 0
+                if f == "yaw" and 0 < len(v) < m:                # :1158-1161 hold the last value
+                    v = np.concatenate([v, np.full(m - len(v), v[-1])])
+                k = min(len(v), m)
+                arrs[f][i, :k] = v[:k]
+            geo = all(present.get(f, False) for f in ("x", "y", "yaw", "s", "d") if f in fields)
+            flags[i] = (1 if geo else 0) | (2 if present.get("d", False) else 0)
+        return arrs, ln, flags
+
+    def _obstacle_args(self, static, dyn, dist):
         req = PlanRequest(0, 0, 0, 0, 0, static=static, dyn=dyn, dist=dist)
         pb = PackedBatch([req], np.float64)
         mode, S, P, T = (int(v) for v in pb.dyn_dims[0])
-        free = np.zeros(max(n, 1), np.int32)
         st = pb.static_xy
+        return pb, (int(st.shape[0]), _as_dp(st) if st.size else None, mode, S, P, T,
+                    _as_dp(pb.dyn_xy) if pb.dyn_xy.size else None)
+
+    def paths_collision_free(self, paths: Sequence, static=None, dyn=None, dist=None) -> np.ndarray:
+        """_path_is_collision_free (frenet_planner.py:1035-1047) for FrenetPath-like objects."""
+        n = len(paths)
+        arrs, ln, _ = self._pack_paths(paths, ("x", "y", "yaw", "t"))
+        keep, oargs = self._obstacle_args(static, dyn, dist)
+        free = np.zeros(max(n, 1), np.int32)
         _abi.check(self._h, self._lib.fot_check_collision_paths(
-            self._h, n, ln.ctypes.data_as(_ip), _as_dp(X), _as_dp(Y), _as_dp(W), _as_dp(Tm),
-            int(st.shape[0]), _as_dp(st) if st.size else None, mode, S, P, T,
-            _as_dp(pb.dyn_xy) if pb.dyn_xy.size else None, free.ctypes.data_as(_ip)))
+            self._h, n, ln.ctypes.data_as(_ip), _as_dp(arrs["x"]), _as_dp(arrs["y"]), _as_dp(arrs["yaw"]),
+            _as_dp(arrs["t"]), *oargs, free.ctypes.data_as(_ip)))
         return free[:n].astype(bool)
+
+    def check_paths(self, paths: Sequence, static=None, dyn=None, overrides=None, dist=None,
+                    max_stop_distance=None) -> np.ndarray:
+        """_check_paths (+ stop-distance filter) categories of FrenetPath-like objects: FOT_ST_* per path."""
+        n = len(paths)
+        fields = ("x", "y", "yaw", "v", "a", "c", "d", "s", "t")
+        arrs, ln, flags = self._pack_paths(paths, fields)
+        for i, fp in enumerate(paths):                           # :933-940 silently skipped
+            if len(fp.x) == 0 or len(fp.x) != len(fp.t):
+                ln[i] = 0
+        keep, oargs = self._obstacle_args(static, dyn, dist)
+        ov = _abi.Overrides()
+        o = overrides or {}
+        nan = float("nan")
+        ov.max_speed, ov.max_accel = float(o.get("max_speed", nan)), float(o.get("max_accel", nan))
+        ov.max_curvature, ov.max_lat_accel = float(o.get("max_curvature", nan)), float(o.get("max_lat_accel", nan))
+        status = np.zeros(max(n, 1), np.int32)
+        _abi.check(self._h, self._lib.fot_check_paths(
+            self._h, n, ln.ctypes.data_as(_ip), flags.ctypes.data_as(_ip), *[_as_dp(arrs[f]) for f in fields],
+            C.byref(ov), nan if max_stop_distance is None else float(max_stop_distance), *oargs,
+            status.ctypes.data_as(_ip)))
+        status = status[:n]
+        status[ln[:n] == 0] = _abi.ST_DROPPED
+        return status
 
 
 class _NearestPointState:
@@ -329,12 +380,35 @@ class FrenetPlanner:
     def _check_collision(self, fp, static_obstacles, dynamic_obstacles=None) -> bool:
         return self._path_is_collision_free(fp, static_obstacles, dynamic_obstacles, None)
 
+    def _engine_for_epsilon(self, epsilon: float) -> BatchPlanner:
+        """chance_epsilon is a handle constant; other values get their own (cached) handle."""
+        if float(epsilon) == self.chance_epsilon:
+            return self._engine
+        cache = self.__dict__.setdefault("_eps_engines", {})
+        if float(epsilon) not in cache:
+            p = self._engine.params
+            kw = {name: getattr(p, name) for name, _ in p._fields_
+                  if name not in ("_pad", "n_circles", "footprint_radius", "footprint_offsets", "chance_epsilon")}
+            cache[float(epsilon)] = BatchPlanner(reference_path=self.csp, chance_epsilon=float(epsilon),
+                                                 footprint=self.footprint, **kw)
+        return cache[float(epsilon)]
+
     def _check_collision_distribution(self, fp, static_obstacles, dynamic_distribution, epsilon=None) -> bool:
-        if epsilon is not None and float(epsilon) != self.chance_epsilon:
-            raise ValueError("epsilon is fixed at construction (chance_epsilon)")
+        eng = self._engine_for_epsilon(self.chance_epsilon if epsilon is None else epsilon)
         if dynamic_distribution is None or np.size(dynamic_distribution) == 0:
-            return self._path_is_collision_free(fp, static_obstacles, None, None)
-        return self._path_is_collision_free(fp, static_obstacles, None, dynamic_distribution)
+            return bool(eng.paths_collision_free([fp], static_obstacles, None, None)[0])
+        return bool(eng.paths_collision_free([fp], static_obstacles, None, dynamic_distribution)[0])
+
+    def _check_paths(self, fp_list, static_obstacles, dynamic_obstacles=None, constraint_overrides=None,
+                     dynamic_obstacles_distribution=None) -> dict:
+        """Same categorisation as the reference's _check_paths (frenet_planner.py:891-993), on the device."""
+        status = self._engine.check_paths(fp_list, static_obstacles, dynamic_obstacles, constraint_overrides,
+                                          dynamic_obstacles_distribution)
+        out = {k: [] for k in _abi.STATUS_NAMES[:7]}
+        for fp, st in zip(fp_list, status):
+            if st < 7:
+                out[_abi.STATUS_NAMES[st]].append(fp)
+        return out
 
     def candidate_table(self):
         """(cost, status, keep, n_t) per candidate of the last plan() call (diagnostic)."""

@@ -1,0 +1,113 @@
+"""No-GPU checks of the drop-in boundary: libfot.so loads, exports every symbol include/fot.h declares,
+the ctypes mirror has the C layout, and the host-side packing / failure behaviour is right."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, Golden
+from integrated_path_planning_amd import _abi, synthetic as syn
+from integrated_path_planning_amd.batch import PackedBatch, PlanRequest
+from integrated_path_planning_amd.params import make_params
+
+HEADER = os.path.join(ROOT, "include", "fot.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fot_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 18
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/fot.h but not exported by libfot.so"
+    assert sorted(_abi.SYMBOLS) == decl, "integrated_path_planning_amd/_abi.py SYMBOLS out of sync with include/fot.h"
+    assert b"gfx950" in lib.fot_version()
+
+
+def test_ctypes_layout_matches_c(tmp_path):
+    """sizeof/offsetof from a C translation unit that includes include/fot.h."""
+    src = tmp_path / "layout.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "fot.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(fot_params), sizeof(fot_ego), sizeof(fot_overrides), sizeof(fot_result), sizeof(fot_batch));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(fot_result, cost), offsetof(fot_result, stats), offsetof(fot_result, frenet0),
+         offsetof(fot_result, t), offsetof(fot_result, c));
+  printf("%zu %zu %zu\n", offsetof(fot_batch, static_xy), offsetof(fot_batch, dyn_dims), offsetof(fot_params, footprint_offsets));
+  return 0; }''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(v) for v in out]
+    R, B, P = _abi.Result, _abi.Batch, _abi.Params
+    want = [C.sizeof(P), C.sizeof(_abi.Ego), C.sizeof(_abi.Overrides), C.sizeof(R), C.sizeof(B),
+            R.cost.offset, R.stats.offset, R.frenet0.offset, R.t.offset, R.c.offset,
+            B.static_xy.offset, B.dyn_dims.offset, P.footprint_offsets.offset]
+    assert got == want
+
+
+def test_create_fails_loudly_without_gpu_or_succeeds_with_one():
+    lib = _abi.lib()
+    p = make_params(dt=0.1)
+    h = C.c_void_p()
+    rc = lib.fot_create(C.byref(p), -1, C.byref(h))
+    if rc == _abi.OK:
+        lib.fot_destroy(h)
+    else:
+        assert rc == _abi.ERR_HIP and not h.value
+        assert b"HIP" in lib.fot_last_error(None) or b"device" in lib.fot_last_error(None)
+
+
+def test_create_rejects_unsupported_configurations():
+    lib = _abi.lib()
+    h = C.c_void_p()
+    for kw, code in ((dict(dt=0.05), _abi.ERR_UNSUPPORTED),          # 101 samples > FOT_MAX_NT
+                     (dict(dt=-1.0), _abi.ERR_INVALID),
+                     (dict(dt=0.1, min_t=1.0, max_t=5.0), _abi.ERR_UNSUPPORTED)):   # 41 horizons > FOT_MAX_TI
+        p = make_params(**kw)
+        assert lib.fot_create(C.byref(p), -1, C.byref(h)) == code, kw
+        assert lib.fot_last_error(None)
+
+
+def test_packed_batch_layout():
+    inst = [syn.config3_instance(0, S=3, P=4, T=5), syn.config2_instance(1, n_static=2), syn.config3_instance(2, S=2, P=1, T=7)]
+    reqs = [PlanRequest(*inst[0].ego, dist=inst[0].dist), PlanRequest(*inst[1].ego, static=inst[1].static),
+            PlanRequest(*inst[2].ego, dyn=inst[2].dist[0], overrides={"max_accel": 3.0}, max_stop_distance=4.0,
+                        prev_s=1.5, last_kappa=0.25)]
+    pb = PackedBatch(reqs, np.float32)
+    assert pb.c.n_inst == 3 and pb.c.obstacle_dtype == _abi.F32
+    assert pb.dyn_dims.tolist() == [[_abi.DYN_DISTRIBUTION, 3, 4, 5], [0, 0, 0, 0], [_abi.DYN_SINGLE, 1, 1, 7]]
+    assert pb.dyn_off.tolist() == [0, 60, 60] and pb.dyn_xy.shape == (67, 2) and pb.dyn_xy.dtype == np.float32
+    assert pb.static_off.tolist() == [0, 0, 2, 2] and pb.static_xy.shape == (2, 2)
+    np.testing.assert_array_equal(pb.dyn_xy[:60].reshape(3, 4, 5, 2), inst[0].dist)
+    assert np.isnan(pb.overrides[0].max_accel) and pb.overrides[2].max_accel == 3.0
+    assert np.isnan(pb.max_stop[0]) and pb.max_stop[2] == 4.0
+    assert pb.ego[2].has_prev_s == 1 and pb.ego[2].prev_s == 1.5 and pb.ego[2].last_kappa == 0.25
+    assert pb.ego[0].has_prev_s == 0
+    # the distribution wins over the single sample, bad shapes mean "no obstacles" (frenet_planner.py:1043-1047, 1205-1208)
+    both = PackedBatch([PlanRequest(0, 0, 0, 1, 0, dyn=inst[0].dist[0], dist=inst[0].dist)])
+    assert both.dyn_dims[0, 0] == _abi.DYN_DISTRIBUTION
+    none = PackedBatch([PlanRequest(0, 0, 0, 1, 0, dyn=np.empty((0, 0, 2)), static=np.empty((0, 2)))])
+    assert none.dyn_dims[0, 0] == _abi.DYN_NONE and not none.c.static_xy and not none.c.dyn_xy
+
+
+def test_lattice_size_matches_reference_counts():
+    """synthetic.lattice_size against the candidate counts the reference generated (golden cand tables)."""
+    for name in golden_names():
+        g = Golden(name)
+        kw = g.meta["planner"]
+        moving = g["frenet0"][1] > 0.1
+        n = syn.lattice_size(g.meta["target_speed"], dt=kw.get("dt", 0.2), min_t=kw.get("min_t", 4.0),
+                             max_t=kw.get("max_t", 5.0), d_t_s=kw.get("d_t_s", 5.0 / 3.6),
+                             d_road_w=kw.get("d_road_w", 0.5), max_road_width=kw.get("max_road_width", 7.0), moving=moving)
+        assert n == len(g["cand_cost"]), name

@@ -1,0 +1,81 @@
+"""Sharding + all-gather of selected-path records with world_size 2 on CPU (gloo).
+
+The planner itself needs a GPU; what is covered here is the N>1 logic the 8-GPU
+run depends on: contiguous shards, padding of uneven shards, global ordering
+after the all-gather.  Each rank fabricates recognisable records for its shard.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.distributed import all_gather_records, max_shard, records_from_bytes, shard_bounds
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 255, 256, 4096, 4097):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert len(b) == w and b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == max_shard(n, w)
+    assert shard_bounds(4096, 8)[3] == (1536, 2048)          # BASELINE config 5: 512 per GPU
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(n_total, world)[rank]
+        recs = (_abi.Result * max(hi - lo, 1))()
+        for i in range(hi - lo):
+            g = lo + i
+            recs[i].status = g % 3
+            recs[i].best_index = g
+            recs[i].cost = 0.5 * g
+            recs[i].n_keep = 2
+            recs[i].x[0] = float(g)
+            recs[i].x[1] = float(rank)
+        local = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)[: (hi - lo) * _abi.RESULT_BYTES].clone()
+        full = all_gather_records(local, n_total, world, rank)
+        out = records_from_bytes(full.numpy(), n_total)
+        bounds = shard_bounds(n_total, world)
+        ok = True
+        for g in range(n_total):
+            owner = [r for r, (a, b) in enumerate(bounds) if a <= g < b][0]
+            r = out[g]
+            ok &= (r.best_index == g and r.status == g % 3 and r.cost == 0.5 * g and r.x[0] == float(g)
+                   and r.x[1] == float(owner))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7, 1])
+def test_all_gather_world2(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(world))

@@ -1,0 +1,506 @@
+"""The reference's own planner tests, restated against the MI355X FrenetPlanner shim.
+
+Same scenarios and numbers as the reference's tests (file:line cited per test), own
+code.  Stages that the reference exposes as Python methods and that are fused into
+kernels here are observed through the candidate table / candidate paths of plan().
+"""
+import numpy as np
+import pytest
+
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.cubic_spline import CubicSpline2D
+from integrated_path_planning_amd.data_structures import EgoVehicleState, FrenetPath
+from integrated_path_planning_amd.footprint import EgoFootprint
+from integrated_path_planning_amd.planner import FrenetPlanner
+
+pytestmark = pytest.mark.gpu
+
+NO_OBS = np.empty((0, 2))
+
+
+def straight_spline(length=100.0, n=2):
+    xs = np.linspace(0.0, length, n)
+    return CubicSpline2D(xs.tolist(), [0.0] * n)
+
+
+@pytest.fixture(scope="module")
+def planner():
+    # tests/test_frenet_planner.py:57-68 (straight 100 m reference)
+    return FrenetPlanner(reference_path=straight_spline(), max_speed=10.0, max_accel=2.0, max_curvature=1.0,
+                         dt=0.1, d_road_w=1.0, max_road_width=7.0)
+
+
+def make_straight_planner(length=120.0, **kwargs):
+    # tests/test_frenet_conventions.py:24-42
+    n = int(length / 10) + 1
+    csp = CubicSpline2D([10.0 * i for i in range(n)], [0.0] * n)
+    defaults = dict(max_speed=10.0, max_accel=2.0, max_curvature=1.0, dt=0.1, d_road_w=1.0, max_road_width=7.0,
+                    robot_radius=1.0, obstacle_radius=0.3)
+    defaults.update(kwargs)
+    return FrenetPlanner(reference_path=csp, **defaults)
+
+
+def make_brake_planner(**kwargs):
+    # tests/test_smooth_braking.py:22-30
+    xs = np.linspace(0, 80, 30)
+    defaults = dict(max_speed=10.0, max_accel=2.0, max_curvature=0.2, dt=0.1, d_road_w=0.5, max_road_width=3.0,
+                    robot_radius=1.0, obstacle_radius=0.2, min_t=4.0, max_t=5.0, d_t_s=1.39, n_s_sample=1)
+    defaults.update(kwargs)
+    return FrenetPlanner(CubicSpline2D(xs.tolist(), [0.0] * 30), **defaults)
+
+
+# ---------------------------------------------------------------- tests/test_frenet_planner.py
+
+def test_initialization(planner):                                            # :70-74
+    assert planner.max_speed == 10.0 and planner.dt == 0.1 and planner.d_road_w == 1.0
+
+
+def test_cartesian_to_frenet(planner):                                       # :76-98
+    fs = planner._cartesian_to_frenet_state(EgoVehicleState(x=10.0, y=2.0, yaw=0.0, v=5.0, a=0.0))
+    assert fs is not None
+    assert np.isclose(fs.s, 10.0, atol=0.05) and np.isclose(fs.d, 2.0, atol=0.05)
+    fs = planner._cartesian_to_frenet_state(EgoVehicleState(x=10.053, y=2.0, yaw=0.0, v=5.0, a=0.0))
+    assert np.isclose(fs.s, 10.053, atol=0.01) and np.isclose(fs.d, 2.0, atol=0.01)
+
+
+def test_collision_check_static(planner):                                    # :116-133
+    fp = FrenetPath()
+    fp.x = list(np.linspace(10.0, 20.0, 21)); fp.y = [0.0] * 21; fp.t = [0.0] * 21
+    assert planner._check_collision(fp, np.array([[15.0, 0.0]])) is False
+    assert planner._check_collision(fp, np.array([[15.0, 5.0]])) is True
+
+
+def test_collision_check_dynamic(planner):                                   # :135-153
+    fp = FrenetPath()
+    fp.t = [0.0, 1.0]; fp.x = [10.0, 11.0]; fp.y = [0.0, 0.0]
+    dyn = np.zeros((1, 10, 2))
+    dyn[0, 0, :] = [10.0, 0.0]; dyn[0, 1, :] = [100.0, 100.0]
+    assert planner._check_collision(fp, None, dyn) is False
+    dyn[0, 0, :] = [10.0, 5.0]
+    assert planner._check_collision(fp, None, dyn) is True
+
+
+def _make_fp(v, a):
+    fp = FrenetPath()
+    n = len(v)
+    fp.x = [float(i) for i in range(n)]; fp.y = [0.0] * n; fp.t = [0.1 * i for i in range(n)]
+    fp.v = v; fp.a = a; fp.c = [0.0] * n
+    return fp
+
+
+def test_speed_and_accel_checks_skip_index_zero(planner):                    # :155-183
+    overrides = {"max_speed": 5.0, "max_accel": 2.0}
+    fp = _make_fp(v=[6.0, 4.0, 4.0], a=[-4.0, 1.0, 0.0])
+    assert planner._check_paths([fp], NO_OBS, None, overrides)["ok"] == [fp]
+    fp_speed = _make_fp(v=[4.0, 6.0, 4.0], a=[0.0, 1.0, 0.0])
+    assert planner._check_paths([fp_speed], NO_OBS, None, overrides)["max_speed_error"] == [fp_speed]
+    fp_accel = _make_fp(v=[4.0, 4.0, 4.0], a=[0.0, -4.0, 0.0])
+    assert planner._check_paths([fp_accel], NO_OBS, None, overrides)["max_accel_error"] == [fp_accel]
+
+
+def _make_kinematic_fp(c, v, yaw=None, x=None, d=None, s=None, dt=0.1):      # :185-203
+    fp = FrenetPath()
+    n = len(c)
+    if x is None:
+        x = [0.0]
+        for i in range(1, n):
+            x.append(x[-1] + v[i] * dt)
+    fp.x = x; fp.y = [0.0] * n
+    fp.yaw = yaw if yaw is not None else [0.0] * n
+    fp.t = [dt * i for i in range(n)]
+    fp.v = v; fp.a = [0.0] * n; fp.c = c
+    fp.d = d if d is not None else [0.0] * n
+    fp.s = s if s is not None else list(x)
+    return fp
+
+
+def test_curvature_check_skips_index_zero_and_low_speed(planner):            # :205-259
+    fp = _make_kinematic_fp(c=[1.5, 0.5, 0.5], v=[2.0, 2.0, 2.0])
+    assert planner._check_paths([fp], NO_OBS, None, None)["ok"] == [fp]
+    fp_curv = _make_kinematic_fp(c=[0.5, 1.5, 0.5], v=[2.0, 2.0, 2.0])
+    assert planner._check_paths([fp_curv], NO_OBS, None, None)["max_curvature_error"] == [fp_curv]
+    fp_restart = _make_kinematic_fp(c=[0.1, 2.0, 1.4, 0.3, 0.1], v=[0.0, 0.05, 0.4, 1.2, 3.0],
+                                    yaw=[0.0, 0.002, 0.004, 0.006, 0.008])
+    assert planner._check_paths([fp_restart], NO_OBS, None, None)["ok"] == [fp_restart]
+    fp_pivot = _make_kinematic_fp(c=[0.1, 2.0, 1.4, 0.3, 0.1], v=[0.0, 0.05, 0.4, 1.2, 3.0],
+                                  yaw=[0.0, 0.3, 0.31, 0.32, 0.33])
+    assert planner._check_paths([fp_pivot], NO_OBS, None, None)["max_curvature_error"] == [fp_pivot]
+    fp_slide = _make_kinematic_fp(c=[0.1, 2.0, 1.4, 0.3, 0.1], v=[0.0, 0.05, 0.4, 1.2, 3.0],
+                                  d=[0.0, 0.3, 0.6, 0.7, 0.7], s=[0.0, 0.001, 0.04, 0.16, 0.46])
+    assert planner._check_paths([fp_slide], NO_OBS, None, None)["max_curvature_error"] == [fp_slide]
+    fp_fast = _make_kinematic_fp(c=[0.1, 2.0, 1.4, 0.3, 0.1], v=[3.0] * 5)
+    assert planner._check_paths([fp_fast], NO_OBS, None, None)["max_curvature_error"] == [fp_fast]
+
+
+def test_lateral_accel_check(planner):                                       # :261-280
+    fp = _make_kinematic_fp(c=[0.0, 0.05, 0.05], v=[8.0, 8.0, 8.0])
+    assert planner._check_paths([fp], NO_OBS, None, None)["max_lat_accel_error"] == [fp]
+    fp0 = _make_kinematic_fp(c=[0.05, 0.01, 0.01], v=[8.0, 8.0, 8.0])
+    assert planner._check_paths([fp0], NO_OBS, None, None)["ok"] == [fp0]
+    fp2 = _make_kinematic_fp(c=[0.0, 0.05, 0.05], v=[8.0, 8.0, 8.0])
+    assert planner._check_paths([fp2], NO_OBS, None, {"max_lat_accel": 6.0})["ok"] == [fp2]
+
+
+def test_road_corridor_check_whole_path(planner):                            # :282-297
+    fp = _make_kinematic_fp(c=[0.0] * 3, v=[4.0] * 3, d=[0.0, 7.5, 6.9])
+    assert planner._check_paths([fp], NO_OBS, None, None)["road_bound_error"] == [fp]
+    fp0 = _make_kinematic_fp(c=[0.0] * 3, v=[4.0] * 3, d=[7.5, 6.9, 6.0])
+    assert planner._check_paths([fp0], NO_OBS, None, None)["ok"] == [fp0]
+
+
+def _all_candidates(pl):
+    cost, status, keep, nt = pl.candidate_table()
+    return [pl.engine.candidate_path(i) for i in range(len(cost))]
+
+
+def test_speed_grid_spans_down_to_stop(planner):                             # :299-307
+    planner.plan(EgoVehicleState(x=5.0, y=0.0, yaw=0.0, v=6.0, a=0.0), NO_OBS, target_speed=6.0)
+    cost, status, keep, nt = planner.candidate_table()
+    n_grid = len(cost) - 7
+    terminal_v = {round(planner.engine.candidate_path(i).s_d[-1], 4) for i in range(0, n_grid, 15)}
+    assert 0.0 in terminal_v and max(terminal_v) <= 6.0 + 1e-9
+
+
+def test_lateral_candidates_bounded_by_max_road_width():                     # :309-328
+    narrow = FrenetPlanner(reference_path=straight_spline(), max_speed=10.0, max_accel=2.0, max_curvature=1.0,
+                           dt=0.1, d_road_w=0.3, max_road_width=1.2)
+    narrow.plan(EgoVehicleState(x=5.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    cost, *_ = narrow.candidate_table()
+    n_grid = len(cost) - 7
+    terminal_d = {round(narrow.engine.candidate_path(i).d[-1], 6) for i in range(0, 9 * 5)}
+    assert n_grid > 0
+    assert terminal_d == {round(0.3 * i, 6) for i in range(-4, 5)}
+
+
+def test_collision_check_dynamic_same_time_only(planner):                    # :330-359
+    fp = FrenetPath()
+    fp.x = [10.0, 13.0, 16.0]; fp.y = [0.0] * 3; fp.t = [0.0, 0.1, 0.2]
+    far = [100.0, 100.0]
+    assert planner._check_collision(fp, None, np.array([[[16.0, 0.0], far, far]])) is True
+    assert planner._check_collision(fp, None, np.array([[far, far, [16.0, 0.0]]])) is False
+    assert planner._check_collision(fp, None, np.array([[far, [13.0, 0.0], far]])) is False
+
+
+def test_collision_check_distribution_chance_constrained(planner):           # :361-378
+    fp = FrenetPath()
+    fp.x = [10.0, 11.0]; fp.y = [0.0, 0.0]; fp.t = [0.0, 0.1]
+    far = [[100.0, 100.0], [100.0, 100.0]]
+    hit = [[10.0, 0.0], [100.0, 100.0]]
+    dist = np.array([hit, far, far, far])[:, None, :, :]
+    assert planner._check_collision_distribution(fp, None, dist, 0.0) is False
+    assert planner._check_collision_distribution(fp, None, dist, 0.25) is True
+    assert planner._check_collision_distribution(fp, None, dist, 0.2) is False
+
+
+def test_collision_check_distribution_static_is_hard(planner):               # :380-395
+    fp = FrenetPath()
+    fp.x = [10.0, 11.0]; fp.y = [0.0, 0.0]; fp.t = [0.0, 0.1]
+    far = [[100.0, 100.0], [100.0, 100.0]]
+    dist = np.array([far, far])[:, None, :, :]
+    assert planner._check_collision_distribution(fp, np.array([[10.0, 0.0]]), dist, 1.0) is False
+    assert planner._check_collision_distribution(fp, None, dist, 0.0) is True
+
+
+@pytest.fixture(scope="module")
+def inflated_planner_pair():                                                 # :397-414
+    kwargs = dict(max_speed=10.0, max_accel=2.0, max_curvature=1.0, dt=0.1, d_road_w=1.0, max_road_width=7.0,
+                  robot_radius=1.0, obstacle_radius=0.3)
+    sp = straight_spline()
+    return FrenetPlanner(sp, **kwargs), FrenetPlanner(sp, **kwargs, collision_margin_inflation=1.2)
+
+
+def _straight_fp():
+    fp = FrenetPath()
+    fp.x = [10.0, 11.0]; fp.y = [0.0, 0.0]; fp.t = [0.0, 0.1]
+    return fp
+
+
+def test_margin_inflation_rejects_borderline_dynamic(inflated_planner_pair):  # :422-432
+    nominal, inflated = inflated_planner_pair
+    dyn = np.full((1, 2, 2), 100.0)
+    dyn[0, 0, :] = [10.0, 1.4]
+    assert nominal._check_collision(_straight_fp(), None, dyn) is True
+    assert inflated._check_collision(_straight_fp(), None, dyn) is False
+
+
+def test_margin_inflation_not_applied_to_distribution(inflated_planner_pair):  # :434-444
+    _, inflated = inflated_planner_pair
+    near_miss = [[10.0, 1.4], [100.0, 100.0]]
+    dist = np.array([near_miss, near_miss])[:, None, :, :]
+    assert inflated._check_collision_distribution(_straight_fp(), None, dist, 0.0) is True
+    assert inflated._check_collision(_straight_fp(), None, np.array(near_miss)[None, :, :]) is False
+
+
+def test_margin_inflation_static_unaffected(inflated_planner_pair):          # :446-455
+    nominal, inflated = inflated_planner_pair
+    static_obs = np.array([[10.0, 1.4]])
+    assert nominal._check_collision(_straight_fp(), static_obs) is True
+    assert inflated._check_collision(_straight_fp(), static_obs) is True
+    assert inflated._check_collision(_straight_fp(), np.array([[10.0, 0.5]])) is False
+
+
+def test_plan_end_to_end(planner):                                           # :472-487
+    path = planner.plan(EgoVehicleState(x=0.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    assert path is not None and len(path.x) > 0
+    assert np.isclose(path.v[-1], 5.0, atol=1.0)
+
+
+# ---------------------------------------------------------------- tests/test_frenet_conventions.py
+
+def _wrap(a):
+    return (np.asarray(a) + np.pi) % (2 * np.pi) - np.pi
+
+
+def test_initial_lateral_velocity_is_temporal():                             # :50-59
+    pl = make_straight_planner()
+    yaw = np.deg2rad(15.0)
+    fs = pl._cartesian_to_frenet_state(EgoVehicleState(x=20.0, y=0.0, yaw=yaw, v=5.0, a=0.0))
+    assert np.isclose(fs.d_d, 5.0 * np.sin(yaw), atol=1e-3)
+    assert abs(fs.d_d - np.tan(yaw)) > 0.5
+
+
+def test_yaw_matches_polyline_tangent_and_speed_continuity():                # :61-83
+    pl = make_straight_planner()
+    path = pl.plan(EgoVehicleState(x=20.0, y=0.0, yaw=np.deg2rad(15.0), v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    assert path is not None
+    x, y, yaw = np.asarray(path.x), np.asarray(path.y), np.asarray(path.yaw)
+    err = np.abs(_wrap(yaw[:-1] - np.arctan2(np.diff(y), np.diff(x))))
+    assert np.max(err) < np.deg2rad(5.0)
+    assert np.isclose(path.v[0], 5.0, atol=1e-6)
+
+
+def test_plan_from_standstill_is_finite():                                   # :85-98
+    pl = make_straight_planner()
+    path = pl.plan(EgoVehicleState(x=20.0, y=0.0, yaw=np.deg2rad(10.0), v=0.0, a=0.0), NO_OBS, target_speed=5.0)
+    assert path is not None
+    for arr in (path.x, path.y, path.yaw, path.v, path.a, path.c):
+        assert np.all(np.isfinite(arr))
+
+
+def test_grid_contains_zero_and_is_symmetric():                              # :102-111
+    pl = make_straight_planner(d_road_w=0.3, max_road_width=7.0)
+    path = pl.plan(EgoVehicleState(x=20.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    assert path is not None and np.isclose(path.d[-1], 0.0, atol=1e-9)
+
+
+def test_time_grid_includes_endpoint_and_max_t():                            # :128-141
+    pl = make_straight_planner(min_t=4.0, max_t=5.0)
+    pl.plan(EgoVehicleState(x=20.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    cost, status, keep, nt = pl.candidate_table()
+    first = pl.engine.candidate_path(0)
+    assert len(first.t) == 41 and np.isclose(first.t[-1], 4.0)
+    assert nt.max() == 51
+    last_grid = pl.engine.candidate_path(len(cost) - 8)
+    assert np.isclose(last_grid.t[-1], pl.max_t)
+
+
+def test_collision_checked_at_horizon_endpoint():                            # :143-166
+    pl = make_straight_planner(min_t=5.0, max_t=5.0)
+    fp = FrenetPath()
+    t = np.arange(51) * 0.1
+    fp.t = t.tolist(); fp.x = (20.0 + 5.0 * t).tolist(); fp.y = [0.0] * 51
+    dyn = np.full((1, 51, 2), 1000.0)
+    dyn[0, 50] = [fp.x[-1], 0.0]
+    assert pl._check_collision(fp, None, dyn) is False
+    dyn2 = np.full((1, 51, 2), 1000.0)
+    dyn2[0, 10] = [fp.x[-1], 0.0]
+    assert pl._check_collision(fp, None, dyn2) is True
+
+
+def test_truncated_path_arrays_stay_in_lockstep():                           # :169-182
+    pl = make_straight_planner(length=60.0)
+    path = pl.plan(EgoVehicleState(x=45.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    assert path is not None
+    n = len(path.x)
+    assert n < 41
+    for f in _abi.PATH_FIELDS:
+        assert len(getattr(path, f)) == n
+
+
+def test_paths_shorter_than_two_points_are_invalidated():                    # :184-190
+    pl = make_straight_planner(length=60.0)
+    pl.plan(EgoVehicleState(x=59.9, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    _, _, keep, _ = pl.candidate_table()
+    assert not np.any(keep == 1)
+
+
+def test_ego_curvature_cache():                                              # :193-207
+    pl = make_straight_planner()
+    assert pl._last_kappa == 0.0
+    ego = EgoVehicleState(x=20.0, y=0.0, yaw=0.0, v=5.0, a=0.0)
+    path = pl.plan(ego, NO_OBS, target_speed=5.0)
+    assert path is not None and pl._last_kappa == float(path.c[1])
+    after = pl._last_kappa
+    wall_y = np.linspace(-8.0, 8.0, 33)
+    wall = np.stack([np.full_like(wall_y, 24.0), wall_y], axis=1)
+    assert pl.plan(ego, wall, target_speed=5.0) is None
+    assert pl._last_kappa == after
+    pl.reset_ego_curvature()
+    assert pl._last_kappa == 0.0
+
+
+# ---------------------------------------------------------------- tests/test_planner_guards.py
+
+def make_arc_planner(radius=5.0, span=1.5 * np.pi, **kwargs):                # :71-83
+    theta = np.linspace(0.0, span, 60)
+    spline = CubicSpline2D((radius * np.sin(theta)).tolist(), (radius * (1.0 - np.cos(theta))).tolist())
+    defaults = dict(max_speed=13.9, max_accel=8.0, max_curvature=10.0, dt=0.1, d_road_w=0.5, max_road_width=7.0,
+                    robot_radius=1.0, min_t=4.0, max_t=5.0, d_t_s=1.39, n_s_sample=1)
+    defaults.update(kwargs)
+    return FrenetPlanner(spline, **defaults)
+
+
+def test_candidates_beyond_curvature_center_are_invalidated():               # :86-115
+    pl = make_arc_planner(radius=5.0)
+    th = 0.4
+    pl.plan(EgoVehicleState(x=5.0 * np.sin(th), y=5.0 * (1 - np.cos(th)), yaw=th, v=3.0, a=0.0), NO_OBS,
+            target_speed=3.0)
+    cost, status, keep, nt = pl.candidate_table()
+    s_max = pl.csp.s[-1]
+    n_singular = 0
+    for i in range(0, len(cost), 7):
+        fp = pl.engine.candidate_path(i)
+        d_arr, s_arr = np.asarray(fp.d), np.asarray(fp.s)
+        in_domain = s_arr <= s_max
+        if np.any((d_arr[in_domain] / 5.0) >= 1.0 - 0.05):
+            n_singular += 1
+            assert keep[i] == 0, f"singular candidate {i} survived with {keep[i]} points"
+    assert n_singular > 0
+
+
+def test_out_of_domain_paths_are_truncated_not_dropped():                    # :117-135
+    xs = np.linspace(0, 60, 25)
+    pl = FrenetPlanner(CubicSpline2D(xs.tolist(), [0.0] * 25), max_speed=10.0, max_accel=8.0, max_curvature=10.0,
+                       dt=0.1, d_road_w=0.5, max_road_width=7.0, robot_radius=1.0, min_t=4.0, max_t=5.0, d_t_s=1.39)
+    path = pl.plan(EgoVehicleState(x=45.0, y=0.0, yaw=0.0, v=6.0, a=0.0), NO_OBS, np.empty((0, 0, 2)),
+                   target_speed=6.0)
+    assert path is not None and len(path.x) >= 2
+
+
+def test_teleporting_and_nonfinite_paths_rejected():                         # :148-171
+    pl = make_arc_planner()
+
+    def mk(xs, ys):
+        n = len(xs)
+        return FrenetPath(t=[0.1 * i for i in range(n)], x=list(xs), y=list(ys), yaw=[0.0] * n, v=[1.0] * n,
+                          a=[0.0] * n, c=[0.0] * n)
+
+    good = mk([0.0, 0.1, 0.2], [0.0] * 3)
+    teleport = mk([0.0, 0.1, 5000.0], [0.0] * 3)
+    result = pl._check_paths([good, teleport], NO_OBS)
+    cats = [fp for fps in result.values() for fp in fps]
+    assert any(fp is good for fp in cats) and not any(fp is teleport for fp in cats)
+    bad = mk([0.0, 0.1, 0.2], [0.0] * 3)
+    bad.v = [1.0, float("nan"), 1.0]
+    result = pl._check_paths([bad], NO_OBS)
+    assert all(not any(fp is bad for fp in fps) for fps in result.values())
+
+
+# ---------------------------------------------------------------- tests/test_smooth_braking.py
+
+def test_brake_ladder_generated_below_min_t():                               # :33-49
+    pl = make_brake_planner()
+    pl.plan(EgoVehicleState(x=5.0, y=0.5, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    cost, status, keep, nt = pl.candidate_table()
+    expected = len(np.arange(0.5, pl.min_t - 1e-9, 0.5))
+    cands = [pl.engine.candidate_path(i) for i in range(len(cost) - expected, len(cost))]
+    assert len(cands) == expected > 0
+    for fp in cands:
+        assert fp.t[-1] == pytest.approx(pl.max_t)
+        assert fp.s_d[-1] == pytest.approx(0.0, abs=1e-9)
+        assert abs(fp.s[-1] - fp.s[-2]) < 1e-9
+        assert fp.d[-1] == pytest.approx(0.5, abs=1e-9)
+    stop = [fp.s[-1] - fp.s[0] for fp in cands]                              # :51-58
+    assert min(stop) < 3.0 and max(stop) < 5.0 * pl.min_t / 2.0
+    assert np.any(status[-expected:] == _abi.ST_ACCEL)                       # :64-76 accel gate
+
+
+def test_no_brake_candidates_at_standstill():                                # :60-62
+    pl = make_brake_planner()
+    pl.plan(EgoVehicleState(x=5.0, y=0.0, yaw=0.0, v=0.0, a=0.0), NO_OBS, target_speed=5.0)
+    moving = make_brake_planner()
+    moving.plan(EgoVehicleState(x=5.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, target_speed=5.0)
+    assert len(moving.candidate_table()[0]) - len(pl.candidate_table()[0]) == 7
+
+
+def test_plan_yields_short_stop_when_wall_inside_min_t_distance():           # :78-92
+    pl = make_brake_planner(max_accel=8.0)
+    ys = np.arange(-3.5, 3.6, 0.25)
+    wall = np.stack([np.full_like(ys, 16.0), ys], axis=1)
+    path = pl.plan(EgoVehicleState(x=10.0, y=0.0, yaw=0.0, v=5.0, a=0.0), wall, np.empty((0, 0, 2)), target_speed=5.0)
+    assert path is not None
+    assert path.v[-1] == pytest.approx(0.0, abs=0.05)
+    assert max(path.x) < 16.0 - 1.0
+
+
+def test_stop_distance_directive():                                          # :96-134
+    pl = make_brake_planner(max_accel=8.0)
+    ego = EgoVehicleState(x=10.0, y=0.0, yaw=0.0, v=3.0, a=0.0)
+    lazy = pl.plan(ego, NO_OBS, np.empty((0, 0, 2)), target_speed=0.0)
+    committed = pl.plan(ego, NO_OBS, np.empty((0, 0, 2)), target_speed=0.0, max_stop_distance=2.5)
+    assert lazy is not None and committed is not None
+    assert lazy.s[-1] - lazy.s[0] > 4.0
+    assert committed.s[-1] - committed.s[0] <= 2.5 + 1e-6
+    assert abs(committed.v[-1]) < 0.15
+    assert pl.last_check_stats["stop_distance_error"] > 0
+    assert pl.plan(EgoVehicleState(x=10.0, y=0.0, yaw=0.0, v=5.0, a=0.0), NO_OBS, np.empty((0, 0, 2)),
+                   target_speed=0.0, max_stop_distance=0.05) is None
+    hold = pl.plan(EgoVehicleState(x=10.0, y=0.0, yaw=0.0, v=0.05, a=0.0), NO_OBS, np.empty((0, 0, 2)),
+                   target_speed=0.0, max_stop_distance=0.3)
+    assert hold is not None and hold.s[-1] - hold.s[0] <= 0.3 + 1e-6
+
+
+# ---------------------------------------------------------------- tests/test_footprint.py
+
+def _fp_planner(**kwargs):
+    return FrenetPlanner(reference_path=straight_spline(), dt=0.1, **kwargs)
+
+
+def _straight_path(n=10, dt=0.1):
+    fp = FrenetPath()
+    fp.x = [i * 1.0 for i in range(n)]; fp.y = [0.0] * n; fp.t = [i * dt for i in range(n)]; fp.yaw = [0.0] * n
+    return fp
+
+
+def test_footprint_model():                                                  # footprint.py:26-40, :105-119
+    m = EgoFootprint.multi_circle(4.5, 2.0, 3)
+    np.testing.assert_allclose(m.offsets, [-1.5, 0.0, 1.5])
+    assert m.radius == pytest.approx(1.25)
+
+
+def test_static_nose_collision_detected_only_with_footprint():               # :121-135
+    obstacle = np.array([[10.4, 0.0]])
+    kw = dict(robot_radius=1.0, obstacle_radius=0.2)
+    assert _fp_planner(**kw)._check_collision(_straight_path(), obstacle)
+    multi = _fp_planner(**kw, footprint=EgoFootprint.multi_circle(4.5, 2.0, 3))
+    assert not multi._check_collision(_straight_path(), obstacle)
+
+
+def test_distribution_check_uses_footprint_and_pads_yaw():                   # :137-155
+    pl = _fp_planner(robot_radius=1.0, obstacle_radius=0.2, footprint=EgoFootprint.multi_circle(4.5, 2.0, 3))
+    distribution = np.full((1, 1, 10, 2), [10.4, 0.0])
+    assert not pl._check_collision_distribution(_straight_path(), NO_OBS, distribution, epsilon=0.0)
+    path = _straight_path()
+    path.yaw = path.yaw[:-1]
+    assert not pl._check_collision(path, np.array([[10.4, 0.0]]))
+
+
+# ---------------------------------------------------------------- cubic spline / converter
+
+def test_curvature_rate_matches_finite_difference():                         # tests/test_cubic_spline_curvature.py:25-35
+    sp = CubicSpline2D([0.0, 10.0, 20.0, 30.0, 40.0], [0.0, 2.0, -1.0, 3.0, 0.0])
+    s = np.linspace(2.0, sp.s[-1] - 2.0, 40)
+    h = 1e-5
+    fd = (sp.calc_curvature(s + h) - sp.calc_curvature(s - h)) / (2 * h)
+    np.testing.assert_allclose(sp.calc_curvature_rate(s), fd, rtol=1e-4, atol=1e-6)
+
+
+def test_spline_domain_and_nearest_point_at_ends():                          # tests/test_coordinate_converter.py:70-83
+    sp = CubicSpline2D([0.0, 10.0, 20.0], [0.0, 0.0, 0.0])
+    x, y = sp.calc_position(np.array([-0.1, 0.0, 20.0, 20.1]))
+    assert np.isnan(x[0]) and np.isnan(x[3]) and x[1] == 0.0 and x[2] == 20.0
+    pl = FrenetPlanner(sp, dt=0.1)
+    fs = pl._cartesian_to_frenet_state(EgoVehicleState(x=-3.0, y=1.0, yaw=0.0, v=1.0, a=0.0))
+    assert fs is not None and abs(fs.s) < 1e-6
+    fs = pl._cartesian_to_frenet_state(EgoVehicleState(x=25.0, y=-1.0, yaw=0.0, v=1.0, a=0.0))
+    assert fs is not None and abs(fs.s - 20.0) < 1e-6
