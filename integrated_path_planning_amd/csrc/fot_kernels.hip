@@ -20,6 +20,32 @@
 namespace fot {
 
 // ---------------------------------------------------------------------------
+// wave-level reductions on the DPP data path (no LDS traffic)
+// ---------------------------------------------------------------------------
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    // lanes without a valid source (or masked rows) keep their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// butterfly inside quads / half rows / rows, then row_bcast15 and row_bcast31: lane 63 ends with the reduction
+#define FOT_WAVE_REDUCE_F32(NAME, OP)                                                        \
+    __device__ __forceinline__ float NAME(float v)                                           \
+    {                                                                                        \
+        v = OP(v, dpp_f32<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2] */                         \
+        v = OP(v, dpp_f32<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1] */                         \
+        v = OP(v, dpp_f32<0x141, 0xf>(v)); /* row_half_mirror */                             \
+        v = OP(v, dpp_f32<0x140, 0xf>(v)); /* row_mirror */                                  \
+        v = OP(v, dpp_f32<0x142, 0xa>(v)); /* row_bcast15 -> rows 1, 3 */                    \
+        v = OP(v, dpp_f32<0x143, 0xc>(v)); /* row_bcast31 -> rows 2, 3 */                    \
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));             \
+    }
+FOT_WAVE_REDUCE_F32(wave_min_f32, fminf)
+FOT_WAVE_REDUCE_F32(wave_max_f32, fmaxf)
+
+// ---------------------------------------------------------------------------
 // ego -> Frenet state
 // ---------------------------------------------------------------------------
 
@@ -128,7 +154,7 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__r
         tab[3 * FOT_MAX_NT + k] = ls.rx;    tab[4 * FOT_MAX_NT + k] = ls.ry;
         tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
         tab[7 * FOT_MAX_NT + k] = ls.kr;    tab[8 * FOT_MAX_NT + k] = ls.dkr;
-        tab[9 * FOT_MAX_NT + k] = sddd;
+        tab[9 * FOT_MAX_NT + k] = ls.inv_sd;
         jerk2 = sddd * sddd;
         sd_k = ls.sd;
     }
@@ -161,16 +187,10 @@ struct ScratchSink {
     // every lane of the wave arrives here once per time step
     __device__ __forceinline__ void row_done(int k)
     {
-        Box32 b = cur;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            Box32 o;
-            o.x0 = __shfl_xor(b.x0, off, WAVE); o.y0 = __shfl_xor(b.y0, off, WAVE);
-            o.x1 = __shfl_xor(b.x1, off, WAVE); o.y1 = __shfl_xor(b.y1, off, WAVE);
-            box_merge(b, o);
-        }
+        const float x0 = wave_min_f32(cur.x0), y0 = wave_min_f32(cur.y0);
+        const float x1 = wave_max_f32(cur.x1), y1 = wave_max_f32(cur.y1);
         if (lane == 0) {
-            float4 w; w.x = b.x0; w.y = b.y0; w.z = b.x1; w.w = b.y1;
+            float4 w; w.x = x0; w.y = y0; w.z = x1; w.w = y1;
             *(float4 *)(wbox + 4 * k) = w;
         }
         cur = box_empty();
@@ -255,12 +275,21 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 // the candidates' bounding box of k grown by the collision radius, FAR32-padded to a multiple of 8.
 template <typename T>
 __global__ void __launch_bounds__(WAVE)
-k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const float *__restrict__ wave_box,
-       const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
+k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int n_inst,
+       const float *__restrict__ wave_box, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid)
 {
     const DevParams &P = *Pp;
-    const int inst = blockIdx.y, k = blockIdx.x;
+    // XCD-aware block -> (instance, time step) map.  Workgroups are dealt round-robin over the 8 XCDs
+    // (blocks b and b+8 share one), and 8 consecutive time steps of one pedestrian share a cache line of
+    // the [S][P][T][2] input, so the 8 time steps of a group are given block ids that are equal mod 8:
+    // the line is fetched into one XCD's L2 once instead of into eight.  Speed only, never correctness.
+    const int groups = (P.n_total + 7) >> 3;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int k_in = slot & 7, q = (slot >> 3) * 8 + xcd;       // q = inst * groups + group
+    const int inst = q / groups, k = (q - inst * groups) * 8 + k_in;
+    if (inst >= n_inst || k >= P.n_total) return;
     const InstDesc &D = desc[inst];
     if (D.ent_cap == 0) return;
     const int lane = threadIdx.x;
@@ -271,13 +300,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
         box_merge(b, o);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Box32 o;
-        o.x0 = __shfl_xor(b.x0, off, WAVE); o.y0 = __shfl_xor(b.y0, off, WAVE);
-        o.x1 = __shfl_xor(b.x1, off, WAVE); o.y1 = __shfl_xor(b.y1, off, WAVE);
-        box_merge(b, o);
-    }
+    b.x0 = wave_min_f32(b.x0); b.y0 = wave_min_f32(b.y0);
+    b.x1 = wave_max_f32(b.x1); b.y1 = wave_max_f32(b.y1);
     const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
     int count = 0;
     if (b.x0 <= b.x1) {
@@ -365,29 +389,49 @@ k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
     bool collided = false;
     uint64_t hit_mask = 0;
     int viol = 0;
+    d2 p_next = my_pts[0];                                        // point of (k = 0, circle 0), prefetched
     for (int k = 0; k < kmax; ++k) {
         const bool act = !collided && k < keep;
         if (!__any(act)) break;                                   // keep is fixed: no lane can become active later
         const int n = cnt[k];
-        if (n == 0) continue;
         const int64_t base = D.ent_off + (int64_t)k * ent_cap;
         const f2x8 *chunks = (const f2x8 *)(ent32 + base);
+        const int n_chunks = n / ENT_CHUNK;
         for (int ci = 0; ci < n_circ; ++ci) {
-            const d2 p = my_pts[((int64_t)ci * n_total + k) * WAVE];
+            const d2 p = p_next;
+            {   // prefetch the next point (next circle, or circle 0 of the next time step) behind this one's work
+                const int cn = ci + 1 < n_circ ? ci + 1 : 0;
+                const int kn = ci + 1 < n_circ ? k : (k + 1 < n_total ? k + 1 : k);
+                p_next = my_pts[((int64_t)cn * n_total + kn) * WAVE];
+            }
+            if (n_chunks == 0) continue;
             const float fx = (float)(p.x - ox0), fy = (float)(p.y - oy0);
             const float thr = filter_threshold(sq_max, fx, fy);
-            const int n_chunks = n / ENT_CHUNK;
-            f2x8 cur = chunks[0];
-            for (int c = 0; c < n_chunks; ++c) {
-                const f2x8 nxt = chunks[c + 1 < n_chunks ? c + 1 : c];     // scalar prefetch of the next chunk
-                const float m = min_sqdist32_8(cur, fx, fy);
-                const bool maybe = act && !collided && m <= thr;
-                if (__any(maybe)) {
-                    if (maybe)
-                        exact_chunk(ent64 + base + c * ENT_CHUNK, ent_sid + base + c * ENT_CHUNK, p.x, p.y, P.sq_r, sq_dyn,
-                                    max_viol, hit_mask, viol, collided);
+            // two chunk buffers, each reloaded right after its use: the scalar load of chunk c+2 is in
+            // flight while chunk c+1 is processed, and no SGPR copies are needed
+            f2x8 ca = chunks[0];
+            f2x8 cb = chunks[n_chunks > 1 ? 1 : 0];
+            for (int c = 0; c < n_chunks; c += 2) {
+                {
+                    const float m = min_sqdist32_8(ca, fx, fy);
+                    ca = chunks[c + 2 < n_chunks ? c + 2 : c];
+                    const bool maybe = act && !collided && m <= thr;
+                    if (__any(maybe)) {
+                        if (maybe)
+                            exact_chunk(ent64 + base + c * ENT_CHUNK, ent_sid + base + c * ENT_CHUNK, p.x, p.y, P.sq_r,
+                                        sq_dyn, max_viol, hit_mask, viol, collided);
+                    }
                 }
-                cur = nxt;
+                if (c + 1 < n_chunks) {
+                    const float m = min_sqdist32_8(cb, fx, fy);
+                    cb = chunks[c + 3 < n_chunks ? c + 3 : c + 1];
+                    const bool maybe = act && !collided && m <= thr;
+                    if (__any(maybe)) {
+                        if (maybe)
+                            exact_chunk(ent64 + base + (c + 1) * ENT_CHUNK, ent_sid + base + (c + 1) * ENT_CHUNK, p.x, p.y,
+                                        P.sq_r, sq_dyn, max_viol, hit_mask, viol, collided);
+                    }
+                }
             }
         }
     }
@@ -625,13 +669,15 @@ int launch_cull(const DevParams *P, const InstDesc *desc, int n_inst, int n_tota
                 const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, hipStream_t st)
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
-    dim3 grid((unsigned)n_total, (unsigned)n_inst);
+    const int groups = (n_total + 7) / 8;
+    const int64_t q_pad = ((int64_t)n_inst * groups + 7) / 8 * 8;          // groups, padded so that every XCD slot exists
+    const unsigned grid = (unsigned)(q_pad * 8);
     if (dtype == FOT_F32)
-        k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, wave_box, (const float *)static_xy, (const float *)dyn_xy,
-                                             e.cnt, e.e32, e.e64, e.sid);
+        k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, n_inst, wave_box, (const float *)static_xy,
+                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid);
     else
-        k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, wave_box, (const double *)static_xy, (const double *)dyn_xy,
-                                              e.cnt, e.e32, e.e64, e.sid);
+        k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, n_inst, wave_box, (const double *)static_xy,
+                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid);
     FOT_LAUNCH_CHECK();
     return 0;
 }

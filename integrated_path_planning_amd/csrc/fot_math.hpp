@@ -254,33 +254,38 @@ FOT_HD void lon_sample(const LonInfo &L, int k, double dt, double &s, double &sd
 
 struct LonSample {
     double s, sd, sdd, rx, ry, cos_r, sin_r, kr, dkr;
+    double inv_sd;                       // 1/sd, or 0 below EPS_S_DOT (d' = d'' = 0 there, frenet_planner.py:792-799)
 };
 
 struct CartSample {
     double x, y, cos_t, sin_t, kappa, v, a, omkd;
 };
 
+// One reciprocal and one reciprocal square root per sample: with h = sqrt(d'^2 + (1-kd)^2) the
+// reference's atan2/cos/tan terms are cos = (1-kd)/h, sin = d'/h, tan = d'/(1-kd), (1-kd)/cos = h and
+// v = sqrt((1-kd)^2 sd^2 + (d' sd)^2) = |sd| h.
 FOT_HD void frenet_to_cart(const LonSample &L, double d, double d_d, double d_dd, CartSample &o)
 {
-    const bool moving = fabs(L.sd) > 1e-3;
-    const double safe = moving ? L.sd : 1.0;
-    const double dp = moving ? d_d / safe : 0.0;
-    const double dpp = moving ? (d_dd - dp * L.sdd) / (safe * safe) : 0.0;
+    const double dp = d_d * L.inv_sd;
+    const double dpp = (d_dd - dp * L.sdd) * (L.inv_sd * L.inv_sd);
     const double omkd = 1.0 - L.kr * d;
-    const double h = sqrt(dp * dp + omkd * omkd);
-    const double cos_d = omkd / h, sin_d = dp / h;      // cos/sin of atan2(dp, omkd)
-    const double tan_d = dp / omkd;
+    const double inv_om = 1.0 / omkd;
+    const double hh = dp * dp + omkd * omkd;
+    const double inv_h = 1.0 / sqrt(hh);
+    const double h = hh * inv_h;
+    const double cos_d = omkd * inv_h, sin_d = dp * inv_h;
+    const double tan_d = dp * inv_om;
+    const double inv_cos = h * inv_om;
     const double krdp = L.dkr * d + L.kr * dp;
-    const double kappa = (((dpp + krdp * tan_d) * cos_d * cos_d) / omkd + L.kr) * cos_d / omkd;
-    const double d_dot = dp * L.sd;
-    const double dtp = omkd / cos_d * kappa - L.kr;
+    const double kappa = (((dpp + krdp * tan_d) * cos_d * cos_d) * inv_om + L.kr) * cos_d * inv_om;
+    const double dtp = h * kappa - L.kr;
     o.x = L.rx - L.sin_r * d;
     o.y = L.ry + L.cos_r * d;
     o.cos_t = cos_d * L.cos_r - sin_d * L.sin_r;
     o.sin_t = sin_d * L.cos_r + cos_d * L.sin_r;
     o.kappa = kappa;
-    o.v = sqrt(omkd * omkd * L.sd * L.sd + d_dot * d_dot);
-    o.a = L.sdd * omkd / cos_d + L.sd * L.sd / cos_d * (dp * dtp - krdp);
+    o.v = fabs(L.sd) * h;
+    o.a = L.sdd * h + L.sd * L.sd * inv_cos * (dp * dtp - krdp);
     o.omkd = omkd;
 }
 
@@ -290,6 +295,7 @@ FOT_HD void load_lon_sample(const double *tab, int k, LonSample &L)
     L.rx = tab[3 * FOT_MAX_NT + k];  L.ry = tab[4 * FOT_MAX_NT + k];
     L.cos_r = tab[5 * FOT_MAX_NT + k]; L.sin_r = tab[6 * FOT_MAX_NT + k];
     L.kr = tab[7 * FOT_MAX_NT + k];  L.dkr = tab[8 * FOT_MAX_NT + k];
+    L.inv_sd = tab[9 * FOT_MAX_NT + k];
 }
 
 // one entry of the longitudinal table: profile state + reference frame at s
@@ -300,6 +306,7 @@ FOT_HD void make_lon_sample(const SplineView &sp, const LonInfo &L, int k, doubl
     spline_point(sp, o.s, p);
     o.rx = p.x; o.ry = p.y;
     spline_frame(p, o.cos_r, o.sin_r, o.kr, o.dkr);
+    o.inv_sd = fabs(o.sd) > 1e-3 ? 1.0 / o.sd : 0.0;            // EPS_S_DOT
 }
 
 // ---------------------------------------------------------------------------
@@ -321,7 +328,7 @@ struct PathSample {
 
 struct CheckAcc {
     bool finite_ok, nan_step, f_speed, f_accel, f_curv, f_lat, f_road;
-    double max_step;
+    double max_step2;                    // largest squared step between consecutive samples
     PathSample prev;
 };
 
@@ -329,7 +336,7 @@ FOT_HD void check_init(CheckAcc &c)
 {
     c.finite_ok = true; c.nan_step = false;
     c.f_speed = c.f_accel = c.f_curv = c.f_lat = c.f_road = false;
-    c.max_step = -INFINITY;
+    c.max_step2 = -INFINITY;
     c.prev.x = c.prev.y = c.prev.kappa = c.prev.v = c.prev.a = c.prev.d = c.prev.s = 0.0;
     c.prev.cos_t = 1.0; c.prev.sin_t = 0.0;
 }
@@ -341,9 +348,10 @@ FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int
 {
     if (!(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa))) c.finite_ok = false;        // :944-946
     if (k > 0) {
-        const double step = hypot(p.x - c.prev.x, p.y - c.prev.y);                            // :953-956
-        if (isnan(step)) c.nan_step = true;
-        if (step > c.max_step) c.max_step = step;
+        const double sx = p.x - c.prev.x, sy = p.y - c.prev.y;                                // :953-956
+        const double step2 = sx * sx + sy * sy;
+        if (isnan(step2)) c.nan_step = true;
+        if (step2 > c.max_step2) c.max_step2 = step2;
         if (p.v > D.lim_speed) c.f_speed = true;                                              // :964
         if (fabs(p.a) > D.lim_accel) c.f_accel = true;                                        // :966
         if (p.v > 0.5) {                                                                       // LOW_SPEED_CURVATURE_GATE
@@ -355,7 +363,7 @@ FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int
             const double sn = p.sin_t * c.prev.cos_t - p.cos_t * c.prev.sin_t;                // sin/cos of the yaw step
             const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
             const double dyaw = fabs(atan2(sn, cs));
-            if (dyaw > fmax(D.lim_curv * step, 0.1)) c.f_curv = true;                         // yaw-step cap
+            if (dyaw > fmax(D.lim_curv * sqrt(step2), 0.1)) c.f_curv = true;                  // yaw-step cap
         }
         if (p.v * p.v * fabs(p.kappa) > D.lim_lat) c.f_lat = true;                            // :975
         if (has_d && fabs(p.d) > P.max_road_width + 1e-9) c.f_road = true;                    // :982
@@ -366,7 +374,7 @@ FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int
 // first failing category in the reference's order; ST_PENDING = collision check outstanding
 FOT_HD int check_status(const InstDesc &D, const CheckAcc &c, int keep)
 {
-    if (keep == 0 || !c.finite_ok || (!c.nan_step && c.max_step > D.step_limit)) return FOT_ST_DROPPED;
+    if (keep == 0 || !c.finite_ok || (!c.nan_step && sqrt(c.max_step2) > D.step_limit)) return FOT_ST_DROPPED;
     if (c.f_speed) return FOT_ST_SPEED;
     if (c.f_accel) return FOT_ST_ACCEL;
     if (c.f_curv) return FOT_ST_CURVATURE;

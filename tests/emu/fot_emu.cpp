@@ -105,7 +105,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 tab[0 * FOT_MAX_NT + k] = ls.s; tab[1 * FOT_MAX_NT + k] = ls.sd; tab[2 * FOT_MAX_NT + k] = ls.sdd;
                 tab[3 * FOT_MAX_NT + k] = ls.rx; tab[4 * FOT_MAX_NT + k] = ls.ry;
                 tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
-                tab[7 * FOT_MAX_NT + k] = ls.kr; tab[8 * FOT_MAX_NT + k] = ls.dkr; tab[9 * FOT_MAX_NT + k] = sddd;
+                tab[7 * FOT_MAX_NT + k] = ls.kr; tab[8 * FOT_MAX_NT + k] = ls.dkr; tab[9 * FOT_MAX_NT + k] = ls.inv_sd;
                 js += sddd * sddd; sd_last = ls.sd;
             }
             Li.Js = js; Li.sd_last = sd_last;
