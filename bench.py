@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--instances-per-gpu", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="diagnostic builds only (FOT_COLLIDE_ABLATE)")
     ap.add_argument("--cpu-instances", type=int, default=256,
                     help="instances of the same workload timed on the CPU oracle (~53 ms each)")
     return ap.parse_args()
@@ -151,7 +152,7 @@ def main():
     from helpers import assert_record_matches_oracle, oracle_plan_for_request
     oparams = orc.make_params(**kw)
     osp = orc.Spline(syn.STRAIGHT_WX, syn.STRAIGHT_WY)
-    n_check = min(4, n_inst)
+    n_check = 0 if args.no_parity else min(4, n_inst)
     for i in range(n_check):
         assert_record_matches_oracle(recs[i], oracle_plan_for_request(orc, oparams, osp, reqs[i]), label=f"inst {i}")
 
@@ -208,7 +209,7 @@ def main():
                                   % (world, _abi.RESULT_BYTES)},
         "roofline": roofline, "roofline_valu": valu, "kernel_ms": kernels,
         "cpu_baseline": cpu, "latency": latency, "host_api": host_api,
-        "parity": {"instances_checked_against_oracle": n_check, "ok": True},
+        "parity": {"instances_checked_against_oracle": n_check, "ok": n_check > 0},
     }
     print(json.dumps(line))
     if world > 1:

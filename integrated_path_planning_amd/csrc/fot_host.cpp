@@ -68,7 +68,7 @@ struct fot_handle {
     PinnedBuf staging;
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
     DevBuf dState, dLonInfo, dLonTab;
-    DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dPts;
+    DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dHit, dPts;
     DevBuf dWaveBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: wave boxes + culled entry lists
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
@@ -208,6 +208,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     HIP_TRY(h, h->dTravel.ensure(sizeof(double) * slots));
     HIP_TRY(h, h->dStatus.ensure(slots));
     HIP_TRY(h, h->dKeep.ensure(slots));
+    HIP_TRY(h, h->dHit.ensure(sizeof(unsigned long long) * slots));
     HIP_TRY(h, h->dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
     HIP_TRY(h, h->dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
     const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
@@ -229,6 +230,8 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     CandArrays ca;
     ca.cost = h->dCost.as<double>(); ca.v_last = h->dVlast.as<double>(); ca.travel = h->dTravel.as<double>();
     ca.status = h->dStatus.as<uint8_t>(); ca.keep = h->dKeep.as<uint8_t>();
+    ca.hit = h->dHit.as<unsigned long long>();
+    if (L.any_obstacles) HIP_TRY(h, hipMemsetAsync(ca.hit, 0, sizeof(unsigned long long) * slots, st));
 
     if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
     EntryArrays ea;
@@ -314,7 +317,7 @@ void fot_destroy(fot_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dMeta, &h->dState, &h->dLonInfo, &h->dLonTab, &h->dCost, &h->dVlast,
-                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dPts, &h->dWaveBox, &h->dEntCnt, &h->dEnt32, &h->dEnt64, &h->dEntSid, &h->dUserStatic,
+                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dHit, &h->dPts, &h->dWaveBox, &h->dEntCnt, &h->dEnt32, &h->dEnt64, &h->dEntSid, &h->dUserStatic,
                        &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     h->staging.release();

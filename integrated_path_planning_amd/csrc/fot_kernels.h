@@ -10,6 +10,7 @@ namespace fot {
 struct CandArrays {
     double *cost, *v_last, *travel;
     uint8_t *status, *keep;
+    unsigned long long *hit;   // prediction samples that hit the candidate (bit per sample)
 };
 
 // broad-phase entry lists in HBM: per instance n_total * ent_cap slots

@@ -14,6 +14,8 @@
 //                    (shuffle reduction, lowest index wins ties), selected path written out
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fot_math.hpp"
 #include "fot_kernels.h"
 
@@ -331,8 +333,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
             const unsigned long long mask = __ballot(inside);
             if (inside) {
                 const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-                f2 q; q.x = (float)(o.x - D.ego.x); q.y = (float)(o.y - D.ego.y);
-                ent32[base + pos] = q;
+                ent32_store(ent32, base + pos, (float)(o.x - D.ego.x), (float)(o.y - D.ego.y));
                 ent64[base + pos] = o;
                 ent_sid[base + pos] = (uint8_t)sid;
             }
@@ -340,9 +341,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
         }
         const int padded = (count + ENT_CHUNK - 1) & ~(ENT_CHUNK - 1);
         if (lane < padded - count) {
-            f2 q; q.x = FAR32; q.y = FAR32;
             d2 o; o.x = INFINITY; o.y = INFINITY;
-            ent32[base + count + lane] = q;
+            ent32_store(ent32, base + count + lane, FAR32, FAR32);
             ent64[base + count + lane] = o;
             ent_sid[base + count + lane] = SID_STATIC;
         }
@@ -351,24 +351,72 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
     if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = count;
 }
 
-// One wave = 64 candidates of one instance, lane = candidate.  Time steps and entry chunks are walked
-// wave-uniformly: a chunk (8 obstacles = 64 B) comes in through one scalar load that is issued one
-// chunk ahead of its use; each lane keeps the float32 minimum squared distance of the chunk and only chunks
-// that come within the conservative threshold are re-checked in float64, so the decision is the reference's.
-__global__ void __launch_bounds__(256)
+// One workgroup = 64 candidates of one instance (lane = candidate) x COLLIDE_SLICES waves, each wave taking
+// a contiguous slice of the time steps: the per-wave dependent-load chain is a quarter as long and the
+// scheduler has four times as many waves to balance.  Time steps and entry chunks (8 obstacles = 64 B, one
+// scalar load, fetched one chunk ahead) are walked wave-uniformly; each lane keeps the float32 minimum squared
+// distance of the chunk and only chunks that come within the conservative threshold are re-checked in
+// float64, so the decision is the reference's.  Slices meet in cand_hit (per-candidate bit mask of colliding
+// prediction samples, atomicOr) and in cand_status for static hits; k_select counts the bits.
+constexpr int COLLIDE_SLICES = 4;
+
+typedef float f16 __attribute__((ext_vector_type(16)));           // one chunk = 8 (x, y) pairs in 16 SGPRs
+
+// s_load_dwordx16 of one chunk, NOT waited for (see k_collide)
+__device__ __forceinline__ void sload_chunk(f16 &dst, const f2x8 *src)
+{
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(dst) : "s"(src) : "memory");
+}
+
+// waits for every outstanding scalar load; `c` is tied in so that its uses stay behind the wait
+__device__ __forceinline__ void swait_chunk(f16 &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c) : : "memory");
+}
+
+// smallest float32 squared distance from (fx, fy) to the 8 entries of a chunk held in SGPRs as x[8], y[8].
+// Two obstacles per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on (x_j, x_j+1) and (y_j, y_j+1).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float fy)
+{
+    const v2f px = { fx, fx }, py = { fy, fy };
+    v2f t[ENT_CHUNK / 2];
+#pragma unroll
+    for (int j = 0; j < ENT_CHUNK / 2; ++j) {
+        const v2f ox = { c[2 * j], c[2 * j + 1] }, oy = { c[8 + 2 * j], c[8 + 2 * j + 1] };
+        const v2f dx = px - ox, dy = py - oy;
+        t[j] = __builtin_elementwise_fma(dy, dy, dx * dx);
+    }
+    float m = fminf(fminf(t[0].x, t[0].y), t[1].x);
+    m = fminf(fminf(m, t[1].y), t[2].x);
+    m = fminf(fminf(m, t[2].y), t[3].x);
+    return fminf(m, t[3].y);
+}
+
+// ABLATE != 0 builds are timing-only diagnostics (wrong results), selected with FOT_COLLIDE_ABLATE:
+//   1 no chunk loads after the first   2 no distance arithmetic   4 no point loads   8 empty time-step loop
+template <int ABLATE>
+__global__ void __launch_bounds__(COLLIDE_SLICES * WAVE)
 k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
           const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
           const int32_t *__restrict__ ent_cnt, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
           const uint8_t *__restrict__ ent_sid, const d2 *__restrict__ pts,
-          uint8_t *__restrict__ cand_status, const uint8_t *__restrict__ cand_keep)
+          uint8_t *__restrict__ cand_status, const uint8_t *__restrict__ cand_keep,
+          unsigned long long *__restrict__ cand_hit)
 {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
+    const int wave = blockIdx.x;                                  // candidate wave (uniform by construction)
     if (wave >= n_waves) return;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int lane = threadIdx.x & (WAVE - 1);
     const DevParams &P = *Pp;
     const int inst = wave_inst[wave];
     const InstDesc &D = desc[inst];
     if (D.ent_cap == 0) return;
+    const int n_total = P.n_total;
+    const int slice_len = (n_total + COLLIDE_SLICES - 1) / COLLIDE_SLICES;
+    const int k_begin = slice * slice_len;
+    const int k_end_slice = k_begin + slice_len < n_total ? k_begin + slice_len : n_total;
     const int64_t slot = (int64_t)D.cand_off + wave_base[wave] + lane;
     const bool pending = cand_status[slot] == ST_PENDING;
     const int keep = pending ? (int)cand_keep[slot] : 0;
@@ -376,21 +424,22 @@ k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, WAVE));
     kmax = __builtin_amdgcn_readfirstlane(kmax);
-    if (kmax == 0) return;
+    const int k_end = kmax < k_end_slice ? kmax : k_end_slice;
+    if (k_begin >= k_end) return;
 
     const int n_circ = P.has_footprint ? P.n_circ : 1;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
     const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     const double ox0 = D.ego.x, oy0 = D.ego.y;
-    const d2 *my_pts = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
-    const int32_t *cnt = ent_cnt + (int64_t)inst * P.n_total;
-    const int ent_cap = D.ent_cap, max_viol = D.max_viol, n_total = P.n_total;
+    const d2 *my_pts = pts + (int64_t)wave * P.n_circ * n_total * WAVE + lane;
+    const int32_t *cnt = ent_cnt + (int64_t)inst * n_total;
+    const int ent_cap = D.ent_cap, max_viol = D.max_viol;
 
-    bool collided = false;
+    bool collided = false, static_hit = false;
     uint64_t hit_mask = 0;
     int viol = 0;
-    d2 p_next = my_pts[0];                                        // point of (k = 0, circle 0), prefetched
-    for (int k = 0; k < kmax; ++k) {
+    d2 p_next = my_pts[(int64_t)k_begin * WAVE];                  // point of (k_begin, circle 0), prefetched
+    for (int k = k_begin; k < k_end; ++k) {
         const bool act = !collided && k < keep;
         if (!__any(act)) break;                                   // keep is fixed: no lane can become active later
         const int n = cnt[k];
@@ -399,43 +448,55 @@ k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
         const int n_chunks = n / ENT_CHUNK;
         for (int ci = 0; ci < n_circ; ++ci) {
             const d2 p = p_next;
-            {   // prefetch the next point (next circle, or circle 0 of the next time step) behind this one's work
+            if (!(ABLATE & 4)) {   // prefetch the next point (next circle, or circle 0 of the next time step)
                 const int cn = ci + 1 < n_circ ? ci + 1 : 0;
                 const int kn = ci + 1 < n_circ ? k : (k + 1 < n_total ? k + 1 : k);
                 p_next = my_pts[((int64_t)cn * n_total + kn) * WAVE];
             }
-            if (n_chunks == 0) continue;
+            if (n_chunks == 0 || (ABLATE & 8)) continue;
             const float fx = (float)(p.x - ox0), fy = (float)(p.y - oy0);
             const float thr = filter_threshold(sq_max, fx, fy);
-            // two chunk buffers, each reloaded right after its use: the scalar load of chunk c+2 is in
-            // flight while chunk c+1 is processed, and no SGPR copies are needed
-            f2x8 ca = chunks[0];
-            f2x8 cb = chunks[n_chunks > 1 ? 1 : 0];
-            for (int c = 0; c < n_chunks; c += 2) {
-                {
-                    const float m = min_sqdist32_8(ca, fx, fy);
-                    ca = chunks[c + 2 < n_chunks ? c + 2 : c];
-                    const bool maybe = act && !collided && m <= thr;
-                    if (__any(maybe)) {
-                        if (maybe)
-                            exact_chunk(ent64 + base + c * ENT_CHUNK, ent_sid + base + c * ENT_CHUNK, p.x, p.y, P.sq_r,
-                                        sq_dyn, max_viol, hit_mask, viol, collided);
-                    }
+            for (int c0 = 0; c0 < n_chunks; c0 += 64) {            // 64 chunks per pass: one bit per chunk and lane
+                const int nb = n_chunks - c0 < 64 ? n_chunks - c0 : 64;
+                const f2x8 *cp = chunks + c0;
+                uint64_t near_mask = 0;                            // chunks that came within the threshold
+                // Branch-free hot loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns
+                // out of order, so a compiler-placed wait for the chunk in use would also wait for the prefetch
+                // behind it; the loads are therefore inline asm (invisible to the waitcnt pass) and each buffer
+                // is waited for right before its own use, one chunk of arithmetic after its load was issued.
+                f16 ca, cb;
+                sload_chunk(ca, cp);
+                swait_chunk(ca);
+                for (int c = 0; c < nb; c += 2) {
+                    const bool has_b = c + 1 < nb;
+                    if (has_b && !(ABLATE & 1)) sload_chunk(cb, cp + c + 1);
+                    if (!(ABLATE & 2)) near_mask |= min_sqdist32_f16(ca, fx, fy) <= thr ? (uint64_t)1 << c : 0;
+                    if (!has_b) break;
+                    if (!(ABLATE & 1)) swait_chunk(cb); else cb = ca;
+                    const bool has_a = c + 2 < nb;
+                    if (has_a && !(ABLATE & 1)) sload_chunk(ca, cp + c + 2);
+                    if (!(ABLATE & 2)) near_mask |= min_sqdist32_f16(cb, fx, fy) <= thr ? (uint64_t)2 << c : 0;
+                    if (has_a && !(ABLATE & 1)) swait_chunk(ca);
                 }
-                if (c + 1 < n_chunks) {
-                    const float m = min_sqdist32_8(cb, fx, fy);
-                    cb = chunks[c + 3 < n_chunks ? c + 3 : c + 1];
-                    const bool maybe = act && !collided && m <= thr;
-                    if (__any(maybe)) {
-                        if (maybe)
-                            exact_chunk(ent64 + base + (c + 1) * ENT_CHUNK, ent_sid + base + (c + 1) * ENT_CHUNK, p.x, p.y,
-                                        P.sq_r, sq_dyn, max_viol, hit_mask, viol, collided);
+                if (!act || collided) near_mask = 0;
+                if (__any(near_mask != 0)) {                       // rare: exact float64 re-check, lane by lane
+                    while (near_mask != 0 && !collided) {
+                        const int c = __ffsll((unsigned long long)near_mask) - 1;
+                        near_mask &= near_mask - 1;
+                        const int64_t e = base + (int64_t)(c0 + c) * ENT_CHUNK;
+                        bool hard = false;
+                        exact_chunk(ent64 + e, ent_sid + e, p.x, p.y, P.sq_r, sq_dyn, max_viol, hit_mask, viol, hard);
+                        if (hard) {                                // static obstacle, or more samples than allowed
+                            collided = true;
+                            if (viol <= max_viol) static_hit = true;
+                        }
                     }
                 }
             }
         }
     }
-    if (pending && collided) cand_status[slot] = FOT_ST_COLLISION;
+    if (pending && hit_mask != 0) atomicOr(cand_hit + slot, (unsigned long long)hit_mask);
+    if (pending && static_hit) cand_status[slot] = FOT_ST_COLLISION;
 }
 
 // ---------------------------------------------------------------------------
@@ -447,7 +508,8 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
          const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
          const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
          const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
-         const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
+         const uint8_t *__restrict__ cand_keep, const unsigned long long *__restrict__ cand_hit,
+         fot_result *__restrict__ out, int n_inst)
 {
     const int inst = blockIdx.x;
     if (inst >= n_inst) return;
@@ -472,6 +534,8 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
     for (int idx = lane; idx < S.n_cand; idx += WAVE) {
         const int64_t slot = (int64_t)D.cand_off + idx;
         int st = cand_status[slot];
+        // chance constraint over the prediction samples that hit (frenet_planner.py:1113-1124)
+        if (st == ST_PENDING && D.ent_cap != 0 && __popcll(cand_hit[slot]) > D.max_viol) st = FOT_ST_COLLISION;
         st = final_status(st, cand_vlast[slot], cand_travel[slot], D.max_stop);
         cand_status[slot] = (uint8_t)st;
 #pragma unroll
@@ -686,9 +750,20 @@ int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave
                    int n_waves, EntryArrays e, const d2 *pts, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
-    const int wpb = 256 / WAVE;
-    k_collide<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, wave_inst, wave_base, n_waves, e.cnt, e.e32, e.e64,
-                                                        e.sid, pts, c.status, c.keep);
+    static const int ablate = getenv("FOT_COLLIDE_ABLATE") ? atoi(getenv("FOT_COLLIDE_ABLATE")) : 0;
+#define FOT_COLLIDE_LAUNCH(A) k_collide<A><<<n_waves, COLLIDE_SLICES * WAVE, 0, st>>>( \
+        P, desc, wave_inst, wave_base, n_waves, e.cnt, e.e32, e.e64, e.sid, pts, c.status, c.keep, c.hit)
+    switch (ablate) {
+    case 1: FOT_COLLIDE_LAUNCH(1); break;
+    case 2: FOT_COLLIDE_LAUNCH(2); break;
+    case 3: FOT_COLLIDE_LAUNCH(3); break;
+    case 4: FOT_COLLIDE_LAUNCH(4); break;
+    case 7: FOT_COLLIDE_LAUNCH(7); break;
+    case 8: FOT_COLLIDE_LAUNCH(8); break;
+    case 12: FOT_COLLIDE_LAUNCH(12); break;
+    default: FOT_COLLIDE_LAUNCH(0); break;
+    }
+#undef FOT_COLLIDE_LAUNCH
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -698,7 +773,7 @@ int launch_select(const DevParams *P, const InstDesc *desc, const InstState *sta
 {
     if (n_inst <= 0) return 0;
     k_select<<<n_inst, WAVE, 0, st>>>(P, desc, state, lon_info, lon_tab, c.cost, c.v_last, c.travel, c.status,
-                                     c.keep, out, n_inst);
+                                     c.keep, c.hit, out, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }

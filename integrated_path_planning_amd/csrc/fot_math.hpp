@@ -564,14 +564,23 @@ FOT_HD bool cull_inside(const Box32 &b, float m, float fx, float fy)
 
 constexpr int ENT_CHUNK = 8;                                                // entries per broad-phase chunk
 constexpr int SID_STATIC = 255;                                             // entry is a static obstacle
-struct alignas(64) f2x8 { f2 v[ENT_CHUNK]; };
+// float32 entries are stored chunk-wise as structure of arrays, x[8] then y[8] (64 B): neighbouring
+// obstacles sit in neighbouring registers, which is what the packed-float32 arithmetic of k_collide wants
+struct alignas(64) f2x8 { float x[ENT_CHUNK]; float y[ENT_CHUNK]; };
+
+FOT_HD void ent32_store(f2 *e32, int64_t pos, float x, float y)
+{
+    f2x8 *c = (f2x8 *)e32 + (pos >> 3);
+    c->x[pos & 7] = x;
+    c->y[pos & 7] = y;
+}
 
 // smallest float32 squared distance from (fx, fy) to the 8 entries of a chunk (FAR32 padded)
 FOT_HD float min_sqdist32_8(const f2x8 &c, float fx, float fy)
 {
     float t[ENT_CHUNK];
     for (int j = 0; j < ENT_CHUNK; ++j) {
-        const float dx = fx - c.v[j].x, dy = fy - c.v[j].y;
+        const float dx = fx - c.x[j], dy = fy - c.y[j];
         t[j] = fmaf(dy, dy, dx * dx);
     }
     float m = fminf(fminf(t[0], t[1]), t[2]);

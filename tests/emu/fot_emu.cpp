@@ -155,8 +155,8 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     else { const int j = i - D.n_static; o = obs.dyn_at(j / D.P, j % D.P, row, D.P, D.T); sd = j / D.P; }
                     const float fx = (float)(o.x - D.ego.x), fy = (float)(o.y - D.ego.y);
                     if (!cull_inside(bx, margin, fx, fy)) continue;
-                    f2 q; q.x = fx; q.y = fy;
-                    e32[cap * k + count] = q; e64[cap * k + count] = o; sid[cap * k + count] = (uint8_t)sd;
+                    ent32_store(e32.data(), (int64_t)cap * k + count, fx, fy);
+                    e64[cap * k + count] = o; sid[cap * k + count] = (uint8_t)sd;
                     ++count;
                 }
                 cnt[k] = (count + ENT_CHUNK - 1) & ~(ENT_CHUNK - 1);
