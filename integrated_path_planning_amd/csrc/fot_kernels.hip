@@ -339,7 +339,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
             }
             count += __popcll(mask);
         }
-        const int padded = (count + ENT_CHUNK - 1) & ~(ENT_CHUNK - 1);
+        const int padded = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);   // whole chunk pairs (k_collide)
         if (lane < padded - count) {
             d2 o; o.x = INFINITY; o.y = INFINITY;
             ent32_store(ent32, base + count + lane, FAR32, FAR32);
@@ -362,10 +362,11 @@ constexpr int COLLIDE_SLICES = 4;
 
 typedef float f16 __attribute__((ext_vector_type(16)));           // one chunk = 8 (x, y) pairs in 16 SGPRs
 
-// s_load_dwordx16 of one chunk, NOT waited for (see k_collide)
+// s_load_dwordx16 of the chunk OFF bytes behind src, NOT waited for (see k_collide)
+template <int OFF>
 __device__ __forceinline__ void sload_chunk(f16 &dst, const f2x8 *src)
 {
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(dst) : "s"(src) : "memory");
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(src), "n"(OFF) : "memory");
 }
 
 // waits for every outstanding scalar load; `c` is tied in so that its uses stay behind the wait
@@ -456,34 +457,33 @@ k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
             if (n_chunks == 0 || (ABLATE & 8)) continue;
             const float fx = (float)(p.x - ox0), fy = (float)(p.y - oy0);
             const float thr = filter_threshold(sq_max, fx, fy);
-            for (int c0 = 0; c0 < n_chunks; c0 += 64) {            // 64 chunks per pass: one bit per chunk and lane
-                const int nb = n_chunks - c0 < 64 ? n_chunks - c0 : 64;
+            for (int c0 = 0; c0 < n_chunks; c0 += 32) {            // 32 chunks per pass: one bit per chunk and lane
+                const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // even: lists are padded to chunk pairs
                 const f2x8 *cp = chunks + c0;
-                uint64_t near_mask = 0;                            // chunks that came within the threshold
+                uint32_t near_bits = 0;                            // chunk c0+i within the threshold -> bit nb-1-i
                 // Branch-free hot loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns
                 // out of order, so a compiler-placed wait for the chunk in use would also wait for the prefetch
                 // behind it; the loads are therefore inline asm (invisible to the waitcnt pass) and each buffer
                 // is waited for right before its own use, one chunk of arithmetic after its load was issued.
+                // The last pair prefetches one chunk past the list (allocated slack, never used).
                 f16 ca, cb;
-                sload_chunk(ca, cp);
+                sload_chunk<0>(ca, cp);
                 swait_chunk(ca);
                 for (int c = 0; c < nb; c += 2) {
-                    const bool has_b = c + 1 < nb;
-                    if (has_b && !(ABLATE & 1)) sload_chunk(cb, cp + c + 1);
-                    if (!(ABLATE & 2)) near_mask |= min_sqdist32_f16(ca, fx, fy) <= thr ? (uint64_t)1 << c : 0;
-                    if (!has_b) break;
+                    if (!(ABLATE & 1)) sload_chunk<64>(cb, cp);
+                    if (!(ABLATE & 2)) near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(ca, fx, fy) <= thr);
                     if (!(ABLATE & 1)) swait_chunk(cb); else cb = ca;
-                    const bool has_a = c + 2 < nb;
-                    if (has_a && !(ABLATE & 1)) sload_chunk(ca, cp + c + 2);
-                    if (!(ABLATE & 2)) near_mask |= min_sqdist32_f16(cb, fx, fy) <= thr ? (uint64_t)2 << c : 0;
-                    if (has_a && !(ABLATE & 1)) swait_chunk(ca);
+                    if (!(ABLATE & 1)) sload_chunk<128>(ca, cp);
+                    if (!(ABLATE & 2)) near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(cb, fx, fy) <= thr);
+                    if (!(ABLATE & 1)) swait_chunk(ca);
+                    cp += 2;
                 }
-                if (!act || collided) near_mask = 0;
-                if (__any(near_mask != 0)) {                       // rare: exact float64 re-check, lane by lane
-                    while (near_mask != 0 && !collided) {
-                        const int c = __ffsll((unsigned long long)near_mask) - 1;
-                        near_mask &= near_mask - 1;
-                        const int64_t e = base + (int64_t)(c0 + c) * ENT_CHUNK;
+                if (!act || collided) near_bits = 0;
+                if (__any(near_bits != 0)) {                       // rare: exact float64 re-check, lane by lane
+                    while (near_bits != 0 && !collided) {
+                        const int hb = 31 - __clz((int)near_bits);  // highest bit = earliest chunk
+                        near_bits &= ~(1u << hb);
+                        const int64_t e = base + (int64_t)(c0 + nb - 1 - hb) * ENT_CHUNK;
                         bool hard = false;
                         exact_chunk(ent64 + e, ent_sid + e, p.x, p.y, P.sq_r, sq_dyn, max_viol, hit_mask, viol, hard);
                         if (hard) {                                // static obstacle, or more samples than allowed

@@ -256,7 +256,7 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         const int64_t per_k = (int64_t)D.n_static + (D.dyn_mode != FOT_DYN_NONE ? (int64_t)D.S * D.P : 0);
         if (per_k > 0) {
             if (per_k > (1 << 24)) { err = "too many obstacle points in one instance"; return FOT_ERR_UNSUPPORTED; }
-            D.ent_cap = (int32_t)((per_k + 7) & ~(int64_t)7);
+            D.ent_cap = (int32_t)((per_k + 15) & ~(int64_t)15);          // whole chunk pairs
             D.ent_off = L.n_entries;
             L.n_entries += (int64_t)D.ent_cap * P.n_total;
             L.any_obstacles = true;

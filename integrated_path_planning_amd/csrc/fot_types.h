@@ -71,7 +71,7 @@ struct InstDesc {
     int32_t dyn_mode, S, P, T;
     int64_t dyn_off;                     // points into the caller's dyn_xy
     int64_t ent_off;                     // first broad-phase entry slot of this instance
-    int32_t ent_cap;                     // entry slots per time step (multiple of 8): S*P + n_static rounded up
+    int32_t ent_cap;                     // entry slots per time step (multiple of 16): S*P + n_static rounded up
     int32_t wave0;                       // first wave of this instance
     int32_t n_waves;                     // waves of this instance
     int32_t max_viol;                    // floor(eps*S)

@@ -137,9 +137,9 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         const size_t cap = (size_t)D.ent_cap;
         f2 farq; farq.x = FAR32; farq.y = FAR32;
         d2 infq; infq.x = INFINITY; infq.y = INFINITY;
-        std::vector<f2> e32(cap * P.n_total + 8, farq);
-        std::vector<d2> e64(cap * P.n_total + 8, infq);
-        std::vector<uint8_t> sid(cap * P.n_total + 8, SID_STATIC);
+        std::vector<f2> e32(cap * P.n_total + 16, farq);
+        std::vector<d2> e64(cap * P.n_total + 16, infq);
+        std::vector<uint8_t> sid(cap * P.n_total + 16, SID_STATIC);
         if (D.ent_cap > 0) {
             const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
             for (int k = 0; k < P.n_total; ++k) {
@@ -159,7 +159,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     e64[cap * k + count] = o; sid[cap * k + count] = (uint8_t)sd;
                     ++count;
                 }
-                cnt[k] = (count + ENT_CHUNK - 1) & ~(ENT_CHUNK - 1);
+                cnt[k] = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);
             }
         }
         // --- k_collide + k_select
