@@ -88,7 +88,7 @@ def main():
     def step():
         bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out_dev)
+            dist.all_gather_into_tensor(gathered, out_dev)      # selected-path records of every rank, RCCL over xGMI
 
     def fence():
         if world > 1:
@@ -122,9 +122,17 @@ def main():
     cand_total = int(cand_total.item())
     value = cand_total * args.steps / elapsed
 
+    gathered_ok = None
+    if world > 1:
+        # every rank's slice of the gathered tensor must hold that rank's records
+        g = gathered.cpu().numpy()
+        rb = _abi.RESULT_BYTES
+        mine = g[rank * n_inst * rb:(rank + 1) * n_inst * rb]
+        allrec = (_abi.Result * (world * n_inst)).from_buffer_copy(g.tobytes())
+        gathered_ok = bool(np.array_equal(mine, recs_host) and all(r.n_cand > 0 for r in allrec))
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel (HIP events on its stream, inside the timed region)
@@ -213,10 +221,11 @@ def main():
                                   % (world, _abi.RESULT_BYTES)},
         "roofline": roofline, "roofline_valu": valu, "kernel_ms": kernels,
         "cpu_baseline": cpu, "latency": latency, "host_api": host_api,
-        "parity": {"instances_checked_against_oracle": n_check, "ok": n_check > 0},
+        "parity": {"instances_checked_against_oracle": n_check, "ok": n_check > 0, "all_gather_ok": gathered_ok},
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -111,3 +111,21 @@ def test_lattice_size_matches_reference_counts():
                              max_t=kw.get("max_t", 5.0), d_t_s=kw.get("d_t_s", 5.0 / 3.6),
                              d_road_w=kw.get("d_road_w", 0.5), max_road_width=kw.get("max_road_width", 7.0), moving=moving)
         assert n == len(g["cand_cost"]), name
+
+
+def test_reference_style_spline_object_is_accepted():
+    """The shim reads knots and coefficients off any CubicSpline2D-like object (reference attributes
+    .s list, .sx/.sy with a[n], b[n-1], c[n], d[n-1]; cubic_spline.py:30-45, 201-204)."""
+    from types import SimpleNamespace
+    from integrated_path_planning_amd.planner import spline_arrays
+    g = Golden("curved_a")
+    n = len(g["sp_s"])
+    ref_like = SimpleNamespace(s=g["sp_s"].tolist(),
+                               sx=SimpleNamespace(a=g["sp_ax"], b=g["sp_bx"], c=g["sp_cx"], d=g["sp_dx"]),
+                               sy=SimpleNamespace(a=g["sp_ay"], b=g["sp_by"], c=g["sp_cy"], d=g["sp_dy"]))
+    arrs = spline_arrays(ref_like)
+    assert [len(a) for a in arrs] == [n, n, n - 1, n, n - 1, n, n - 1, n, n - 1]
+    np.testing.assert_array_equal(arrs[3], g["sp_cx"])
+    bad = SimpleNamespace(s=[0.0, 1.0], sx=SimpleNamespace(a=[0, 1], b=[1, 2], c=[0, 0], d=[0]), sy=ref_like.sy)
+    with pytest.raises(ValueError):
+        spline_arrays(bad)

@@ -58,3 +58,25 @@ def test_spline_matches_reference(golden):
     got = bp.path_coeffs()
     for arr, key in zip(got, ["sp_s", "sp_ax", "sp_bx", "sp_cx", "sp_dx", "sp_ay", "sp_by", "sp_cy", "sp_dy"]):
         np.testing.assert_allclose(arr, g[key], rtol=1e-10, atol=1e-11, err_msg=key)
+
+
+def test_golden_case_through_adopted_reference_spline(golden):
+    """reference_path handed over as an object with the reference's attributes (fot_set_path_coeffs):
+    the device spline is then the reference's own coefficients bit for bit."""
+    from types import SimpleNamespace
+    g = golden
+    ref_like = SimpleNamespace(s=g["sp_s"].tolist(),
+                               sx=SimpleNamespace(a=g["sp_ax"], b=g["sp_bx"], c=g["sp_cx"], d=g["sp_dx"]),
+                               sy=SimpleNamespace(a=g["sp_ay"], b=g["sp_by"], c=g["sp_cy"], d=g["sp_dy"]))
+    bp = BatchPlanner(reference_path=ref_like, **g.planner_kwargs())
+    got = bp.path_coeffs()
+    for arr, key in zip(got, ["sp_s", "sp_ax", "sp_bx", "sp_cx", "sp_dx", "sp_ay", "sp_by", "sp_cy", "sp_dy"]):
+        np.testing.assert_array_equal(arr, g[key])
+    res = bp.plan_batch([request_from_golden(g)])
+    r = res.records[0]
+    assert r.best_index == int(g["best_index"])
+    cost, status, keep, nt = bp.candidates(0)
+    np.testing.assert_array_equal(status, g["cand_status"].astype(np.int32))
+    np.testing.assert_allclose(cost, g["cand_cost"], rtol=TIGHT, atol=TIGHT)
+    if r.best_index >= 0:
+        np.testing.assert_allclose(np.array(r.x[: r.n_keep]), g["best_x"], rtol=TIGHT, atol=TIGHT)
