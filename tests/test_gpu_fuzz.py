@@ -1,0 +1,116 @@
+"""Randomised parity: random planner parameters, reference paths, ego states and obstacle sets, GPU vs the oracle.
+
+Every per-candidate status, length and cost must agree, as well as the selected path.  Seeds are fixed; a failure
+message names the seed so the case can be replayed.
+"""
+import numpy as np
+import pytest
+
+from helpers import TIGHT, assert_record_matches_oracle, oracle_plan_for_request
+from integrated_path_planning_amd.batch import PlanRequest
+from integrated_path_planning_amd.footprint import EgoFootprint
+from integrated_path_planning_amd.planner import BatchPlanner
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def random_path(rng):
+    kind = rng.integers(0, 4)
+    if kind == 0:                                   # straight, random heading
+        L, th = rng.uniform(60, 150), rng.uniform(-np.pi, np.pi)
+        t = np.linspace(0, L, rng.integers(2, 16))
+        return t * np.cos(th) + rng.uniform(-50, 50), t * np.sin(th) + rng.uniform(-50, 50)
+    if kind == 1:                                   # arc
+        R, span = rng.uniform(8, 60), rng.uniform(0.5, 2.5)
+        th = np.linspace(0, span, rng.integers(8, 40))
+        sgn = rng.choice([-1.0, 1.0])
+        return R * np.sin(th), sgn * R * (1 - np.cos(th))
+    if kind == 2:                                   # gentle random walk in heading
+        n = rng.integers(6, 25)
+        hd = np.cumsum(rng.normal(0, 0.15, n))
+        step = rng.uniform(4, 12, n)
+        return np.concatenate([[0], np.cumsum(step * np.cos(hd))]), np.concatenate([[0], np.cumsum(step * np.sin(hd))])
+    x = np.linspace(0, rng.uniform(60, 120), rng.integers(8, 30))          # sine lane
+    return x, rng.uniform(0.5, 4) * np.sin(x / rng.uniform(8, 25))
+
+
+def random_planner_kwargs(rng):
+    dt = float(rng.choice([0.1, 0.2, 0.125]))
+    min_t = float(rng.choice([2.0, 3.0, 4.0]))
+    max_t = min_t + float(rng.choice([0.0, 0.5, 1.0]))
+    kw = dict(dt=dt, min_t=min_t, max_t=max_t,
+              max_speed=float(rng.uniform(6, 16)), max_accel=float(rng.uniform(1.5, 8)),
+              max_curvature=float(rng.choice([0.2, 1.0, 10.0])), max_lat_accel=float(rng.uniform(2, 6)),
+              d_road_w=float(rng.choice([0.3, 0.5, 1.0])), max_road_width=float(rng.uniform(1.0, 7.0)),
+              robot_radius=float(rng.uniform(0.5, 2.0)), obstacle_radius=float(rng.uniform(0.1, 0.5)),
+              d_t_s=float(rng.uniform(1.0, 2.5)), k_j=float(rng.choice([0.1, 1.0])), k_t=float(rng.choice([0.1, 1.0])),
+              k_d=float(rng.uniform(0.5, 2)), k_s_dot=float(rng.uniform(0.5, 2)), k_lat=1.0, k_lon=float(rng.uniform(0.5, 1.5)),
+              chance_epsilon=float(rng.choice([0.0, 0.0, 0.1, 0.3])),
+              collision_margin_inflation=float(rng.choice([1.0, 1.2])))
+    if rng.random() < 0.35:
+        kw["footprint"] = EgoFootprint.multi_circle(float(rng.uniform(3.5, 5)), float(rng.uniform(1.6, 2.1)),
+                                                    int(rng.integers(1, 6)))
+    return kw
+
+
+def random_request(rng, sp, kw):
+    s_end = sp.coeffs()[0][-1]
+    s = rng.uniform(0.0, s_end) if rng.random() < 0.9 else rng.uniform(s_end - 3, s_end)
+    x, y, yaw, _, _ = [a[0] for a in sp.eval([s])]
+    off = rng.normal(0, 0.6)
+    ex, ey = x - np.sin(yaw) * off + rng.normal(0, 0.05), y + np.cos(yaw) * off + rng.normal(0, 0.05)
+    v = float(rng.choice([0.0, rng.uniform(0, 1), rng.uniform(1, kw["max_speed"])]))
+    target = float(rng.choice([0.0, rng.uniform(1.0, kw["max_speed"])]))
+    req = PlanRequest(float(ex), float(ey), float(yaw + rng.normal(0, 0.1)), v, float(rng.uniform(-1.5, 1.5)),
+                      target_speed=target, last_kappa=float(rng.normal(0, 0.02)),
+                      prev_s=float(np.clip(s + rng.normal(0, 2.0), 0, s_end)) if rng.random() < 0.5 else None)
+    if rng.random() < 0.3:
+        req.overrides = {k: float(kw[k] * rng.uniform(0.6, 2.0)) for k in ("max_accel", "max_speed", "max_lat_accel")
+                         if rng.random() < 0.6} or None
+    if rng.random() < 0.2:
+        req.max_stop_distance = float(rng.uniform(0.05, 12.0))
+    n_t = int(round(kw["max_t"] / kw["dt"])) + 1
+    ahead = np.stack([a for a in sp.eval(np.clip(s + rng.uniform(0, 45, 64), 0, s_end))[:2]], axis=1)
+    mode = rng.integers(0, 4)
+    if rng.random() < 0.5:
+        pick = ahead[rng.integers(0, 64, rng.integers(1, 40))]
+        req.static = pick + rng.normal(0, 4.0, pick.shape)
+    if mode in (1, 2):
+        P = int(rng.integers(1, 25))
+        T = int(rng.choice([1, n_t // 2, n_t, n_t + 3]))
+        S = 1 if mode == 1 else int(rng.integers(2, 24))
+        p0 = ahead[rng.integers(0, 64, P)] + rng.normal(0, 5.0, (P, 2))
+        vel = rng.normal(0, 1.2, (S, P, 1, 2))
+        t = (np.arange(T) * kw["dt"])[None, None, :, None]
+        traj = p0[None, :, None, :] + vel * t + np.cumsum(rng.normal(0, 0.05, (S, P, T, 2)), axis=2)
+        if mode == 1:
+            req.dyn = traj[0]
+        else:
+            req.dist = traj
+    return req
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration(seed):
+    rng = np.random.default_rng(1000 + seed)
+    wx, wy = random_path(rng)
+    kw = random_planner_kwargs(rng)
+    okw = dict(kw)
+    fp = okw.pop("footprint", None)
+    if fp is not None:
+        okw["footprint_offsets"], okw["footprint_radius"] = list(fp.offsets), fp.radius
+    params, sp = orc.make_params(**okw), orc.Spline(wx, wy)
+    bp = BatchPlanner(waypoints=(wx, wy), **kw)
+    reqs = [random_request(rng, sp, kw) for _ in range(6)]
+    res = bp.plan_batch(reqs)
+    for i, rq in enumerate(reqs):
+        want = oracle_plan_for_request(orc, params, sp, rq, table=True)
+        label = f"seed {seed} inst {i}"
+        cost, status, keep, nt = bp.candidates(i)
+        assert len(cost) == want.n_cand, label
+        np.testing.assert_array_equal(nt, want.cand_nt, err_msg=label)
+        np.testing.assert_array_equal(keep, want.cand_keep, err_msg=label)
+        np.testing.assert_array_equal(status, want.cand_status, err_msg=label)
+        np.testing.assert_allclose(cost, want.cand_cost, rtol=TIGHT, atol=TIGHT, err_msg=label)
+        assert_record_matches_oracle(res.records[i], want, label=label)
