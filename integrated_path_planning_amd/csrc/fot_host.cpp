@@ -53,26 +53,50 @@ struct PinnedBuf {
 
 }  // namespace
 
+// Per-lane workspace.  A large batch is split into FOT_LANES contiguous sub-batches that run on their own
+// streams: the short, latency-bound kernels of one half (nearest-point search, tables, cull, select) overlap
+// with the wide kernels of the other half instead of leaving the GPU idle between them.
+struct Workspace {
+    hipStream_t stream = nullptr;            // internal stream of this lane
+    hipEvent_t staging_done = nullptr;       // the pinned staging buffer may be overwritten after this
+    hipEvent_t done = nullptr;               // this lane's part of the current call has been enqueued up to here
+    bool staging_pending = false;
+    PinnedBuf staging;
+    DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
+    DevBuf dState, dLonInfo, dLonTab;
+    DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dHit, dPts;
+    DevBuf dWaveBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: wave boxes + culled entry lists
+    BatchLayout last;                        // layout of this lane's part of the most recent plan call
+    int first_inst = 0;                      // global index of this lane's first instance
+    void release()
+    {
+        DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dLonTab, &dCost, &dVlast, &dTravel, &dStatus, &dKeep, &dHit,
+                           &dPts, &dWaveBox, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
+        for (DevBuf *b : bufs) b->release();
+        staging.release();
+        if (staging_done) (void)hipEventDestroy(staging_done);
+        if (done) (void)hipEventDestroy(done);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+constexpr int FOT_LANES = 2;
+constexpr int FOT_SPLIT_MIN_INSTANCES = 32;  // smaller batches run as one piece on the caller's stream
+
 struct fot_handle {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t staging_done = nullptr;       // the pinned staging buffer may be overwritten after this
-    bool staging_pending = false;
+    hipStream_t stream = nullptr;            // the handle's own stream (host-pointer entry points, helpers)
+    hipEvent_t fork = nullptr;               // caller's stream -> lanes
     fot_params params;
     DevParams P;
     DevBuf dP;
     HostSpline spline;
     DevBuf dSpline;
     bool has_path = false;
-    // workspace
-    PinnedBuf staging;
-    DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
-    DevBuf dState, dLonInfo, dLonTab;
-    DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dHit, dPts;
-    DevBuf dWaveBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: wave boxes + culled entry lists
+    Workspace ws[FOT_LANES];
+    int lanes_used = 0;                      // lanes of the most recent plan call
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
-    BatchLayout last;                        // layout of the most recent plan call
     bool last_valid = false;
     // profiling: event pairs around kernel launches
     bool prof_on = false;
@@ -120,7 +144,7 @@ int upload_spline(fot_handle *h)
     for (int f = 0; f < 9; ++f)
         std::memcpy(flat.data() + (size_t)f * n, src[f]->data(), sizeof(double) * std::min((size_t)n, src[f]->size()));
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipDeviceSynchronize());                          // nothing may still be reading the old spline
     HIP_TRY(h, h->dSpline.ensure(flat.size() * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->dSpline.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
     h->has_path = true;
@@ -170,104 +194,165 @@ struct ProfScope {
     ~ProfScope() { if (active) (void)hipEventRecord(stop, st); }
 };
 
-// Stage descriptors, size the workspace and enqueue the whole pipeline on `st`.
-// d_static / d_dyn are device pointers to the caller's obstacle coordinates, d_out a device fot_result[n_inst].
-int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
-                 hipStream_t st)
+// Stage descriptors, size the lane's workspace and enqueue the whole pipeline for the sub-batch `b` on `st`.
+// d_static / d_dyn are device pointers to the caller's obstacle coordinates (offsets in b are absolute),
+// d_out the device fot_result slot of the sub-batch's first instance.
+int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_static, const void *d_dyn,
+                 fot_result *d_out, hipStream_t st)
 {
-    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
-    BatchLayout &L = h->last;
-    h->last_valid = false;
+    BatchLayout &L = w.last;
     std::string err;
     int rc = build_batch_layout(h->params, h->P, b, L, err);
     if (rc != FOT_OK) return fail(h, rc, err);
-    if (L.n_inst == 0) { h->last_valid = true; return FOT_OK; }
-    if (!d_out) return fail(h, FOT_ERR_INVALID, "out is NULL");
+    if (L.n_inst == 0) return FOT_OK;
 
-    HIP_TRY(h, hipSetDevice(h->device));
     // --- staging: descriptors + wave maps in one pinned block, one H2D copy
     const size_t desc_bytes = align256(sizeof(InstDesc) * (size_t)L.n_inst);
     const size_t map_bytes = align256(sizeof(int32_t) * (size_t)L.n_waves);
     const size_t meta_bytes = desc_bytes + 2 * map_bytes;
-    if (h->staging_pending) { HIP_TRY(h, hipEventSynchronize(h->staging_done)); h->staging_pending = false; }
-    HIP_TRY(h, h->staging.ensure(meta_bytes));
-    char *stg = (char *)h->staging.p;
+    if (w.staging_pending) { HIP_TRY(h, hipEventSynchronize(w.staging_done)); w.staging_pending = false; }
+    HIP_TRY(h, w.staging.ensure(meta_bytes));
+    char *stg = (char *)w.staging.p;
     std::memcpy(stg, L.desc.data(), sizeof(InstDesc) * (size_t)L.n_inst);
     std::memcpy(stg + desc_bytes, L.wave_inst.data(), sizeof(int32_t) * (size_t)L.n_waves);
     std::memcpy(stg + desc_bytes + map_bytes, L.wave_base.data(), sizeof(int32_t) * (size_t)L.n_waves);
 
     // --- workspace (grow-only; a growing hipFree/hipMalloc synchronises, steady state does not)
     const DevParams &P = h->P;
-    HIP_TRY(h, h->dMeta.ensure(meta_bytes));
-    HIP_TRY(h, h->dState.ensure(sizeof(InstState) * (size_t)L.n_inst));
-    HIP_TRY(h, h->dLonInfo.ensure(sizeof(LonInfo) * (size_t)std::max<int64_t>(L.n_lon, 1)));
-    HIP_TRY(h, h->dLonTab.ensure(sizeof(double) * LON_FIELDS * FOT_MAX_NT * (size_t)std::max<int64_t>(L.n_lon, 1)));
+    HIP_TRY(h, w.dMeta.ensure(meta_bytes));
+    HIP_TRY(h, w.dState.ensure(sizeof(InstState) * (size_t)L.n_inst));
+    HIP_TRY(h, w.dLonInfo.ensure(sizeof(LonInfo) * (size_t)std::max<int64_t>(L.n_lon, 1)));
+    HIP_TRY(h, w.dLonTab.ensure(sizeof(double) * LON_FIELDS * FOT_MAX_NT * (size_t)std::max<int64_t>(L.n_lon, 1)));
     const size_t slots = (size_t)std::max<int64_t>(L.n_slots, 1);
-    HIP_TRY(h, h->dCost.ensure(sizeof(double) * slots));
-    HIP_TRY(h, h->dVlast.ensure(sizeof(double) * slots));
-    HIP_TRY(h, h->dTravel.ensure(sizeof(double) * slots));
-    HIP_TRY(h, h->dStatus.ensure(slots));
-    HIP_TRY(h, h->dKeep.ensure(slots));
-    HIP_TRY(h, h->dHit.ensure(sizeof(unsigned long long) * slots));
-    HIP_TRY(h, h->dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
-    HIP_TRY(h, h->dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
+    HIP_TRY(h, w.dCost.ensure(sizeof(double) * slots));
+    HIP_TRY(h, w.dVlast.ensure(sizeof(double) * slots));
+    HIP_TRY(h, w.dTravel.ensure(sizeof(double) * slots));
+    HIP_TRY(h, w.dStatus.ensure(slots));
+    HIP_TRY(h, w.dKeep.ensure(slots));
+    HIP_TRY(h, w.dHit.ensure(sizeof(unsigned long long) * slots));
+    HIP_TRY(h, w.dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
+    HIP_TRY(h, w.dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
     const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
-    HIP_TRY(h, h->dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
-    HIP_TRY(h, h->dEnt32.ensure(sizeof(f2) * n_ent));
-    HIP_TRY(h, h->dEnt64.ensure(sizeof(d2) * n_ent));
-    HIP_TRY(h, h->dEntSid.ensure(n_ent));
+    HIP_TRY(h, w.dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
+    HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
+    HIP_TRY(h, w.dEnt64.ensure(sizeof(d2) * n_ent));
+    HIP_TRY(h, w.dEntSid.ensure(n_ent));
 
-    HIP_TRY(h, hipMemcpyAsync(h->dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipEventRecord(h->staging_done, st));
-    h->staging_pending = true;
+    HIP_TRY(h, hipMemcpyAsync(w.dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipEventRecord(w.staging_done, st));
+    w.staging_pending = true;
     HIP_TRY(h, hipMemsetAsync(d_out, 0, sizeof(fot_result) * (size_t)L.n_inst, st));
 
-    const InstDesc *d_desc = (const InstDesc *)h->dMeta.p;
-    const int32_t *d_wave_inst = (const int32_t *)((char *)h->dMeta.p + desc_bytes);
-    const int32_t *d_wave_base = (const int32_t *)((char *)h->dMeta.p + desc_bytes + map_bytes);
+    const InstDesc *d_desc = (const InstDesc *)w.dMeta.p;
+    const int32_t *d_wave_inst = (const int32_t *)((char *)w.dMeta.p + desc_bytes);
+    const int32_t *d_wave_base = (const int32_t *)((char *)w.dMeta.p + desc_bytes + map_bytes);
     const DevParams *dP = h->dP.as<DevParams>();
     const SplineView sv = spline_view(h);
     CandArrays ca;
-    ca.cost = h->dCost.as<double>(); ca.v_last = h->dVlast.as<double>(); ca.travel = h->dTravel.as<double>();
-    ca.status = h->dStatus.as<uint8_t>(); ca.keep = h->dKeep.as<uint8_t>();
-    ca.hit = h->dHit.as<unsigned long long>();
+    ca.cost = w.dCost.as<double>(); ca.v_last = w.dVlast.as<double>(); ca.travel = w.dTravel.as<double>();
+    ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
+    ca.hit = w.dHit.as<unsigned long long>();
     if (L.any_obstacles) HIP_TRY(h, hipMemsetAsync(ca.hit, 0, sizeof(unsigned long long) * slots, st));
 
-    if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
     EntryArrays ea;
-    ea.cnt = h->dEntCnt.as<int32_t>(); ea.e32 = h->dEnt32.as<f2>(); ea.e64 = h->dEnt64.as<d2>();
-    ea.sid = h->dEntSid.as<uint8_t>();
+    ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
+    ea.sid = w.dEntSid.as<uint8_t>();
     {
         ProfScope ps(h, 0, st);
-        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, h->dState.as<InstState>(), L.n_inst, st));
+        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, st));
     }
     {
         ProfScope ps(h, 1, st);
-        LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
-                                       h->dLonTab.as<double>(), L.n_inst, L.max_lon, st));
+        LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
+                                       w.dLonTab.as<double>(), L.n_inst, L.max_lon, st));
     }
     {
         ProfScope ps(h, 2, st);
-        LAUNCH_TRY(h, launch_evaluate(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
-                                      h->dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
-                                      h->dPts.as<d2>(), h->dWaveBox.as<float>(), st));
+        LAUNCH_TRY(h, launch_evaluate(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
+                                      w.dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
+                                      w.dPts.as<d2>(), w.dWaveBox.as<float>(), st));
     }
     if (L.any_obstacles) {
         {
             ProfScope ps(h, 3, st);
-            LAUNCH_TRY(h, launch_cull(dP, d_desc, L.n_inst, P.n_total, h->dWaveBox.as<float>(), d_static, d_dyn,
+            LAUNCH_TRY(h, launch_cull(dP, d_desc, L.n_inst, P.n_total, w.dWaveBox.as<float>(), d_static, d_dyn,
                                       b.obstacle_dtype, ea, st));
         }
         ProfScope ps(h, 4, st);
-        LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, ea, h->dPts.as<d2>(), ca, st));
+        LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, ea, w.dPts.as<d2>(), ca, st));
     }
     {
         ProfScope ps(h, 5, st);
-        LAUNCH_TRY(h, launch_select(dP, d_desc, h->dState.as<InstState>(), h->dLonInfo.as<LonInfo>(),
-                                    h->dLonTab.as<double>(), ca, d_out, L.n_inst, st));
+        LAUNCH_TRY(h, launch_select(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
+                                    w.dLonTab.as<double>(), ca, d_out, L.n_inst, st));
     }
+    return FOT_OK;
+}
+
+// sub-batch [i0, i0+n) of b: per-instance arrays shifted, obstacle offsets stay absolute
+fot_batch sub_batch(const fot_batch &b, int i0, int n)
+{
+    fot_batch s = b;
+    s.n_inst = n;
+    s.ego = b.ego + i0;
+    s.target_speed = b.target_speed + i0;
+    s.overrides = b.overrides ? b.overrides + i0 : nullptr;
+    s.max_stop_distance = b.max_stop_distance ? b.max_stop_distance + i0 : nullptr;
+    s.static_off = b.static_off ? b.static_off + i0 : nullptr;
+    s.dyn_off = b.dyn_off ? b.dyn_off + i0 : nullptr;
+    s.dyn_dims = b.dyn_dims ? b.dyn_dims + 4 * (size_t)i0 : nullptr;
+    return s;
+}
+
+// Enqueue one plan call behind everything already on `user`; small batches run on `user` itself, large ones
+// fork into the lanes' streams and join `user` again.
+int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
+                 hipStream_t user)
+{
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    h->last_valid = false;
+    if (b.n_inst < 0) return fail(h, FOT_ERR_INVALID, "n_inst < 0");
+    if (b.n_inst == 0) { h->lanes_used = 0; h->last_valid = true; return FOT_OK; }
+    if (!d_out) return fail(h, FOT_ERR_INVALID, "out is NULL");
+    if (!b.ego || !b.target_speed) return fail(h, FOT_ERR_INVALID, "ego / target_speed missing");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
+
+    if (b.n_inst < FOT_SPLIT_MIN_INSTANCES) {
+        h->ws[0].first_inst = 0;
+        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user);
+        if (rc != FOT_OK) return rc;
+        h->lanes_used = 1;
+        h->last_valid = true;
+        return FOT_OK;
+    }
+    HIP_TRY(h, hipEventRecord(h->fork, user));
+    int i0 = 0;
+    for (int l = 0; l < FOT_LANES; ++l) {
+        Workspace &w = h->ws[l];
+        const int n = b.n_inst / FOT_LANES + (l < b.n_inst % FOT_LANES ? 1 : 0);
+        HIP_TRY(h, hipStreamWaitEvent(w.stream, h->fork, 0));
+        w.first_inst = i0;
+        int rc = enqueue_lane(h, w, sub_batch(b, i0, n), d_static, d_dyn, d_out + i0, w.stream);
+        if (rc != FOT_OK) return rc;
+        HIP_TRY(h, hipEventRecord(w.done, w.stream));
+        HIP_TRY(h, hipStreamWaitEvent(user, w.done, 0));
+        i0 += n;
+    }
+    h->lanes_used = FOT_LANES;
     h->last_valid = true;
     return FOT_OK;
+}
+
+// lane and local index of global instance `inst` of the most recent plan call
+Workspace *lane_of(fot_handle *h, int inst, int *local)
+{
+    for (int l = h->lanes_used - 1; l >= 0; --l)
+        if (inst >= h->ws[l].first_inst && inst < h->ws[l].first_inst + h->ws[l].last.n_inst) {
+            *local = inst - h->ws[l].first_inst;
+            return &h->ws[l];
+        }
+    return nullptr;
 }
 
 }  // namespace
@@ -304,7 +389,12 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    if ((e = hipEventCreateWithFlags(&h->staging_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&h->fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (Workspace &w : h->ws) {
+        if ((e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+        if ((e = hipEventCreateWithFlags(&w.staging_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
     if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemcpy(h->dP.p, &h->P, sizeof(DevParams), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
     *out = h;
@@ -316,13 +406,12 @@ void fot_destroy(fot_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dMeta, &h->dState, &h->dLonInfo, &h->dLonTab, &h->dCost, &h->dVlast,
-                       &h->dTravel, &h->dStatus, &h->dKeep, &h->dHit, &h->dPts, &h->dWaveBox, &h->dEntCnt, &h->dEnt32, &h->dEnt64, &h->dEntSid, &h->dUserStatic,
-                       &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
+    for (Workspace &w : h->ws) if (w.stream) (void)hipStreamSynchronize(w.stream);
+    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
-    h->staging.release();
+    for (Workspace &w : h->ws) w.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
-    if (h->staging_done) (void)hipEventDestroy(h->staging_done);
+    if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -494,20 +583,21 @@ int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
 {
     if (!h) return FOT_ERR_INVALID;
     if (!h->last_valid) return fail(h, FOT_ERR_INVALID, "no completed plan call on this handle");
-    const BatchLayout &L = h->last;
-    if (inst < 0 || inst >= L.n_inst) return fail(h, FOT_ERR_INVALID, "instance index out of range");
+    int local = 0;
+    Workspace *w = lane_of(h, inst, &local);
+    if (!w) return fail(h, FOT_ERR_INVALID, "instance index out of range");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const InstDesc &D = L.desc[inst];
+    HIP_TRY(h, hipDeviceSynchronize());                          // diagnostic entry: whatever stream the plan ran on
+    const InstDesc &D = w->last.desc[local];
     InstState S;
-    HIP_TRY(h, hipMemcpy(&S, h->dState.as<InstState>() + inst, sizeof(InstState), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(&S, w->dState.as<InstState>() + local, sizeof(InstState), hipMemcpyDeviceToHost));
     const int n = S.n_cand;
     const int m = n < cap ? n : cap;
     if (m <= 0) return n;
     std::vector<uint8_t> st8((size_t)m), kp8((size_t)m);
-    if (cost) HIP_TRY(h, hipMemcpy(cost, h->dCost.as<double>() + D.cand_off, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(st8.data(), h->dStatus.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(kp8.data(), h->dKeep.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
+    if (cost) HIP_TRY(h, hipMemcpy(cost, w->dCost.as<double>() + D.cand_off, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(st8.data(), w->dStatus.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(kp8.data(), w->dKeep.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
     for (int i = 0; i < m; ++i) {
         if (status) status[i] = st8[i];
         if (keep) keep[i] = kp8[i];
@@ -523,16 +613,17 @@ int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double 
 {
     if (!h) return FOT_ERR_INVALID;
     if (!h->last_valid) return fail(h, FOT_ERR_INVALID, "no completed plan call on this handle");
-    const BatchLayout &L = h->last;
-    if (inst < 0 || inst >= L.n_inst) return fail(h, FOT_ERR_INVALID, "instance index out of range");
+    int local = 0;
+    Workspace *w = lane_of(h, inst, &local);
+    if (!w) return fail(h, FOT_ERR_INVALID, "instance index out of range");
     if (!arrays) return fail(h, FOT_ERR_INVALID, "arrays is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, h->dTmpA.ensure(sizeof(double) * 15 * FOT_MAX_NT));
     HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * 2));
     HIP_TRY(h, hipMemsetAsync(h->dTmpA.p, 0, sizeof(double) * 15 * FOT_MAX_NT, h->stream));
-    LAUNCH_TRY(h, launch_debug_path(h->dP.as<DevParams>(), (const InstDesc *)h->dMeta.p, h->dState.as<InstState>(),
-                                    h->dLonInfo.as<LonInfo>(), h->dLonTab.as<double>(), inst, index,
+    LAUNCH_TRY(h, launch_debug_path(h->dP.as<DevParams>(), (const InstDesc *)w->dMeta.p, w->dState.as<InstState>(),
+                                    w->dLonInfo.as<LonInfo>(), w->dLonTab.as<double>(), local, index,
                                     h->dTmpA.as<double>(), h->dTmpD.as<int32_t>(), h->stream));
     int32_t meta[2] = { 0, 0 };
     HIP_TRY(h, hipMemcpyAsync(arrays, h->dTmpA.p, sizeof(double) * 15 * FOT_MAX_NT, hipMemcpyDeviceToHost, h->stream));

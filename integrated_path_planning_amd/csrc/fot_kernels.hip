@@ -47,6 +47,34 @@ __device__ __forceinline__ float dpp_f32(float v)
 FOT_WAVE_REDUCE_F32(wave_min_f32, fminf)
 FOT_WAVE_REDUCE_F32(wave_max_f32, fmaxf)
 
+// The four box reductions of one time step as fused DPP instructions (v_min/v_max with a DPP source: one
+// instruction per butterfly step instead of v_mov_dpp + v_min).  The four chains are interleaved, so every DPP
+// read of a register is at least three VALU instructions behind its write (the DPP read-after-VALU-write
+// hazard needs two wait states and is not handled for inline asm); the leading s_nop covers the first group.
+// Masked rows of the row_bcast steps keep their value (destination tied to the source).  Lane 63 of each
+// result holds the reduction, which v_readlane returns to every lane.
+__device__ __forceinline__ void wave_reduce_box(float &x0, float &y0, float &x1, float &y1)
+{
+#define FOT_BOX_STEP(CTRL)                                                     \
+    asm volatile("s_nop 1\n\t"                                                 \
+                 "v_min_f32_dpp %0, %0, %0 " CTRL "\n\t"                        \
+                 "v_min_f32_dpp %1, %1, %1 " CTRL "\n\t"                        \
+                 "v_max_f32_dpp %2, %2, %2 " CTRL "\n\t"                        \
+                 "v_max_f32_dpp %3, %3, %3 " CTRL                                \
+                 : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1))
+    FOT_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    FOT_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    FOT_BOX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf");
+    FOT_BOX_STEP("row_mirror row_mask:0xf bank_mask:0xf");
+    FOT_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    FOT_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef FOT_BOX_STEP
+    x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0), 63));
+    y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y0), 63));
+    x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), 63));
+    y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), 63));
+}
+
 // ---------------------------------------------------------------------------
 // ego -> Frenet state
 // ---------------------------------------------------------------------------
@@ -189,8 +217,8 @@ struct ScratchSink {
     // every lane of the wave arrives here once per time step
     __device__ __forceinline__ void row_done(int k)
     {
-        const float x0 = wave_min_f32(cur.x0), y0 = wave_min_f32(cur.y0);
-        const float x1 = wave_max_f32(cur.x1), y1 = wave_max_f32(cur.y1);
+        float x0 = cur.x0, y0 = cur.y0, x1 = cur.x1, y1 = cur.y1;
+        wave_reduce_box(x0, y0, x1, y1);
         if (lane == 0) {
             float4 w; w.x = x0; w.y = y0; w.z = x1; w.w = y1;
             *(float4 *)(wbox + 4 * k) = w;
