@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -80,7 +81,7 @@ struct Workspace {
     }
 };
 
-constexpr int FOT_LANES = 2;
+constexpr int FOT_LANES = 4;                  // lanes available; lanes_cfg of them are used (FOT_LANES env, default 2)
 constexpr int FOT_SPLIT_MIN_INSTANCES = 32;  // smaller batches run as one piece on the caller's stream
 
 struct fot_handle {
@@ -94,6 +95,7 @@ struct fot_handle {
     DevBuf dSpline;
     bool has_path = false;
     Workspace ws[FOT_LANES];
+    int lanes_cfg = 2;                       // sub-batches a large batch is split into
     int lanes_used = 0;                      // lanes of the most recent plan call
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
@@ -241,7 +243,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, hipMemcpyAsync(w.dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipEventRecord(w.staging_done, st));
     w.staging_pending = true;
-    HIP_TRY(h, hipMemsetAsync(d_out, 0, sizeof(fot_result) * (size_t)L.n_inst, st));
 
     const InstDesc *d_desc = (const InstDesc *)w.dMeta.p;
     const int32_t *d_wave_inst = (const int32_t *)((char *)w.dMeta.p + desc_bytes);
@@ -252,7 +253,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     ca.cost = w.dCost.as<double>(); ca.v_last = w.dVlast.as<double>(); ca.travel = w.dTravel.as<double>();
     ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
     ca.hit = w.dHit.as<unsigned long long>();
-    if (L.any_obstacles) HIP_TRY(h, hipMemsetAsync(ca.hit, 0, sizeof(unsigned long long) * slots, st));
 
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
@@ -318,7 +318,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
 
-    if (b.n_inst < FOT_SPLIT_MIN_INSTANCES) {
+    if (b.n_inst < FOT_SPLIT_MIN_INSTANCES * h->lanes_cfg / 2 || h->lanes_cfg <= 1) {
         h->ws[0].first_inst = 0;
         int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user);
         if (rc != FOT_OK) return rc;
@@ -328,9 +328,10 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     }
     HIP_TRY(h, hipEventRecord(h->fork, user));
     int i0 = 0;
-    for (int l = 0; l < FOT_LANES; ++l) {
+    const int lanes = h->lanes_cfg;
+    for (int l = 0; l < lanes; ++l) {
         Workspace &w = h->ws[l];
-        const int n = b.n_inst / FOT_LANES + (l < b.n_inst % FOT_LANES ? 1 : 0);
+        const int n = b.n_inst / lanes + (l < b.n_inst % lanes ? 1 : 0);
         HIP_TRY(h, hipStreamWaitEvent(w.stream, h->fork, 0));
         w.first_inst = i0;
         int rc = enqueue_lane(h, w, sub_batch(b, i0, n), d_static, d_dyn, d_out + i0, w.stream);
@@ -339,7 +340,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
         HIP_TRY(h, hipStreamWaitEvent(user, w.done, 0));
         i0 += n;
     }
-    h->lanes_used = FOT_LANES;
+    h->lanes_used = lanes;
     h->last_valid = true;
     return FOT_OK;
 }
@@ -380,6 +381,10 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     fot_handle *h = new (std::nothrow) fot_handle();
     if (!h) return fail(nullptr, FOT_ERR_HIP, "out of host memory");
     h->device = device;
+    if (const char *ev = std::getenv("FOT_LANES")) {             // tuning knob: 1 disables the split
+        const int v = std::atoi(ev);
+        if (v >= 1 && v <= FOT_LANES) h->lanes_cfg = v;
+    }
     h->params = *params;
     h->P = P;
     auto bail = [&](hipError_t ee, const char *what) {

@@ -243,8 +243,8 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
            const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
            const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
-           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep, d2 *__restrict__ pts,
-           float *__restrict__ wave_box)
+           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep,
+           unsigned long long *__restrict__ cand_hit, d2 *__restrict__ pts, float *__restrict__ wave_box)
 {
     // wave index through readfirstlane: everything derived from it (instance, descriptor) is wave-uniform -> SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
@@ -257,6 +257,7 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int idx = wave_base[wave] + lane;                    // candidate index inside the instance
     const int64_t slot = (int64_t)D.cand_off + idx;
     float *wbox = wave_box + (int64_t)wave * P.n_total * 4;
+    cand_hit[slot] = 0;                                        // k_collide ORs the colliding prediction samples in
     const bool live = S.c2f_ok && idx < S.n_cand;
     if (!__any(live)) {                                        // whole wave idle: empty boxes, padding status
         for (int k = lane; k < P.n_total; k += WAVE) {
@@ -546,6 +547,10 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
     const InstState &S = state[inst];
     const int lane = threadIdx.x;
     fot_result &R = out[inst];
+    // the record starts out all zero (stores of one wave to one address retire in program order, so the
+    // fields written below win)
+    for (int i = lane; i < (int)(sizeof(fot_result) / sizeof(unsigned long long)); i += WAVE)
+        ((unsigned long long *)&R)[i] = 0ull;
 
     if (!S.c2f_ok) {
         if (lane == 0) {
@@ -751,8 +756,8 @@ int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *s
     if (n_waves <= 0) return 0;
     const int wpb = 256 / WAVE;
     k_evaluate<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, state, lon_info, lon_tab, wave_inst, wave_base,
-                                                         n_waves, c.cost, c.v_last, c.travel, c.status, c.keep, pts,
-                                                         wave_box);
+                                                         n_waves, c.cost, c.v_last, c.travel, c.status, c.keep, c.hit,
+                                                         pts, wave_box);
     FOT_LAUNCH_CHECK();
     return 0;
 }

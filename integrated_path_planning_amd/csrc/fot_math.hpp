@@ -14,6 +14,37 @@
 namespace fot {
 
 // ---------------------------------------------------------------------------
+// reciprocal and reciprocal square root: hardware seed + two Newton steps on the device (no scaling /
+// fix-up sequence: denormal and overflow inputs do not occur here; 0, inf and NaN still propagate to
+// non-finite results, which is all the callers rely on), plain IEEE expressions on the host
+// ---------------------------------------------------------------------------
+
+FOT_HD double fast_rcp(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double x = __builtin_amdgcn_rcp(a);
+    x = fma(x, fma(-a, x, 1.0), x);
+    x = fma(x, fma(-a, x, 1.0), x);
+    return x;
+#else
+    return 1.0 / a;
+#endif
+}
+
+FOT_HD double fast_rsqrt(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+#else
+    return 1.0 / sqrt(a);
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // cubic spline (reference: src/planning/cubic_spline.py:47-166, 215-288)
 // ---------------------------------------------------------------------------
 
@@ -228,11 +259,11 @@ FOT_HD void lon_eval(const LonInfo &L, double t, double &s, double &sd, double &
 
 FOT_HD void lat_eval(const double *q, double t, double &d, double &dd, double &ddd, double &dddd)
 {
-    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, t5 = t4 * t;
-    d = q[0] + q[1] * t + q[2] * t2 + q[3] * t3 + q[4] * t4 + q[5] * t5;
-    dd = q[1] + 2.0 * q[2] * t + 3.0 * q[3] * t2 + 4.0 * q[4] * t3 + 5.0 * q[5] * t4;
-    ddd = 2.0 * q[2] + 6.0 * q[3] * t + 12.0 * q[4] * t2 + 20.0 * q[5] * t3;
-    dddd = 6.0 * q[3] + 24.0 * q[4] * t + 60.0 * q[5] * t2;
+    // Horner form of the quintic and its three derivatives (:688-691)
+    d = q[0] + t * (q[1] + t * (q[2] + t * (q[3] + t * (q[4] + t * q[5]))));
+    dd = q[1] + t * (2.0 * q[2] + t * (3.0 * q[3] + t * (4.0 * q[4] + t * (5.0 * q[5]))));
+    ddd = 2.0 * q[2] + t * (6.0 * q[3] + t * (12.0 * q[4] + t * (20.0 * q[5])));
+    dddd = 6.0 * q[3] + t * (24.0 * q[4] + t * (60.0 * q[5]));
 }
 
 // longitudinal state of sample k of a profile, brake padding included (:483-500)
@@ -269,9 +300,9 @@ FOT_HD void frenet_to_cart(const LonSample &L, double d, double d_d, double d_dd
     const double dp = d_d * L.inv_sd;
     const double dpp = (d_dd - dp * L.sdd) * (L.inv_sd * L.inv_sd);
     const double omkd = 1.0 - L.kr * d;
-    const double inv_om = 1.0 / omkd;
+    const double inv_om = fast_rcp(omkd);
     const double hh = dp * dp + omkd * omkd;
-    const double inv_h = 1.0 / sqrt(hh);
+    const double inv_h = fast_rsqrt(hh);
     const double h = hh * inv_h;
     const double cos_d = omkd * inv_h, sin_d = dp * inv_h;
     const double tan_d = dp * inv_om;
