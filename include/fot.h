@@ -205,6 +205,32 @@ int fot_check_paths(fot_handle *h, int32_t n_paths, const int32_t *len, const in
                     int32_t n_static, const double *static_xy,
                     int32_t mode, int32_t S, int32_t P, int32_t T, const double *dyn, int32_t *status_out);
 
+/* ---- the obstacle-tensor producer in front of the planner ------------------------------
+ * TrajectoryPredictor.process_prediction (trajectory_predictor.py:233-313) for S prediction samples, fused
+ * with the current-position prepend of IntegratedSimulator._update_prediction (integrated_simulator.py:503-525):
+ * raw Social-GAN predictions (0.4 s grid, anchored at the last observation) -> the planner's [S][P][T][2]
+ * obstacle tensor on the dt grid, written where fot_plan_batch_device reads it (no host round trip).
+ *   pred    [S][pred_len][P][2] (pred_dtype), host or device memory according to on_device
+ *   anchor  [P][2] host, or NULL (no anchor point);  current [P][2] host, or NULL (no prepend)
+ *   out     [S][P][T][2] (out_dtype), same memory space as pred; *T_out = n_dense (+1 with current)
+ *   sample_dist [S] host or NULL: sum over (p, k) of |sample - sample mean|, whose first minimum is
+ *               predict_single_best's representative sample (:346-351); requesting it synchronises
+ * pred_len <= FOT_MAX_PRED_LEN, T <= FOT_MAX_NT.  stream: NULL = the handle's stream. */
+#define FOT_MAX_PRED_LEN 32
+typedef struct fot_resample_params {
+    double sgan_dt, sim_dt, plan_horizon;
+} fot_resample_params;
+int fot_resample_n_dense(const fot_resample_params *rp, int32_t pred_len);
+int fot_resample_predictions(fot_handle *h, const fot_resample_params *rp, int32_t S, int32_t pred_len, int32_t P,
+                             const void *pred, int32_t pred_dtype, const double *anchor, const double *current,
+                             double staleness, void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out,
+                             double *sample_dist, void *stream);
+/* TrajectoryPredictor.predict_cv (:188-231): obs_last / obs_prev [P][2] host (obs_prev NULL = zero velocity)
+ * -> out [P][T][2] with the same prepend / memory-space conventions */
+int fot_predict_cv(fot_handle *h, const fot_resample_params *rp, int32_t pred_len, int32_t P,
+                   const double *obs_last, const double *obs_prev, const double *current, double staleness,
+                   void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream);
+
 /* ---- measurement (no reference counterpart: the reference times plan() with perf_counter,
  *      integrated_simulator.py:575-585) ----
  * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "fot_kernels.h"
+#include "fot_math.hpp"
 #include "fot_setup.hpp"
 
 using namespace fot;
@@ -492,6 +493,88 @@ int fot_plan_batch_device(fot_handle *h, const fot_batch *batch, fot_result *out
     if (!batch) return fail(h, FOT_ERR_INVALID, "batch is NULL");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     return enqueue_plan(h, *batch, batch->static_xy, batch->dyn_xy, out_dev, st);
+}
+
+int fot_resample_n_dense(const fot_resample_params *rp, int32_t pred_len)
+{
+    if (!rp || !(rp->sim_dt > 0.0) || !(rp->sgan_dt > 0.0) || pred_len < 1) return FOT_ERR_INVALID;
+    return resample_n_dense(rp->sgan_dt, rp->sim_dt, rp->plan_horizon, pred_len);
+}
+
+namespace {
+
+// shared body of fot_resample_predictions (cv = 0) and fot_predict_cv (cv = 1: anchor = obs_last, pred = obs_prev)
+int resample_common(fot_handle *h, const fot_resample_params *rp, int cv, int32_t S, int32_t pred_len, int32_t P,
+                    const void *pred, int32_t pred_dtype, const double *anchor, const double *current,
+                    double staleness, void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out,
+                    double *sample_dist, void *stream)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!rp || !(rp->sim_dt > 0.0) || !(rp->sgan_dt > 0.0)) return fail(h, FOT_ERR_INVALID, "sgan_dt and sim_dt must be positive");
+    if (S < 0 || P < 0 || pred_len < 1) return fail(h, FOT_ERR_INVALID, "bad S / P / pred_len");
+    if (pred_len > FOT_MAX_PRED_LEN) return fail(h, FOT_ERR_UNSUPPORTED, "pred_len > FOT_MAX_PRED_LEN");
+    if ((pred_dtype != FOT_F32 && pred_dtype != FOT_F64) || (out_dtype != FOT_F32 && out_dtype != FOT_F64))
+        return fail(h, FOT_ERR_INVALID, "dtype");
+    const int n_dense = resample_n_dense(rp->sgan_dt, rp->sim_dt, rp->plan_horizon, pred_len);
+    const int T = n_dense + (current ? 1 : 0);
+    if (T > FOT_MAX_NT) return fail(h, FOT_ERR_UNSUPPORTED, "more than FOT_MAX_NT time steps");
+    if (T_out) *T_out = T;
+    if (S == 0 || P == 0 || T == 0) return FOT_OK;
+    if (!out || (!cv && !pred) || (cv && !anchor)) return fail(h, FOT_ERR_INVALID, "NULL tensor");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    // small per-pedestrian inputs: anchor | current  (and obs_prev for cv) through the handle's scratch
+    const size_t row = sizeof(double) * 2 * (size_t)P;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, h->dTmpA.ensure(3 * row + 64));
+    char *scr = (char *)h->dTmpA.p;
+    const double *d_anchor = nullptr, *d_current = nullptr;
+    const void *d_pred = pred;
+    if (anchor) { HIP_TRY(h, hipMemcpyAsync(scr, anchor, row, hipMemcpyHostToDevice, st)); d_anchor = (const double *)scr; }
+    if (current) { HIP_TRY(h, hipMemcpyAsync(scr + row, current, row, hipMemcpyHostToDevice, st)); d_current = (const double *)(scr + row); }
+    void *d_out = out;
+    const size_t in_elem = pred_dtype == FOT_F32 ? 4 : 8, out_elem = out_dtype == FOT_F32 ? 4 : 8;
+    const size_t in_bytes = in_elem * 2 * (size_t)P * (cv ? 1 : (size_t)S * pred_len);
+    const size_t out_bytes = out_elem * 2 * (size_t)S * P * T;
+    if (cv) {                                                      // obs_prev is a host array of doubles
+        d_pred = nullptr;
+        if (pred) { HIP_TRY(h, hipMemcpyAsync(scr + 2 * row, pred, row, hipMemcpyHostToDevice, st)); d_pred = scr + 2 * row; }
+    } else if (!on_device) {
+        HIP_TRY(h, h->dTmpB.ensure(in_bytes));
+        HIP_TRY(h, hipMemcpyAsync(h->dTmpB.p, pred, in_bytes, hipMemcpyHostToDevice, st));
+        d_pred = h->dTmpB.p;
+    }
+    if (!on_device) { HIP_TRY(h, h->dTmpC.ensure(out_bytes)); d_out = h->dTmpC.p; }
+    LAUNCH_TRY(h, launch_resample(rp->sgan_dt, rp->sim_dt, staleness, S, pred_len, P, n_dense, anchor ? 1 : 0,
+                                  current ? 1 : 0, cv, d_pred, cv ? FOT_F64 : pred_dtype, d_anchor, d_current, d_out,
+                                  out_dtype, st));
+    if (sample_dist) {
+        HIP_TRY(h, h->dTmpD.ensure(sizeof(double) * (size_t)S));
+        LAUNCH_TRY(h, launch_sample_dist(S, P, T, current ? 1 : 0, d_out, out_dtype, h->dTmpD.as<double>(), st));
+        HIP_TRY(h, hipMemcpyAsync(sample_dist, h->dTmpD.p, sizeof(double) * (size_t)S, hipMemcpyDeviceToHost, st));
+    }
+    if (!on_device) HIP_TRY(h, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    if (!on_device || sample_dist) HIP_TRY(h, hipStreamSynchronize(st));
+    return FOT_OK;
+}
+
+}  // namespace
+
+int fot_resample_predictions(fot_handle *h, const fot_resample_params *rp, int32_t S, int32_t pred_len, int32_t P,
+                             const void *pred, int32_t pred_dtype, const double *anchor, const double *current,
+                             double staleness, void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out,
+                             double *sample_dist, void *stream)
+{
+    return resample_common(h, rp, 0, S, pred_len, P, pred, pred_dtype, anchor, current, staleness, out, out_dtype,
+                           on_device, T_out, sample_dist, stream);
+}
+
+int fot_predict_cv(fot_handle *h, const fot_resample_params *rp, int32_t pred_len, int32_t P,
+                   const double *obs_last, const double *obs_prev, const double *current, double staleness,
+                   void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream)
+{
+    return resample_common(h, rp, 1, 1, pred_len, P, obs_prev, FOT_F64, obs_last, current, staleness, out, out_dtype,
+                           on_device, T_out, nullptr, stream);
 }
 
 int fot_profile_enable(fot_handle *h, int on)

@@ -38,6 +38,10 @@ int launch_select(const DevParams *P, const InstDesc *desc, const InstState *sta
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                       const double *lon_tab, int inst, int idx, double *out, int32_t *meta, hipStream_t st);
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
+int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
+                    int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
+                    const double *current, void *out, int out_dtype, hipStream_t st);
+int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, double *dist, hipStream_t st);
 int launch_check_ext(const DevParams *P, const InstDesc *desc, int n_paths, int mode, const int32_t *len,
                      const int32_t *flags, const double *arrays, const double *static_xy, const double *dyn_xy,
                      int32_t *status_out, hipStream_t st);

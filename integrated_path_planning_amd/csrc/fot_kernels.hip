@@ -725,6 +725,81 @@ __global__ void k_check_ext(const DevParams *__restrict__ Pp, const InstDesc *__
 }
 
 // ---------------------------------------------------------------------------
+// prediction resampling -> obstacle tensor
+// ---------------------------------------------------------------------------
+
+struct ResampleArgs {
+    double sgan_dt, sim_dt, staleness;
+    int S, pred_len, P, n_dense, T;          // T = n_dense + prepend
+    int has_anchor, prepend, cv;             // cv: sources are (obs_prev, obs_last) -> constant velocity
+};
+
+// one thread per (sample, pedestrian, axis); out[s][p][k][axis]
+template <typename TI, typename TO>
+__global__ void k_resample(ResampleArgs A, const TI *__restrict__ pred, const double *__restrict__ anchor,
+                           const double *__restrict__ current, TO *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= A.S * A.P * 2) return;
+    const int ax = idx & 1, sp = idx >> 1, p = sp % A.P, smp = sp / A.P;
+    TO *dst = out + ((int64_t)sp * A.T) * 2 + ax;
+    if (A.prepend) dst[0] = (TO)current[2 * p + ax];
+    dst += 2 * A.prepend;
+    if (A.cv) {                                                     // predict_cv (:188-231)
+        const double cur = anchor[2 * p + ax];                      // obs_last
+        const double vel = pred ? (cur - (double)pred[2 * p + ax]) / A.sgan_dt : 0.0;   // obs_prev
+        for (int i = 0; i < A.n_dense; ++i) {
+            const double t = (A.sim_dt + (double)i * A.sim_dt) + A.staleness;
+            dst[2 * i] = (TO)(cur + vel * t);
+        }
+        return;
+    }
+    ResampleAxis R;
+    R.sgan_dt = A.sgan_dt; R.staleness = A.staleness;
+    R.first_k = A.has_anchor ? 0 : 1;
+    int n = 0;
+    if (A.has_anchor) R.co[n++] = anchor[2 * p + ax];
+    for (int k = 0; k < A.pred_len; ++k) R.co[n++] = (double)pred[(((int64_t)smp * A.pred_len + k) * A.P + p) * 2 + ax];
+    R.n_src = n;
+    const bool constant = R.all_close(R.co[0]) || R.all_close(0.0);
+    const double v_tail = R.tail_velocity();
+    for (int i = 0; i < A.n_dense; ++i)
+        dst[2 * i] = (TO)R.at(A.sim_dt + (double)i * A.sim_dt, constant, v_tail);
+}
+
+// block = sample: sum over (p, k) of the distance to the sample mean (predict_single_best :346-350)
+template <typename TO>
+__global__ void __launch_bounds__(256)
+k_sample_dist(int S, int P, int T, int skip, const TO *__restrict__ out, double *__restrict__ dist)
+{
+    const int smp = blockIdx.x;
+    const int n = P * (T - skip);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int p = i / (T - skip), k = i - p * (T - skip) + skip;  // the prepended current position is not part of it
+        double mx = 0.0, my = 0.0;
+        for (int q = 0; q < S; ++q) {
+            const TO *e = out + (((int64_t)q * P + p) * T + k) * 2;
+            mx += (double)e[0]; my += (double)e[1];
+        }
+        mx /= (double)S; my /= (double)S;
+        const TO *e = out + (((int64_t)smp * P + p) * T + k) * 2;
+        const double dx = (double)e[0] - mx, dy = (double)e[1] - my;
+        acc += sqrt(dx * dx + dy * dy);
+    }
+    __shared__ double part[256 / WAVE];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x / WAVE); ++w) t += part[w];
+        dist[smp] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 
@@ -823,6 +898,38 @@ int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipSt
 {
     if (n <= 0) return 0;
     k_spline_eval<<<(n + 255) / 256, 256, 0, st>>>(sp, n, s, out);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
+                    int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
+                    const double *current, void *out, int out_dtype, hipStream_t st)
+{
+    const int total = S * P * 2;
+    if (total <= 0) return 0;
+    ResampleArgs A;
+    A.sgan_dt = sgan_dt; A.sim_dt = sim_dt; A.staleness = staleness;
+    A.S = S; A.pred_len = pred_len; A.P = P; A.n_dense = n_dense; A.T = n_dense + (prepend ? 1 : 0);
+    A.has_anchor = has_anchor; A.prepend = prepend; A.cv = cv;
+    const int bs = 128, grid = (total + bs - 1) / bs;
+    if (pred_dtype == FOT_F32 && out_dtype == FOT_F32)
+        k_resample<float, float><<<grid, bs, 0, st>>>(A, (const float *)pred, anchor, current, (float *)out);
+    else if (pred_dtype == FOT_F32)
+        k_resample<float, double><<<grid, bs, 0, st>>>(A, (const float *)pred, anchor, current, (double *)out);
+    else if (out_dtype == FOT_F32)
+        k_resample<double, float><<<grid, bs, 0, st>>>(A, (const double *)pred, anchor, current, (float *)out);
+    else
+        k_resample<double, double><<<grid, bs, 0, st>>>(A, (const double *)pred, anchor, current, (double *)out);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, double *dist, hipStream_t st)
+{
+    if (S <= 0) return 0;
+    if (out_dtype == FOT_F32) k_sample_dist<float><<<S, 256, 0, st>>>(S, P, T, skip, (const float *)out, dist);
+    else k_sample_dist<double><<<S, 256, 0, st>>>(S, P, T, skip, (const double *)out, dist);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -733,4 +733,53 @@ FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const double *lon
     o[12] = c.v; o[13] = c.a; o[14] = c.kappa;
 }
 
+// ---------------------------------------------------------------------------
+// prediction resampling (reference: src/prediction/trajectory_predictor.py:188-313)
+// ---------------------------------------------------------------------------
+
+// len(np.arange(sim_dt, max(plan_horizon, pred_len*sgan_dt) + 1e-9, sim_dt))
+FOT_HD int resample_n_dense(double sgan_dt, double sim_dt, double plan_horizon, int pred_len)
+{
+    const double target = fmax(plan_horizon, (double)pred_len * sgan_dt);
+    const double n = ceil((target + 1e-9 - sim_dt) / sim_dt);
+    return n > 0.0 ? (int)n : 0;
+}
+
+// One coordinate axis of one pedestrian: n_src source values co[] at times ts(i) -> n_dense values.
+// ts(i) = (i + first_k) * sgan_dt - staleness with first_k = 0 when an anchor point leads the sources, else 1.
+struct ResampleAxis {
+    double co[FOT_MAX_PRED_LEN + 1];
+    int n_src, first_k;
+    double sgan_dt, staleness;
+    FOT_HD double ts(int i) const { return (double)(i + first_k) * sgan_dt - staleness; }
+    // np.allclose(co, b): every |co_i - b| <= 1e-8 + 1e-5 |b|   (:292)
+    FOT_HD bool all_close(double b) const
+    {
+        bool ok = true;
+        for (int i = 0; i < n_src; ++i) ok = ok && (fabs(co[i] - b) <= 1e-8 + 1e-5 * fabs(b));
+        return ok;
+    }
+    // np.interp at t, then the clamped-velocity tail beyond the last source (:297-311)
+    FOT_HD double at(double t, bool constant, double v_tail) const
+    {
+        if (constant) return co[n_src - 1];
+        const double t_last = ts(n_src - 1);
+        if (n_src >= 2 && t > t_last) return co[n_src - 1] + v_tail * (t - t_last);
+        if (t > t_last) return co[n_src - 1];
+        if (t < ts(0)) return co[0];
+        int j = 0;
+        for (int i = 1; i < n_src; ++i) j = ts(i) <= t ? i : j;     // last source time <= t
+        if (j == n_src - 1 || ts(j) == t) return co[j];
+        const double slope = (co[j + 1] - co[j]) / (ts(j + 1) - ts(j));
+        return slope * (t - ts(j)) + co[j];
+    }
+    FOT_HD double tail_velocity() const
+    {
+        if (n_src < 2) return 0.0;
+        const int lookback = n_src < 3 ? n_src : 3;
+        const double v = (co[n_src - 1] - co[n_src - lookback]) / ((double)(lookback - 1) * sgan_dt);
+        return fmax(fmin(v, 2.5), -2.5);                              // MAX_WALKING_SPEED
+    }
+};
+
 }  // namespace fot

@@ -901,3 +901,115 @@ int orc_plan_batch(const orc_params *p, const orc_spline *sp, int n_inst, const 
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* prediction resampling, src/prediction/trajectory_predictor.py */
+/* ------------------------------------------------------------------------- */
+
+/* len(np.arange(start, stop, step)) = ceil((stop - start) / step) */
+int orc_n_dense(double sgan_dt, double sim_dt, double plan_horizon, int pred_len)
+{
+    double target = fmax(plan_horizon, (double)pred_len * sgan_dt);
+    double n = ceil((target + 1e-9 - sim_dt) / sim_dt);
+    return n > 0 ? (int)n : 0;
+}
+
+/* np.allclose(a, b): all |a_i - b| <= 1e-8 + 1e-5 |b| */
+static int all_close(const double *a, int n, double b)
+{
+    for (int i = 0; i < n; ++i)
+        if (!(fabs(a[i] - b) <= 1e-8 + 1e-5 * fabs(b))) return 0;
+    return 1;
+}
+
+/* np.interp(x, xp, fp) for one x (xp increasing) */
+static double np_interp(double x, const double *xp, const double *fp, int n)
+{
+    if (isnan(x)) return x;
+    if (x > xp[n - 1]) return fp[n - 1];
+    if (x < xp[0]) return fp[0];
+    int lo = 0, hi = n;                     /* j with xp[j] <= x < xp[j+1] */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid + 1; else hi = mid; }
+    int j = lo - 1;
+    if (j == n - 1) return fp[j];
+    if (xp[j] == x) return fp[j];
+    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double r = slope * (x - xp[j]) + fp[j];
+    if (isnan(r)) {
+        r = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+    }
+    return r;
+}
+
+int orc_process_prediction(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
+                           const double *pred, const double *anchor, double staleness, double *out)
+{
+    int n_dense = orc_n_dense(sgan_dt, sim_dt, plan_horizon, pred_len);
+    int n_src = pred_len + (anchor ? 1 : 0);
+    double *ts = dalloc(n_src), *co = dalloc(n_src);
+    int o = 0;
+    if (anchor) ts[o++] = -staleness;                                   /* :268-270 */
+    for (int k = 1; k <= pred_len; ++k) ts[o++] = (double)k * sgan_dt - staleness;
+    for (int p = 0; p < P; ++p)
+        for (int ax = 0; ax < 2; ++ax) {
+            o = 0;
+            if (anchor) co[o++] = anchor[2 * p + ax];
+            for (int k = 0; k < pred_len; ++k) co[o++] = pred[((size_t)k * P + p) * 2 + ax];
+            double *dst = out + ((size_t)p * n_dense) * 2 + ax;
+            if (all_close(co, n_src, co[0]) || all_close(co, n_src, 0.0)) {   /* :292-294 */
+                for (int i = 0; i < n_dense; ++i) dst[2 * i] = co[n_src - 1];
+                continue;
+            }
+            int lookback = n_src < 3 ? n_src : 3;
+            double v_tail = 0.0;
+            if (n_src >= 2) {
+                v_tail = (co[n_src - 1] - co[n_src - lookback]) / ((double)(lookback - 1) * sgan_dt);
+                v_tail = fmax(fmin(v_tail, 2.5), -2.5);                  /* MAX_WALKING_SPEED */
+            }
+            for (int i = 0; i < n_dense; ++i) {
+                double t = sim_dt + (double)i * sim_dt;                   /* np.arange(sim_dt, ..., sim_dt)[i] */
+                double v = np_interp(t, ts, co, n_src);
+                if (n_src >= 2 && t > ts[n_src - 1]) v = co[n_src - 1] + v_tail * (t - ts[n_src - 1]);
+                dst[2 * i] = v;
+            }
+        }
+    free(ts); free(co);
+    return n_dense;
+}
+
+int orc_predict_cv(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
+                   const double *obs_last, const double *obs_prev, double staleness, double *out)
+{
+    int n_dense = orc_n_dense(sgan_dt, sim_dt, plan_horizon, pred_len);
+    for (int p = 0; p < P; ++p)
+        for (int ax = 0; ax < 2; ++ax) {
+            double cur = obs_last[2 * p + ax];
+            double vel = obs_prev ? (cur - obs_prev[2 * p + ax]) / sgan_dt : 0.0;
+            for (int i = 0; i < n_dense; ++i) {
+                double t = (sim_dt + (double)i * sim_dt) + staleness;
+                out[((size_t)p * n_dense + i) * 2 + ax] = cur + vel * t;
+            }
+        }
+    return n_dense;
+}
+
+int orc_best_sample(int S, int P, int T, const double *samples, double *dist_out)
+{
+    size_t n = (size_t)P * T;
+    int best = 0;
+    double best_d = INFINITY;
+    for (int s = 0; s < S; ++s) {
+        double acc = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            double mx = 0.0, my = 0.0;
+            for (int q = 0; q < S; ++q) { mx += samples[((size_t)q * n + i) * 2]; my += samples[((size_t)q * n + i) * 2 + 1]; }
+            mx /= (double)S; my /= (double)S;
+            double dx = samples[((size_t)s * n + i) * 2] - mx, dy = samples[((size_t)s * n + i) * 2 + 1] - my;
+            acc += sqrt(dx * dx + dy * dy);
+        }
+        if (dist_out) dist_out[s] = acc;
+        if (acc < best_d) { best_d = acc; best = s; }
+    }
+    return best;
+}

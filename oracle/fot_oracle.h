@@ -140,6 +140,19 @@ int orc_plan_batch(const orc_params *p, const orc_spline *sp, int n_inst, const 
 int orc_path_collision_free(const orc_params *p, int n, const double *x, const double *y,
                             const double *yaw, const double *t, const orc_obstacles *obs);
 
+/* ---- obstacle-tensor producer ----
+ * TrajectoryPredictor.process_prediction (trajectory_predictor.py:233-313) for one sample:
+ * pred [pred_len][P][2] raw predictions anchored at the last observation, anchor [P][2] or NULL,
+ * out [P][n_dense][2].  Returns n_dense = len(arange(sim_dt, max(plan_horizon, pred_len*sgan_dt)+1e-9, sim_dt)). */
+int orc_n_dense(double sgan_dt, double sim_dt, double plan_horizon, int pred_len);
+int orc_process_prediction(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
+                           const double *pred, const double *anchor, double staleness, double *out);
+/* predict_cv (:188-231): obs_last, obs_prev [P][2] (obs_prev NULL: zero velocity) -> out [P][n_dense][2] */
+int orc_predict_cv(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
+                   const double *obs_last, const double *obs_prev, double staleness, double *out);
+/* predict_single_best (:338-351): samples [S][P][T][2] -> index of the sample closest to the sample mean */
+int orc_best_sample(int S, int P, int T, const double *samples, double *dist_out);
+
 #ifdef __cplusplus
 }
 #endif

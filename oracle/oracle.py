@@ -114,6 +114,10 @@ def lib():
                                      C.POINTER(Overrides), dp, C.POINTER(Obstacles), C.POINTER(Result)]
         L.orc_path_collision_free.argtypes = [C.POINTER(Params), C.c_int, dp, dp, dp, dp,
                                               C.POINTER(Obstacles)]
+        L.orc_n_dense.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+        L.orc_process_prediction.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, dp]
+        L.orc_predict_cv.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, dp]
+        L.orc_best_sample.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
         _lib = L
     return _lib
 
@@ -315,3 +319,34 @@ def path_collision_free(params: Params, x, y, yaw, t, static=None, dyn=None, dis
     obs = ObstacleSet(static, dyn, dist)
     return bool(lib().orc_path_collision_free(C.byref(params), n, _dp(x), _dp(y), _dp(yaw), _dp(t),
                                               C.byref(obs.c)))
+
+
+# ---- prediction resampling -------------------------------------------------------------
+
+def process_prediction(pred, anchor=None, staleness=0.0, sgan_dt=0.4, sim_dt=0.1, plan_horizon=5.0):
+    """pred [pred_len, P, 2] -> dense [P, n_dense, 2] (trajectory_predictor.py:233-313)."""
+    pred = np.ascontiguousarray(pred, dtype=np.float64)
+    pred_len, P = pred.shape[0], pred.shape[1]
+    n = lib().orc_n_dense(sgan_dt, sim_dt, plan_horizon, pred_len)
+    out = np.zeros((P, n, 2))
+    a = None if anchor is None else np.ascontiguousarray(anchor, dtype=np.float64)
+    lib().orc_process_prediction(sgan_dt, sim_dt, plan_horizon, pred_len, P, _dp(pred), None if a is None else _dp(a),
+                                 float(staleness), _dp(out))
+    return out
+
+
+def predict_cv(obs_last, obs_prev=None, staleness=0.0, pred_len=12, sgan_dt=0.4, sim_dt=0.1, plan_horizon=5.0):
+    last = np.ascontiguousarray(obs_last, dtype=np.float64)
+    prev = None if obs_prev is None else np.ascontiguousarray(obs_prev, dtype=np.float64)
+    P = last.shape[0]
+    n = lib().orc_n_dense(sgan_dt, sim_dt, plan_horizon, pred_len)
+    out = np.zeros((P, n, 2))
+    lib().orc_predict_cv(sgan_dt, sim_dt, plan_horizon, pred_len, P, _dp(last), None if prev is None else _dp(prev),
+                         float(staleness), _dp(out))
+    return out
+
+
+def best_sample(samples):
+    s = np.ascontiguousarray(samples, dtype=np.float64)
+    dist = np.zeros(s.shape[0])
+    return lib().orc_best_sample(s.shape[0], s.shape[1], s.shape[2], _dp(s), _dp(dist)), dist
