@@ -83,9 +83,13 @@ typedef struct fot_ego {
     double x, y, yaw, v, a;
     double last_kappa;           /* FrenetPlanner._last_kappa */
     double prev_s;               /* CoordinateConverter._prev_s */
-    int32_t has_prev_s;          /* 0: first call (global nearest-point search) */
+    int32_t has_prev_s;          /* 0: first call (global nearest-point search); 1: prev_s valid;
+                                    2 (FOT_PREV_S_CHAINED): prev_s := new_prev_s of the PREVIOUS instance of the
+                                    batch, i.e. this instance is the next plan() call on the same planner object
+                                    (the escalation retries of integrated_simulator.py:602-644 in one launch) */
     int32_t _pad;
 } fot_ego;
+#define FOT_PREV_S_CHAINED 2
 
 /* replaces constraint_overrides (frenet_planner.py:921-930); NaN = key absent */
 typedef struct fot_overrides {

@@ -26,6 +26,7 @@ class PlanRequest:
     target_speed: float = 30.0 / 3.6
     last_kappa: float = 0.0
     prev_s: Optional[float] = None
+    chain_prev_s: bool = False                   # prev_s := new_prev_s of the previous request (next call on the same planner)
     overrides: Optional[dict] = None
     max_stop_distance: Optional[float] = None
     static: Optional[np.ndarray] = None          # [Ns, 2]
@@ -68,12 +69,19 @@ class PackedBatch:
         dyns: List[np.ndarray] = []
         dyn_cursor = 0
         nan = float("nan")
+        shared = {}                                  # (id(array), mode) -> offset: requests passing the SAME dynamic tensor
+                                                     # object (escalation retries of one step) share one copy of it
         for i, r in enumerate(requests):
             e = self.ego[i]
             e.x, e.y, e.yaw, e.v, e.a = float(r.x), float(r.y), float(r.yaw), float(r.v), float(r.a)
             e.last_kappa = float(r.last_kappa)
-            e.has_prev_s = 0 if r.prev_s is None else 1
-            e.prev_s = 0.0 if r.prev_s is None else float(r.prev_s)
+            if r.chain_prev_s:
+                if i == 0:
+                    raise ValueError("the first request of a batch cannot chain its nearest-point cache")
+                e.has_prev_s, e.prev_s = 2, 0.0
+            else:
+                e.has_prev_s = 0 if r.prev_s is None else 1
+                e.prev_s = 0.0 if r.prev_s is None else float(r.prev_s)
             self.target[i] = float(r.target_speed)
             ov = r.overrides or {}
             o = self.overrides[i]
@@ -91,8 +99,14 @@ class PackedBatch:
             if mode != _abi.DYN_NONE:
                 S, P, T = d.shape[0], d.shape[1], d.shape[2]
                 self.dyn_dims[i] = (mode, S, P, T)
-                dyns.append(np.ascontiguousarray(d, dtype=self.np_dtype).reshape(-1, 2))
-                dyn_cursor += S * P * T
+                src = r.dist if mode == _abi.DYN_DISTRIBUTION else r.dyn
+                key = (id(src), mode)
+                if key in shared:
+                    self.dyn_off[i] = shared[key]
+                else:
+                    shared[key] = dyn_cursor
+                    dyns.append(np.ascontiguousarray(d, dtype=self.np_dtype).reshape(-1, 2))
+                    dyn_cursor += S * P * T
         self.static_xy = (np.concatenate(statics, axis=0) if statics else np.empty((0, 2))).astype(self.np_dtype)
         self.static_xy = np.ascontiguousarray(self.static_xy)
         self.dyn_xy = np.ascontiguousarray(np.concatenate(dyns, axis=0) if dyns else np.empty((0, 2), self.np_dtype))

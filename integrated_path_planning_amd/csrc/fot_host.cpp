@@ -332,7 +332,11 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     const int lanes = h->lanes_cfg;
     for (int l = 0; l < lanes; ++l) {
         Workspace &w = h->ws[l];
-        const int n = b.n_inst / lanes + (l < b.n_inst % lanes ? 1 : 0);
+        int n = b.n_inst / lanes + (l < b.n_inst % lanes ? 1 : 0);
+        if (l == lanes - 1) n = b.n_inst - i0;
+        while (i0 + n < b.n_inst && b.ego[i0 + n].has_prev_s == FOT_PREV_S_CHAINED) ++n;   // never cut a chain
+        if (n > b.n_inst - i0) n = b.n_inst - i0;
+        if (n <= 0) { w.last = BatchLayout(); w.first_inst = i0; continue; }
         HIP_TRY(h, hipStreamWaitEvent(w.stream, h->fork, 0));
         w.first_inst = i0;
         int rc = enqueue_lane(h, w, sub_batch(b, i0, n), d_static, d_dyn, d_out + i0, w.stream);

@@ -95,53 +95,63 @@ __global__ void __launch_bounds__(WAVE)
 k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
                InstState *__restrict__ state, int n_inst)
 {
-    const int inst = blockIdx.x;
+    int inst = blockIdx.x;
     if (inst >= n_inst) return;
+    if (desc[inst].ego.has_prev_s == FOT_PREV_S_CHAINED) return;   // handled by the head of its chain
     const DevParams &P = *Pp;
-    const InstDesc &D = desc[inst];
     const int lane = threadIdx.x;
-    const double x = D.ego.x, y = D.ego.y;
     const double s_end = sp.s[sp.n - 1];
-
-    double best_s = 0.0;
-    bool need_global = true;
-    if (D.ego.has_prev_s) {                                   // cached window +-10 m, 100 samples
-        const double s_min = fmax(0.0, D.ego.prev_s - 10.0);
-        const double s_max = fmin(s_end, D.ego.prev_s + 10.0);
-        ScanBest b = wave_argmin(scan_samples(sp, x, y, s_min, s_max, 100, lane, WAVE, false));
-        best_s = b.idx >= 0 ? linspace_at(s_min, s_max, 100, b.idx) : 0.0;
-        const bool at_lower = fabs(best_s - s_min) < 1e-3 && s_min > 0.0;
-        const bool at_upper = fabs(best_s - s_max) < 1e-3 && s_max < s_end;
-        need_global = at_lower || at_upper;
-    }
     const int n_glob = global_search_count(sp);
-    if (need_global) {
-        ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
-        best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
-    }
-    best_s = refine_nearest(sp, x, y, best_s);                // uniform across the wave
-    const double new_prev_s = best_s;
+    double carry_prev_s = 0.0;                                 // new_prev_s of the previous member of the chain
+    bool chained = false;
+    do {
+        const InstDesc &D = desc[inst];
+        const double x = D.ego.x, y = D.ego.y;
+        const bool has_prev = chained ? true : D.ego.has_prev_s != 0;
+        const double prev_s = chained ? carry_prev_s : D.ego.prev_s;
 
-    double fr[6], ref[6];
-    bool ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
-    if (!ok) {
-        double px, py;
-        spline_xy(sp, best_s, px, py);
-        if (isnan(px) || isnan(py)) {                         // coordinate_converter.py:289-295
+        double best_s = 0.0;
+        bool need_global = true;
+        if (has_prev) {                                        // cached window +-10 m, 100 samples
+            const double s_min = fmax(0.0, prev_s - 10.0);
+            const double s_max = fmin(s_end, prev_s + 10.0);
+            ScanBest b = wave_argmin(scan_samples(sp, x, y, s_min, s_max, 100, lane, WAVE, false));
+            best_s = b.idx >= 0 ? linspace_at(s_min, s_max, 100, b.idx) : 0.0;
+            const bool at_lower = fabs(best_s - s_min) < 1e-3 && s_min > 0.0;
+            const bool at_upper = fabs(best_s - s_max) < 1e-3 && s_max < s_end;
+            need_global = at_lower || at_upper;
+        }
+        if (need_global) {
             ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
             best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
-            ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
         }
-    }
-    if (lane == 0) {
-        InstState &S = state[inst];
-        for (int i = 0; i < 6; ++i) { S.frenet0[i] = ok ? fr[i] : NAN; S.ref0[i] = ok ? ref[i] : NAN; }
-        S.new_prev_s = new_prev_s;
-        S.c2f_ok = ok ? 1 : 0;
-        const int nb = (ok && fr[1] > 0.1) ? P.n_brake : 0;   // BRAKE_MIN_SPEED gate
-        S.n_brake = nb;
-        S.n_cand = ok ? D.n_grid + nb : 0;
-    }
+        best_s = refine_nearest(sp, x, y, best_s);            // uniform across the wave
+        const double new_prev_s = best_s;
+
+        double fr[6], ref[6];
+        bool ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
+        if (!ok) {
+            double px, py;
+            spline_xy(sp, best_s, px, py);
+            if (isnan(px) || isnan(py)) {                     // coordinate_converter.py:289-295
+                ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
+                best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
+                ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
+            }
+        }
+        if (lane == 0) {
+            InstState &S = state[inst];
+            for (int i = 0; i < 6; ++i) { S.frenet0[i] = ok ? fr[i] : NAN; S.ref0[i] = ok ? ref[i] : NAN; }
+            S.new_prev_s = new_prev_s;
+            S.c2f_ok = ok ? 1 : 0;
+            const int nb = (ok && fr[1] > 0.1) ? P.n_brake : 0;   // BRAKE_MIN_SPEED gate
+            S.n_brake = nb;
+            S.n_cand = ok ? D.n_grid + nb : 0;
+        }
+        carry_prev_s = new_prev_s;
+        chained = true;
+        ++inst;
+    } while (inst < n_inst && desc[inst].ego.has_prev_s == FOT_PREV_S_CHAINED);
 }
 
 // ---------------------------------------------------------------------------

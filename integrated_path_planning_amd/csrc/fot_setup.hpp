@@ -191,6 +191,8 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         InstDesc &D = L.desc[i];
         D = InstDesc();
         D.ego = b.ego[i];
+        if (D.ego.has_prev_s < 0 || D.ego.has_prev_s > FOT_PREV_S_CHAINED) { err = "has_prev_s must be 0, 1 or 2"; return FOT_ERR_INVALID; }
+        if (i == 0 && D.ego.has_prev_s == FOT_PREV_S_CHAINED) { err = "the first instance cannot be chained"; return FOT_ERR_INVALID; }
         const double target = b.target_speed[i];
         D.target_speed = target;
         D.max_stop = b.max_stop_distance ? b.max_stop_distance[i] : NAN;

@@ -62,8 +62,10 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         const double x = D.ego.x, y = D.ego.y, s_end = sp.s[sp.n - 1];
         double best_s = 0.0;
         bool need_global = true;
+        const bool chained = D.ego.has_prev_s == FOT_PREV_S_CHAINED;
+        const double prev_s_in = chained ? out[inst - 1].new_prev_s : D.ego.prev_s;
         if (D.ego.has_prev_s) {
-            const double s_min = fmax(0.0, D.ego.prev_s - 10.0), s_max = fmin(s_end, D.ego.prev_s + 10.0);
+            const double s_min = fmax(0.0, prev_s_in - 10.0), s_max = fmin(s_end, prev_s_in + 10.0);
             ScanBest bb = scan_samples(sp, x, y, s_min, s_max, 100, 0, 1, false);
             best_s = bb.idx >= 0 ? linspace_at(s_min, s_max, 100, bb.idx) : 0.0;
             need_global = (fabs(best_s - s_min) < 1e-3 && s_min > 0.0) || (fabs(best_s - s_max) < 1e-3 && s_max < s_end);
