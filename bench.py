@@ -201,6 +201,46 @@ def main():
             latency[name] = {"p50_ms": float(np.percentile(ts, 50)), "p95_ms": float(np.percentile(ts, 95)),
                              "calls": len(ts)}
             p1.close()
+        # ---- rows f1 / f2 of SURVEY 8 (the stages either side of the path), one ego
+        from integrated_path_planning_amd.prediction import PredictionResampler
+        rng = np.random.default_rng(0)
+        S, P, Lp = 20, 30, 12
+        raw = rng.normal(0, 5, (S, Lp, P, 2)).astype(np.float32)
+        p0 = rng.normal(0, 5, (P, 2))
+        rs = PredictionResampler(bp)
+        raw_dev = torch.from_numpy(raw).to(dev)
+        obs_dev = torch.zeros((S, P, rs.n_dense + 1, 2), dtype=torch.float32, device=dev)
+        ts = []
+        for it in range(200):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            rs.resample_device(raw_dev.data_ptr(), np.float32, S, P, p0, p0, 0.2, obs_dev.data_ptr(), np.float32,
+                               stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        for s_ in range(S):
+            orc.process_prediction(raw[s_].astype(np.float64), p0, 0.2)
+        latency["f1_resample_20x30"] = {"p50_ms": float(np.percentile(np.array(ts) * 1e3, 50)),
+                                        "cpu_port_ms": (time.perf_counter() - t1) * 1e3}
+        p3 = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **syn.CONFIG3_PLANNER)
+        inst3 = syn.config3_instance(1)                       # a NO_PATH instance: the reference would retry twice
+        lvl = [dict(), dict(target_speed=0.8 * syn.TARGET_SPEED, overrides=dict(max_accel=3.0, max_speed=11.0)),
+               dict(target_speed=0.0, overrides=dict(max_accel=6.0, max_lat_accel=6.0), max_stop_distance=8.0)]
+        from integrated_path_planning_amd.batch import PlanRequest
+        reqs3 = [PlanRequest(*inst3.ego, dist=inst3.dist, chain_prev_s=bool(j), **kw_) for j, kw_ in enumerate(lvl)]
+        one_launch = PackedBatch(reqs3, np.float32)
+        seq = [PackedBatch([PlanRequest(*inst3.ego, dist=inst3.dist, **kw_)], np.float32) for kw_ in lvl]
+        t_spec, t_seq = [], []
+        for it in range(200):
+            t1 = time.perf_counter(); p3.plan_packed(one_launch); t_spec.append(time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            for b_ in seq:
+                p3.plan_packed(b_)
+            t_seq.append(time.perf_counter() - t1)
+        latency["f2_three_level_cycle"] = {"one_launch_p50_ms": float(np.percentile(np.array(t_spec) * 1e3, 50)),
+                                           "three_calls_p50_ms": float(np.percentile(np.array(t_seq) * 1e3, 50))}
+        p3.close()
         ts = []
         for _ in range(5):
             t1 = time.perf_counter()

@@ -235,6 +235,19 @@ int fot_predict_cv(fot_handle *h, const fot_resample_params *rp, int32_t pred_le
                    const double *obs_last, const double *obs_prev, const double *current, double staleness,
                    void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream);
 
+/* ---- compute_safety_metrics_static (data_structures.py:301-388) for n egos in one launch ----
+ * ego [n][4] = x, y, yaw, v; pedestrians of ego i: ped_pos / ped_vel [ped_off[i] .. ped_off[i+1])[2]  (host arrays).
+ * use_footprint != 0: the handle's multi-circle footprint (footprint= argument of the reference); otherwise, or when the
+ * handle has none, the single centre circle of ego_radius. */
+typedef struct fot_safety {
+    double min_distance, ttc, clearance, clearance_ahead;
+    int32_t collision;
+    int32_t _pad;
+} fot_safety;
+int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const int32_t *ped_off,
+                             const double *ped_pos, const double *ped_vel, double ego_radius, double ped_radius,
+                             int32_t use_footprint, fot_safety *out);
+
 /* ---- measurement (no reference counterpart: the reference times plan() with perf_counter,
  *      integrated_simulator.py:575-585) ----
  * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the

@@ -68,6 +68,11 @@ class ResampleParams(C.Structure):
     _fields_ = [("sgan_dt", C.c_double), ("sim_dt", C.c_double), ("plan_horizon", C.c_double)]
 
 
+class Safety(C.Structure):
+    _fields_ = [("min_distance", C.c_double), ("ttc", C.c_double), ("clearance", C.c_double),
+                ("clearance_ahead", C.c_double), ("collision", C.c_int32), ("_pad", C.c_int32)]
+
+
 class Batch(C.Structure):
     _fields_ = [("n_inst", C.c_int32), ("obstacle_dtype", C.c_int32),
                 ("ego", C.POINTER(Ego)), ("target_speed", C.POINTER(C.c_double)),
@@ -86,7 +91,7 @@ SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_se
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
            "fot_debug_candidate_path", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
-           "fot_predict_cv", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
+           "fot_predict_cv", "fot_safety_metrics_batch", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 6
 
 _lib = None
@@ -136,6 +141,7 @@ def lib():
                                            dp, dp, C.c_double, vp, C.c_int32, C.c_int32, ip, dp, vp]
     L.fot_predict_cv.argtypes = [vp, C.POINTER(ResampleParams), C.c_int32, C.c_int32, dp, dp, dp, C.c_double, vp,
                                  C.c_int32, C.c_int32, ip, vp]
+    L.fot_safety_metrics_batch.argtypes = [vp, C.c_int32, dp, ip, dp, dp, C.c_double, C.c_double, C.c_int32, C.POINTER(Safety)]
     L.fot_profile_enable.argtypes = [vp, C.c_int]
     L.fot_profile_read.argtypes = [vp, C.c_int, ip, dp]
     L.fot_profile_kernel_name.argtypes = [C.c_int]

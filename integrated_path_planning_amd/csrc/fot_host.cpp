@@ -581,6 +581,40 @@ int fot_predict_cv(fot_handle *h, const fot_resample_params *rp, int32_t pred_le
                            on_device, T_out, nullptr, stream);
 }
 
+int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const int32_t *ped_off,
+                             const double *ped_pos, const double *ped_vel, double ego_radius, double ped_radius,
+                             int32_t use_footprint, fot_safety *out)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n <= 0) return n == 0 ? FOT_OK : fail(h, FOT_ERR_INVALID, "n < 0");
+    if (!ego || !ped_off || !out) return fail(h, FOT_ERR_INVALID, "NULL array");
+    for (int i = 0; i < n; ++i)
+        if (ped_off[i + 1] < ped_off[i] || ped_off[0] < 0) return fail(h, FOT_ERR_INVALID, "ped_off must be non-decreasing");
+    const size_t n_ped = (size_t)ped_off[n];
+    if (n_ped > 0 && (!ped_pos || !ped_vel)) return fail(h, FOT_ERR_INVALID, "NULL pedestrian array");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const size_t ego_b = sizeof(double) * 4 * (size_t)n, off_b = align256(sizeof(int32_t) * ((size_t)n + 1));
+    const size_t ped_b = sizeof(double) * 2 * std::max<size_t>(n_ped, 1);
+    HIP_TRY(h, h->dTmpA.ensure(align256(ego_b) + off_b));
+    HIP_TRY(h, h->dTmpB.ensure(2 * align256(ped_b)));
+    HIP_TRY(h, h->dTmpC.ensure(sizeof(fot_safety) * (size_t)n));
+    char *a = (char *)h->dTmpA.p, *b = (char *)h->dTmpB.p;
+    HIP_TRY(h, hipMemcpyAsync(a, ego, ego_b, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(a + align256(ego_b), ped_off, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    if (n_ped) {
+        HIP_TRY(h, hipMemcpyAsync(b, ped_pos, sizeof(double) * 2 * n_ped, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(b + align256(ped_b), ped_vel, sizeof(double) * 2 * n_ped, hipMemcpyHostToDevice, st));
+    }
+    LAUNCH_TRY(h, launch_safety(h->dP.as<DevParams>(), n, (const double *)a, (const int32_t *)(a + align256(ego_b)),
+                                (const double *)b, (const double *)(b + align256(ped_b)), ego_radius, ped_radius,
+                                h->params.footprint_radius, use_footprint, h->dTmpC.as<fot_safety>(), st));
+    HIP_TRY(h, hipMemcpyAsync(out, h->dTmpC.p, sizeof(fot_safety) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return FOT_OK;
+}
+
 int fot_profile_enable(fot_handle *h, int on)
 {
     if (!h) return FOT_ERR_INVALID;

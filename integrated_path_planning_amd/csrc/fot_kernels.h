@@ -42,6 +42,9 @@ int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int 
                     int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
                     const double *current, void *out, int out_dtype, hipStream_t st);
 int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, double *dist, hipStream_t st);
+int launch_safety(const DevParams *P, int n, const double *ego, const int32_t *ped_off, const double *ped_pos,
+                  const double *ped_vel, double ego_radius, double ped_radius, double footprint_radius, int use_fp,
+                  fot_safety *out, hipStream_t st);
 int launch_check_ext(const DevParams *P, const InstDesc *desc, int n_paths, int mode, const int32_t *len,
                      const int32_t *flags, const double *arrays, const double *static_xy, const double *dyn_xy,
                      int32_t *status_out, hipStream_t st);

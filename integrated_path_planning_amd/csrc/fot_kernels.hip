@@ -810,6 +810,58 @@ k_sample_dist(int S, int P, int T, int skip, const TO *__restrict__ out, double 
 }
 
 // ---------------------------------------------------------------------------
+// safety metrics, one wave per ego, lanes over (footprint circle, pedestrian) pairs
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+__global__ void __launch_bounds__(WAVE)
+k_safety(const DevParams *__restrict__ Pp, int n, const double *__restrict__ ego, const int32_t *__restrict__ ped_off,
+         const double *__restrict__ ped_pos, const double *__restrict__ ped_vel, double ego_radius, double ped_radius,
+         double footprint_radius, int use_fp, fot_safety *__restrict__ out)
+{
+    const int e = blockIdx.x;
+    if (e >= n) return;
+    const DevParams &P = *Pp;
+    const double x = ego[4 * e], y = ego[4 * e + 1], yaw = ego[4 * e + 2], v = ego[4 * e + 3];
+    const double hx = cos(yaw), hy = sin(yaw);
+    const bool fp = use_fp && P.has_footprint;
+    const int nc = fp ? P.n_circ : 1;
+    const double combined = (fp ? footprint_radius : ego_radius) + ped_radius;
+    const int p0 = ped_off[e], np_ = ped_off[e + 1] - p0;
+    double min_d = INFINITY, ttc = INFINITY, ahead = INFINITY;
+    for (int i = threadIdx.x; i < nc * np_; i += WAVE) {
+        const int c = i / np_, p = i - c * np_;
+        const double off = fp ? P.circ_off[c] : 0.0;
+        const double cx = x + off * hx, cy = y + off * hy;                      // footprint.py:42-45
+        const double px = ped_pos[2 * (p0 + p)], py = ped_pos[2 * (p0 + p) + 1];
+        const double rx = px - cx, ry = py - cy;
+        const double dist = sqrt(rx * rx + ry * ry);
+        min_d = fmin(min_d, dist);
+        const double vx = ped_vel[2 * (p0 + p)] - v * hx, vy = ped_vel[2 * (p0 + p) + 1] - v * hy;
+        const double along = -(rx * vx + ry * vy) / (dist + 1e-8);
+        if (along > 1e-5) {
+            const double t = (dist - combined) / along;
+            if (t >= 0.0) ttc = fmin(ttc, t);
+        }
+        if ((px - x) * hx + (py - y) * hy > 0.0) ahead = fmin(ahead, dist);      // strictly ahead of the vehicle centre
+    }
+    min_d = wave_min_f64(min_d); ttc = wave_min_f64(ttc); ahead = wave_min_f64(ahead);
+    if (threadIdx.x == 0) {
+        fot_safety r;
+        r.min_distance = min_d; r.ttc = ttc; r.clearance = min_d - combined;
+        r.clearance_ahead = isinf(ahead) ? INFINITY : ahead - combined;
+        r.collision = min_d < combined ? 1 : 0; r._pad = 0;
+        out[e] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 
@@ -940,6 +992,16 @@ int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_d
     if (S <= 0) return 0;
     if (out_dtype == FOT_F32) k_sample_dist<float><<<S, 256, 0, st>>>(S, P, T, skip, (const float *)out, dist);
     else k_sample_dist<double><<<S, 256, 0, st>>>(S, P, T, skip, (const double *)out, dist);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_safety(const DevParams *P, int n, const double *ego, const int32_t *ped_off, const double *ped_pos,
+                  const double *ped_vel, double ego_radius, double ped_radius, double footprint_radius, int use_fp,
+                  fot_safety *out, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    k_safety<<<n, WAVE, 0, st>>>(P, n, ego, ped_off, ped_pos, ped_vel, ego_radius, ped_radius, footprint_radius, use_fp, out);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -207,6 +207,33 @@ class BatchPlanner:
                                                              ok.ctypes.data_as(_ip)))
         return fr[:n], ref[:n], nps[:n], ok[:n]
 
+    def safety_metrics(self, egos, ped_positions: Sequence, ped_velocities: Sequence, ego_radius: float,
+                       ped_radius: float, use_footprint: bool = True) -> np.ndarray:
+        """compute_safety_metrics_static (data_structures.py:301-388) for n egos in one launch.
+
+        egos [n, 4] = x, y, yaw, v; ped_positions / ped_velocities: one [P_i, 2] array per ego.  Returns a structured
+        array with fields min_distance, ttc, clearance, clearance_ahead, collision."""
+        ego = np.ascontiguousarray(egos, dtype=np.float64).reshape(-1, 4)
+        n = ego.shape[0]
+        if len(ped_positions) != n or len(ped_velocities) != n:
+            raise ValueError("one pedestrian array per ego is required")
+        off = np.zeros(n + 1, np.int32)
+        pos, vel = [], []
+        for i in range(n):
+            p = np.asarray(ped_positions[i], dtype=np.float64).reshape(-1, 2)
+            v = np.asarray(ped_velocities[i], dtype=np.float64).reshape(-1, 2)
+            if p.shape != v.shape:
+                raise ValueError(f"ego {i}: positions {p.shape} and velocities {v.shape} differ")
+            off[i + 1] = off[i] + p.shape[0]
+            pos.append(p); vel.append(v)
+        pos = np.ascontiguousarray(np.concatenate(pos, axis=0)) if n else np.empty((0, 2))
+        vel = np.ascontiguousarray(np.concatenate(vel, axis=0)) if n else np.empty((0, 2))
+        out = (_abi.Safety * max(n, 1))()
+        _abi.check(self._h, self._lib.fot_safety_metrics_batch(
+            self._h, n, _as_dp(ego), off.ctypes.data_as(_ip), _as_dp(pos) if pos.size else None,
+            _as_dp(vel) if vel.size else None, float(ego_radius), float(ped_radius), int(bool(use_footprint)), out))
+        return np.ctypeslib.as_array(out)[:n].copy() if n else np.zeros(0, dtype=np.dtype(_abi.Safety))
+
     @staticmethod
     def _pack_paths(paths: Sequence, fields: Sequence[str]):
         """FrenetPath-like objects -> {field: [n, MAX_NT]} arrays, lengths, presence flags."""

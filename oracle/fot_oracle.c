@@ -1013,3 +1013,47 @@ int orc_best_sample(int S, int P, int T, const double *samples, double *dist_out
     }
     return best;
 }
+
+/* ------------------------------------------------------------------------- */
+/* safety metrics, src/core/data_structures.py:301-388            */
+/* ------------------------------------------------------------------------- */
+
+void orc_safety_metrics(const orc_params *p, double ego_radius, double ped_radius, const double *ego, int P,
+                        const double *ped_pos, const double *ped_vel, double *out)
+{
+    double cx[ORC_MAX_CIRCLES], cy[ORC_MAX_CIRCLES];
+    int nc = 1;
+    double combined = ego_radius + ped_radius;
+    if (p->n_circles > 0) {                                       /* footprint.circle_centers, footprint.py:42-45 */
+        nc = p->n_circles;
+        for (int c = 0; c < nc; ++c) {
+            cx[c] = ego[0] + p->footprint_offsets[c] * cos(ego[2]);
+            cy[c] = ego[1] + p->footprint_offsets[c] * sin(ego[2]);
+        }
+        combined = p->footprint_radius + ped_radius;
+    } else {
+        cx[0] = ego[0]; cy[0] = ego[1];
+    }
+    double min_d = INFINITY, ttc = INFINITY, ahead_min = INFINITY;
+    const double evx = ego[3] * cos(ego[2]), evy = ego[3] * sin(ego[2]);
+    const double hx = cos(ego[2]), hy = sin(ego[2]);
+    for (int c = 0; c < nc; ++c)
+        for (int i = 0; i < P; ++i) {
+            const double rx = ped_pos[2 * i] - cx[c], ry = ped_pos[2 * i + 1] - cy[c];
+            const double dist = sqrt(rx * rx + ry * ry);
+            if (dist < min_d) min_d = dist;
+            const double vx = ped_vel[2 * i] - evx, vy = ped_vel[2 * i + 1] - evy;
+            const double along = -(rx * vx + ry * vy) / (sqrt(rx * rx + ry * ry) + 1e-8);
+            if (along > 1e-5) {
+                const double t = (dist - combined) / along;
+                if (t >= 0 && t < ttc) ttc = t;
+            }
+            const double ex = ped_pos[2 * i] - ego[0], ey = ped_pos[2 * i + 1] - ego[1];
+            if (ex * hx + ey * hy > 0.0 && dist < ahead_min) ahead_min = dist;
+        }
+    out[0] = min_d;
+    out[1] = min_d < combined ? 1.0 : 0.0;
+    out[2] = ttc;
+    out[3] = min_d - combined;
+    out[4] = isinf(ahead_min) ? INFINITY : ahead_min - combined;
+}

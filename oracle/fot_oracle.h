@@ -153,6 +153,12 @@ int orc_predict_cv(double sgan_dt, double sim_dt, double plan_horizon, int pred_
 /* predict_single_best (:338-351): samples [S][P][T][2] -> index of the sample closest to the sample mean */
 int orc_best_sample(int S, int P, int T, const double *samples, double *dist_out);
 
+/* ---- compute_safety_metrics_static (data_structures.py:301-388) for one ego ----
+ * ego = x, y, yaw, v; ped_pos / ped_vel [P][2]; footprint from p (n_circles 0: single circle of ego_radius).
+ * out[5] = min_distance, collision (0/1), ttc, clearance, clearance_ahead */
+void orc_safety_metrics(const orc_params *p, double ego_radius, double ped_radius, const double *ego, int P,
+                        const double *ped_pos, const double *ped_vel, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,8 @@ def lib():
         L.orc_process_prediction.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, dp]
         L.orc_predict_cv.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, dp]
         L.orc_best_sample.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
+        L.orc_safety_metrics.argtypes = [C.POINTER(Params), C.c_double, C.c_double, dp, C.c_int, dp, dp, dp]
+        L.orc_safety_metrics.restype = None
         _lib = L
     return _lib
 
@@ -350,3 +352,16 @@ def best_sample(samples):
     s = np.ascontiguousarray(samples, dtype=np.float64)
     dist = np.zeros(s.shape[0])
     return lib().orc_best_sample(s.shape[0], s.shape[1], s.shape[2], _dp(s), _dp(dist)), dist
+
+
+# ---- safety metrics -----------------------------------------------------------------------
+
+def safety_metrics(params: Params, ego_radius, ped_radius, ego_xyyawv, ped_pos, ped_vel) -> dict:
+    ego = np.ascontiguousarray(ego_xyyawv, dtype=np.float64)
+    pos = np.ascontiguousarray(ped_pos, dtype=np.float64).reshape(-1, 2)
+    vel = np.ascontiguousarray(ped_vel, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(5)
+    lib().orc_safety_metrics(C.byref(params), float(ego_radius), float(ped_radius), _dp(ego), pos.shape[0],
+                             _dp(pos), _dp(vel), _dp(out))
+    return {"min_distance": out[0], "collision": bool(out[1]), "ttc": out[2], "clearance": out[3],
+            "clearance_ahead": out[4]}
