@@ -138,7 +138,10 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on its stream, inside the timed region)
     dom = max(prof, key=lambda k: prof[k]["total_ms"])
     dom_ms = prof[dom]["total_ms"] / max(prof[dom]["launches"], 1)
-    alg_bytes = B_ALG * cand_local                       # per launch: one launch = this rank's whole batch
+    # candidates of one launch: a step splits the batch over the handle's lanes (one launch of each kernel per lane)
+    launches_per_step = max(prof[dom]["launches"] / max(args.steps, 1), 1.0)
+    cand_launch = cand_local / launches_per_step
+    alg_bytes = B_ALG * cand_launch
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as the
     # gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); null when no profile is committed for it
     traffic = None
@@ -150,9 +153,10 @@ def main():
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
-                "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes}
+                "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "candidates_per_launch": cand_launch, "launches_per_step": launches_per_step}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    valu = {"kernel": dom, "bound": "valu_fp64", "achieved": F_ALG * cand_local / (dom_ms * 1e-3) / 1e12,
+    valu = {"kernel": dom, "bound": "valu_fp64", "achieved": F_ALG * cand_launch / (dom_ms * 1e-3) / 1e12,
             "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s",
             "note": "nominal brute-force flops of SURVEY 8(d) (every candidate sample x every obstacle point); the "
                     "broad phase skips ~96% of those pair tests, so this can exceed the peak"}

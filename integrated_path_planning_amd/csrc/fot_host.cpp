@@ -66,14 +66,14 @@ struct Workspace {
     PinnedBuf staging;
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
     DevBuf dState, dLonInfo, dLonTab;
-    DevBuf dCost, dVlast, dTravel, dStatus, dKeep, dHit, dPts;
-    DevBuf dWaveBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: wave boxes + culled entry lists
+    DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
+    DevBuf dProfBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: profile boxes + culled entry lists
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
-        DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dLonTab, &dCost, &dVlast, &dTravel, &dStatus, &dKeep, &dHit,
-                           &dPts, &dWaveBox, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
+        DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dLonTab, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
+                           &dProfBox, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
         for (DevBuf *b : bufs) b->release();
         staging.release();
         if (staging_done) (void)hipEventDestroy(staging_done);
@@ -157,8 +157,8 @@ int upload_spline(fot_handle *h)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_lon_table", "k_evaluate", "k_cull",
-                                                        "k_collide", "k_select" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_lon_table", "k_cull", "k_evaluate",
+                                                        "k_select" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -232,9 +232,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dTravel.ensure(sizeof(double) * slots));
     HIP_TRY(h, w.dStatus.ensure(slots));
     HIP_TRY(h, w.dKeep.ensure(slots));
-    HIP_TRY(h, w.dHit.ensure(sizeof(unsigned long long) * slots));
-    HIP_TRY(h, w.dPts.ensure(sizeof(d2) * slots * (size_t)P.n_circ * (size_t)P.n_total));
-    HIP_TRY(h, w.dWaveBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
+    HIP_TRY(h, w.dProfBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max<int64_t>(L.n_lon, 1)));
     const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
     HIP_TRY(h, w.dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
     HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
@@ -253,7 +251,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     CandArrays ca;
     ca.cost = w.dCost.as<double>(); ca.v_last = w.dVlast.as<double>(); ca.travel = w.dTravel.as<double>();
     ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
-    ca.hit = w.dHit.as<unsigned long long>();
 
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
@@ -265,25 +262,20 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     {
         ProfScope ps(h, 1, st);
         LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                       w.dLonTab.as<double>(), L.n_inst, L.max_lon, st));
-    }
-    {
-        ProfScope ps(h, 2, st);
-        LAUNCH_TRY(h, launch_evaluate(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                      w.dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ca,
-                                      w.dPts.as<d2>(), w.dWaveBox.as<float>(), st));
+                                       w.dLonTab.as<double>(), w.dProfBox.as<float>(), L.n_inst, L.max_lon, st));
     }
     if (L.any_obstacles) {
-        {
-            ProfScope ps(h, 3, st);
-            LAUNCH_TRY(h, launch_cull(dP, d_desc, L.n_inst, P.n_total, w.dWaveBox.as<float>(), d_static, d_dyn,
-                                      b.obstacle_dtype, ea, st));
-        }
-        ProfScope ps(h, 4, st);
-        LAUNCH_TRY(h, launch_collide(dP, d_desc, d_wave_inst, d_wave_base, L.n_waves, ea, w.dPts.as<d2>(), ca, st));
+        ProfScope ps(h, 2, st);
+        LAUNCH_TRY(h, launch_cull(dP, d_desc, w.dState.as<InstState>(), L.n_inst, P.n_total, w.dProfBox.as<float>(),
+                                  d_static, d_dyn, b.obstacle_dtype, ea, st));
     }
     {
-        ProfScope ps(h, 5, st);
+        ProfScope ps(h, 3, st);
+        LAUNCH_TRY(h, launch_evaluate(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
+                                      w.dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ea, ca, st));
+    }
+    {
+        ProfScope ps(h, 4, st);
         LAUNCH_TRY(h, launch_select(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
                                     w.dLonTab.as<double>(), ca, d_out, L.n_inst, st));
     }

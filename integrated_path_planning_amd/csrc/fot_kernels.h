@@ -10,7 +10,6 @@ namespace fot {
 struct CandArrays {
     double *cost, *v_last, *travel;
     uint8_t *status, *keep;
-    unsigned long long *hit;   // prediction samples that hit the candidate (bit per sample)
 };
 
 // broad-phase entry lists in HBM: per instance n_total * ent_cap slots
@@ -25,14 +24,13 @@ struct EntryArrays {
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         hipStream_t st);
 int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                     LonInfo *lon_info, double *lon_tab, int n_inst, int max_lon, hipStream_t st);
+                     LonInfo *lon_info, double *lon_tab, float *prof_box, int n_inst, int max_lon, hipStream_t st);
+int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
+                const float *prof_box, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
+                hipStream_t st);
 int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                     const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
-                    CandArrays c, d2 *pts, float *wave_box, hipStream_t st);
-int launch_cull(const DevParams *P, const InstDesc *desc, int n_inst, int n_total, const float *wave_box,
-                const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, hipStream_t st);
-int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
-                   int n_waves, EntryArrays e, const d2 *pts, CandArrays c, hipStream_t st);
+                    EntryArrays e, CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                   const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,

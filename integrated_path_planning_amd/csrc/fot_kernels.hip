@@ -2,14 +2,15 @@
 //
 // Pipeline of one fot_plan_batch (one launch each over the whole batch; every decision in float64):
 //   k_frenet_state : 1 wave / instance: nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
-//   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t)
-//   k_evaluate     : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks;
-//                    collision points to scratch in [wave][circle][k][lane] order (coalesced 1 KiB stores)
-//                    and, per wave and time step, the float32 bounding box of those points (DPP/shuffle reduce)
-//   k_cull         : 1 wave / (instance, time step): merges the wave boxes, then compacts the obstacles of that
+//   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t), and the
+//                    float32 bounding box of the profile's lateral candidates at that sample (two end points of a
+//                    segment: the quintic is affine in its target offset)
+//   k_cull         : 1 wave / (instance, time step): merges the profile boxes, then compacts the obstacles of that
 //                    time row that lie inside the grown box into an entry list (ballot + popcount prefix)
-//   k_collide      : 1 lane / surviving candidate: walks the entry lists wave-uniformly (scalar loads,
-//                    software-prefetched), float32 broad phase, exact float64 re-check of near chunks
+//   k_evaluate     : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks, and -- while
+//                    the candidate can still pass -- the collision test of each sample against the entry list of
+//                    its time step (wave-uniform chunk walk on scalar loads, float32 broad phase, exact float64
+//                    re-check of near chunks).  Candidate points never leave registers.
 //   k_select       : 1 wave / instance: stop-distance filter, rejection histogram, first-minimum argmin
 //                    (shuffle reduction, lowest index wins ties), selected path written out
 #include <hip/hip_runtime.h>
@@ -46,34 +47,6 @@ __device__ __forceinline__ float dpp_f32(float v)
     }
 FOT_WAVE_REDUCE_F32(wave_min_f32, fminf)
 FOT_WAVE_REDUCE_F32(wave_max_f32, fmaxf)
-
-// The four box reductions of one time step as fused DPP instructions (v_min/v_max with a DPP source: one
-// instruction per butterfly step instead of v_mov_dpp + v_min).  The four chains are interleaved, so every DPP
-// read of a register is at least three VALU instructions behind its write (the DPP read-after-VALU-write
-// hazard needs two wait states and is not handled for inline asm); the leading s_nop covers the first group.
-// Masked rows of the row_bcast steps keep their value (destination tied to the source).  Lane 63 of each
-// result holds the reduction, which v_readlane returns to every lane.
-__device__ __forceinline__ void wave_reduce_box(float &x0, float &y0, float &x1, float &y1)
-{
-#define FOT_BOX_STEP(CTRL)                                                     \
-    asm volatile("s_nop 1\n\t"                                                 \
-                 "v_min_f32_dpp %0, %0, %0 " CTRL "\n\t"                        \
-                 "v_min_f32_dpp %1, %1, %1 " CTRL "\n\t"                        \
-                 "v_max_f32_dpp %2, %2, %2 " CTRL "\n\t"                        \
-                 "v_max_f32_dpp %3, %3, %3 " CTRL                                \
-                 : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1))
-    FOT_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    FOT_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    FOT_BOX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf");
-    FOT_BOX_STEP("row_mirror row_mask:0xf bank_mask:0xf");
-    FOT_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    FOT_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
-#undef FOT_BOX_STEP
-    x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0), 63));
-    y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y0), 63));
-    x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), 63));
-    y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), 63));
-}
 
 // ---------------------------------------------------------------------------
 // ego -> Frenet state
@@ -160,7 +133,8 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *
 
 __global__ void __launch_bounds__(WAVE)
 k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
-            const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, double *__restrict__ lon_tab)
+            const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, double *__restrict__ lon_tab,
+            float *__restrict__ prof_box)
 {
     const DevParams &P = *Pp;
     const int inst = blockIdx.y;
@@ -172,18 +146,20 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__r
     if (slot >= n_grid_lon + S.n_brake) return;
 
     LonInfo L;
-    if (slot < n_grid_lon) {
+    const bool brake = slot >= n_grid_lon;
+    const TimeInfo &lat_ti = brake ? P.brake[slot - n_grid_lon] : P.ti[slot / D.n_tv];
+    if (!brake) {
         const int ti = slot / D.n_tv, itv = slot - ti * D.n_tv;
         lon_coeffs(S.frenet0, tv_value(P, D, itv), P.ti[ti], L);
         L.n_t = P.ti[ti].n_t;
         L.n_eval = L.n_t;
     } else {
-        const TimeInfo &tb = P.brake[slot - n_grid_lon];
-        lon_coeffs(S.frenet0, 0.0, tb, L);
+        lon_coeffs(S.frenet0, 0.0, lat_ti, L);
         L.n_t = P.n_total;
-        L.n_eval = tb.n_t;
+        L.n_eval = lat_ti.n_t;
     }
     const int k = threadIdx.x;
+    Box32 box = box_empty();
     double *tab = lon_tab + (int64_t)(D.lon_off + slot) * (LON_FIELDS * FOT_MAX_NT);
     double jerk2 = 0.0, sd_k = 0.0;
     if (k < L.n_t) {
@@ -197,6 +173,11 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__r
         tab[9 * FOT_MAX_NT + k] = ls.inv_sd;
         jerk2 = sddd * sddd;
         sd_k = ls.sd;
+        box = profile_box(P, S.frenet0, brake, lat_ti, ls, k, L.n_eval, D.ego.x, D.ego.y);
+    }
+    if (k < P.n_total) {
+        float4 w; w.x = box.x0; w.y = box.y0; w.z = box.x1; w.w = box.y1;
+        *(float4 *)(prof_box + ((int64_t)(D.lon_off + slot) * P.n_total + k) * 4) = w;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) jerk2 += __shfl_xor(jerk2, off, WAVE);
@@ -212,49 +193,108 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__r
 // candidate evaluation
 // ---------------------------------------------------------------------------
 
-struct ScratchSink {
-    d2 *base;          // this wave's scratch + lane
-    float *wbox;       // this wave's boxes [n_total][4]
-    double ox, oy;     // instance origin
-    int n_total, lane;
-    Box32 cur;         // this lane's points of the current time step
-    __device__ __forceinline__ void put(int k, int ci, double x, double y)
-    {
-        d2 v; v.x = x; v.y = y;
-        base[((int64_t)ci * n_total + k) * WAVE] = v;
-        box_add(cur, (float)(x - ox), (float)(y - oy));
-    }
-    // every lane of the wave arrives here once per time step
-    __device__ __forceinline__ void row_done(int k)
-    {
-        float x0 = cur.x0, y0 = cur.y0, x1 = cur.x1, y1 = cur.y1;
-        wave_reduce_box(x0, y0, x1, y1);
-        if (lane == 0) {
-            float4 w; w.x = x0; w.y = y0; w.z = x1; w.w = y1;
-            *(float4 *)(wbox + 4 * k) = w;
-        }
-        cur = box_empty();
-    }
-};
+typedef float f16 __attribute__((ext_vector_type(16)));           // one chunk = 8 (x, y) pairs in 16 SGPRs
 
-struct ScratchSource {
-    const d2 *base;
-    int n_total;
-    __device__ __forceinline__ void get(int k, int ci, double &x, double &y) const
-    {
-        const d2 v = base[((int64_t)ci * n_total + k) * WAVE];
-        x = v.x; y = v.y;
+// s_load_dwordx16 of the chunk OFF bytes behind src, NOT waited for (see FusedSink::put)
+template <int OFF>
+__device__ __forceinline__ void sload_chunk(f16 &dst, const f2x8 *src)
+{
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(src), "n"(OFF) : "memory");
+}
+
+// waits for every outstanding scalar load; `c` is tied in so that its uses stay behind the wait
+__device__ __forceinline__ void swait_chunk(f16 &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c) : : "memory");
+}
+
+// smallest float32 squared distance from (fx, fy) to the 8 entries of a chunk held in SGPRs as x[8], y[8].
+// Two obstacles per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on (x_j, x_j+1) and (y_j, y_j+1).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float fy)
+{
+    const v2f px = { fx, fx }, py = { fy, fy };
+    v2f t[ENT_CHUNK / 2];
+#pragma unroll
+    for (int j = 0; j < ENT_CHUNK / 2; ++j) {
+        const v2f ox = { c[2 * j], c[2 * j + 1] }, oy = { c[8 + 2 * j], c[8 + 2 * j + 1] };
+        const v2f dx = px - ox, dy = py - oy;
+        t[j] = __builtin_elementwise_fma(dy, dy, dx * dx);
     }
-    __device__ __forceinline__ int tindex(int k) const { return k; }
+    float m = fminf(fminf(t[0].x, t[0].y), t[1].x);
+    m = fminf(fminf(m, t[1].y), t[2].x);
+    m = fminf(fminf(m, t[2].y), t[3].x);
+    return fminf(m, t[3].y);
+}
+
+// EntryCollider (fot_math.hpp) with the chunk walk on the scalar unit.  Everything that addresses the entry lists is
+// wave-uniform (instance, time step), so one chunk (8 obstacles, 64 B) is one s_load_dwordx16 shared by the 64
+// candidates of the wave; each lane keeps the float32 minimum squared distance of the chunk and only chunks that
+// come within the conservative threshold are re-checked in float64, so the decision is the reference's.
+struct FusedSink {
+    const int32_t *cnt;                  // [n_total] of this instance; nullptr: nothing to collide with
+    const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
+    const d2 *e64;
+    const uint8_t *sid;
+    int ent_cap, max_viol;
+    double ox, oy, sq_static, sq_dyn, sq_max;
+    uint64_t hit_mask;
+    int viol;
+    bool hit;
+    int n_chunks;                        // of the current time step
+
+    __device__ __forceinline__ void row_begin(int k) { n_chunks = cnt ? cnt[k] / ENT_CHUNK : 0; }
+
+    __device__ __forceinline__ void put(int k, int, double px, double py, bool alive)
+    {
+        if (n_chunks == 0) return;                                // wave-uniform
+        if (!alive || hit) return;                                // lanes whose collision outcome is already settled
+        const float fx = (float)(px - ox), fy = (float)(py - oy);
+        const float thr = filter_threshold(sq_max, fx, fy);
+        const int64_t base = (int64_t)k * ent_cap;
+        const f2x8 *row = chunks + (int64_t)k * (ent_cap / ENT_CHUNK);
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
+            const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // even: lists are padded to chunk pairs
+            const f2x8 *cp = row + c0;
+            uint32_t near_bits = 0;                               // chunk c0+i within the threshold -> bit nb-1-i
+            // Branch-free loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns out of
+            // order, so a compiler-placed wait for the chunk in use would also wait for the prefetch behind it;
+            // the loads are therefore inline asm (invisible to the waitcnt pass) and each buffer is waited for
+            // right before its own use, one chunk of arithmetic after its load was issued.  The last pair
+            // prefetches one chunk past the list (allocated slack, never used).
+            f16 ca, cb;
+            sload_chunk<0>(ca, cp);
+            swait_chunk(ca);
+            for (int c = 0; c < nb; c += 2) {
+                sload_chunk<64>(cb, cp);
+                near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(ca, fx, fy) <= thr);
+                swait_chunk(cb);
+                sload_chunk<128>(ca, cp);
+                near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(cb, fx, fy) <= thr);
+                swait_chunk(ca);
+                cp += 2;
+            }
+            while (near_bits != 0 && !hit) {                      // rare: exact float64 re-check
+                const int hb = 31 - __clz((int)near_bits);         // highest bit = earliest chunk
+                near_bits &= ~(1u << hb);
+                const int64_t e = base + (int64_t)(c0 + nb - 1 - hb) * ENT_CHUNK;
+                exact_chunk(e64 + e, sid + e, px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
+            }
+        }
+    }
+
+    __device__ __forceinline__ bool collided() const { return hit; }
 };
 
 __global__ void __launch_bounds__(256)
 k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
            const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
            const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
+           const int32_t *__restrict__ ent_cnt, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
+           const uint8_t *__restrict__ ent_sid,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
-           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep,
-           unsigned long long *__restrict__ cand_hit, d2 *__restrict__ pts, float *__restrict__ wave_box)
+           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep)
 {
     // wave index through readfirstlane: everything derived from it (instance, descriptor) is wave-uniform -> SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
@@ -266,58 +306,49 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const InstState &S = state[inst];
     const int idx = wave_base[wave] + lane;                    // candidate index inside the instance
     const int64_t slot = (int64_t)D.cand_off + idx;
-    float *wbox = wave_box + (int64_t)wave * P.n_total * 4;
-    cand_hit[slot] = 0;                                        // k_collide ORs the colliding prediction samples in
     const bool live = S.c2f_ok && idx < S.n_cand;
-    if (!__any(live)) {                                        // whole wave idle: empty boxes, padding status
-        for (int k = lane; k < P.n_total; k += WAVE) {
-            float4 w; w.x = INFINITY; w.y = INFINITY; w.z = -INFINITY; w.w = -INFINITY;
-            *(float4 *)(wbox + 4 * k) = w;
-        }
+    if (!live) {                                               // padding lane: never counted
         cand_status[slot] = 255;
         cand_keep[slot] = 0;
         return;
     }
-    // padding lanes of a partially filled wave evaluate candidate 0 (results discarded) so that the wave
-    // stays converged for the cross-lane box reduction
-    const int eidx = live ? idx : 0;
-    const CandDecode cd = decode_candidate(P, D, S.frenet0, eidx);
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
     const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
     const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
 
-    ScratchSink sink;
-    sink.base = pts + (int64_t)wave * P.n_circ * P.n_total * WAVE + lane;
-    sink.wbox = wbox;
+    FusedSink sink;
+    sink.cnt = D.ent_cap != 0 ? ent_cnt + (int64_t)inst * P.n_total : nullptr;
+    sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
+    sink.e64 = ent64 + D.ent_off;
+    sink.sid = ent_sid + D.ent_off;
+    sink.ent_cap = D.ent_cap; sink.max_viol = D.max_viol;
     sink.ox = D.ego.x; sink.oy = D.ego.y;
-    sink.n_total = P.n_total; sink.lane = lane;
-    sink.cur = box_empty();
+    sink.sq_static = P.sq_r;
+    sink.sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    sink.sq_max = sink.sq_dyn > P.sq_r ? sink.sq_dyn : P.sq_r;
+    sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0;
     CandResult r;
     evaluate_candidate(P, D, L, tab, q, P.n_total, sink, r);
-    if (live) {
-        cand_cost[slot] = r.cost;
-        cand_vlast[slot] = r.v_last;
-        cand_travel[slot] = r.travel;
-        cand_status[slot] = (uint8_t)r.status;
-        cand_keep[slot] = (uint8_t)r.keep;
-    } else {
-        cand_status[slot] = 255;                               // padding lane: never counted
-        cand_keep[slot] = 0;
-    }
+    cand_cost[slot] = r.cost;
+    cand_vlast[slot] = r.v_last;
+    cand_travel[slot] = r.travel;
+    cand_status[slot] = (uint8_t)r.status;
+    cand_keep[slot] = (uint8_t)r.keep;
 }
 
 // ---------------------------------------------------------------------------
-// collision: cull + collide
+// collision broad phase: entry lists
 // ---------------------------------------------------------------------------
 
-// One wave per (time step k = blockIdx.x, instance = blockIdx.y).  Entries of k: static obstacles first,
-// then the dynamic obstacles of time row min(k, T-1) in (sample, pedestrian) order, compacted to those inside
-// the candidates' bounding box of k grown by the collision radius, FAR32-padded to a multiple of 8.
+// One wave per (time step k, instance).  Entries of k: static obstacles first, then the dynamic obstacles of time
+// row min(k, T-1) in (sample, pedestrian) order, compacted to those inside the candidates' bounding box of k
+// (merged over the instance's longitudinal profiles) grown by the collision radius, FAR32-padded to chunk pairs.
 template <typename T>
 __global__ void __launch_bounds__(WAVE)
-k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int n_inst,
-       const float *__restrict__ wave_box, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
+k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+       int n_inst, const float *__restrict__ prof_box, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid)
 {
     const DevParams &P = *Pp;
@@ -333,11 +364,13 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
     if (inst >= n_inst || k >= P.n_total) return;
     const InstDesc &D = desc[inst];
     if (D.ent_cap == 0) return;
+    const InstState &S = state[inst];
     const int lane = threadIdx.x;
-    // box of time step k over all waves of the instance
+    // box of time step k over all longitudinal profiles of the instance
     Box32 b = box_empty();
-    for (int w = lane; w < D.n_waves; w += WAVE) {
-        const float4 v = *(const float4 *)(wave_box + ((int64_t)(D.wave0 + w) * P.n_total + k) * 4);
+    const int n_prof = S.c2f_ok ? P.n_ti * D.n_tv + S.n_brake : 0;
+    for (int w = lane; w < n_prof; w += WAVE) {
+        const float4 v = *(const float4 *)(prof_box + ((int64_t)(D.lon_off + w) * P.n_total + k) * 4);
         Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
         box_merge(b, o);
     }
@@ -347,7 +380,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
     int count = 0;
     if (b.x0 <= b.x1) {
         const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-        const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, b);
+        const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, b) + box_footprint_slack(P);
         const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
         const int n_dyn = dyn_on ? D.S * D.P : 0;
         const int total = D.n_static + n_dyn;
@@ -390,154 +423,6 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, int 
     if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = count;
 }
 
-// One workgroup = 64 candidates of one instance (lane = candidate) x COLLIDE_SLICES waves, each wave taking
-// a contiguous slice of the time steps: the per-wave dependent-load chain is a quarter as long and the
-// scheduler has four times as many waves to balance.  Time steps and entry chunks (8 obstacles = 64 B, one
-// scalar load, fetched one chunk ahead) are walked wave-uniformly; each lane keeps the float32 minimum squared
-// distance of the chunk and only chunks that come within the conservative threshold are re-checked in
-// float64, so the decision is the reference's.  Slices meet in cand_hit (per-candidate bit mask of colliding
-// prediction samples, atomicOr) and in cand_status for static hits; k_select counts the bits.
-constexpr int COLLIDE_SLICES = 4;
-
-typedef float f16 __attribute__((ext_vector_type(16)));           // one chunk = 8 (x, y) pairs in 16 SGPRs
-
-// s_load_dwordx16 of the chunk OFF bytes behind src, NOT waited for (see k_collide)
-template <int OFF>
-__device__ __forceinline__ void sload_chunk(f16 &dst, const f2x8 *src)
-{
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(src), "n"(OFF) : "memory");
-}
-
-// waits for every outstanding scalar load; `c` is tied in so that its uses stay behind the wait
-__device__ __forceinline__ void swait_chunk(f16 &c)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c) : : "memory");
-}
-
-// smallest float32 squared distance from (fx, fy) to the 8 entries of a chunk held in SGPRs as x[8], y[8].
-// Two obstacles per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on (x_j, x_j+1) and (y_j, y_j+1).
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float fy)
-{
-    const v2f px = { fx, fx }, py = { fy, fy };
-    v2f t[ENT_CHUNK / 2];
-#pragma unroll
-    for (int j = 0; j < ENT_CHUNK / 2; ++j) {
-        const v2f ox = { c[2 * j], c[2 * j + 1] }, oy = { c[8 + 2 * j], c[8 + 2 * j + 1] };
-        const v2f dx = px - ox, dy = py - oy;
-        t[j] = __builtin_elementwise_fma(dy, dy, dx * dx);
-    }
-    float m = fminf(fminf(t[0].x, t[0].y), t[1].x);
-    m = fminf(fminf(m, t[1].y), t[2].x);
-    m = fminf(fminf(m, t[2].y), t[3].x);
-    return fminf(m, t[3].y);
-}
-
-// ABLATE != 0 builds are timing-only diagnostics (wrong results), selected with FOT_COLLIDE_ABLATE:
-//   1 no chunk loads after the first   2 no distance arithmetic   4 no point loads   8 empty time-step loop
-template <int ABLATE>
-__global__ void __launch_bounds__(COLLIDE_SLICES * WAVE)
-k_collide(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
-          const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
-          const int32_t *__restrict__ ent_cnt, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
-          const uint8_t *__restrict__ ent_sid, const d2 *__restrict__ pts,
-          uint8_t *__restrict__ cand_status, const uint8_t *__restrict__ cand_keep,
-          unsigned long long *__restrict__ cand_hit)
-{
-    const int wave = blockIdx.x;                                  // candidate wave (uniform by construction)
-    if (wave >= n_waves) return;
-    const int slice = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const int lane = threadIdx.x & (WAVE - 1);
-    const DevParams &P = *Pp;
-    const int inst = wave_inst[wave];
-    const InstDesc &D = desc[inst];
-    if (D.ent_cap == 0) return;
-    const int n_total = P.n_total;
-    const int slice_len = (n_total + COLLIDE_SLICES - 1) / COLLIDE_SLICES;
-    const int k_begin = slice * slice_len;
-    const int k_end_slice = k_begin + slice_len < n_total ? k_begin + slice_len : n_total;
-    const int64_t slot = (int64_t)D.cand_off + wave_base[wave] + lane;
-    const bool pending = cand_status[slot] == ST_PENDING;
-    const int keep = pending ? (int)cand_keep[slot] : 0;
-    int kmax = keep;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, WAVE));
-    kmax = __builtin_amdgcn_readfirstlane(kmax);
-    const int k_end = kmax < k_end_slice ? kmax : k_end_slice;
-    if (k_begin >= k_end) return;
-
-    const int n_circ = P.has_footprint ? P.n_circ : 1;
-    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
-    const double ox0 = D.ego.x, oy0 = D.ego.y;
-    const d2 *my_pts = pts + (int64_t)wave * P.n_circ * n_total * WAVE + lane;
-    const int32_t *cnt = ent_cnt + (int64_t)inst * n_total;
-    const int ent_cap = D.ent_cap, max_viol = D.max_viol;
-
-    bool collided = false, static_hit = false;
-    uint64_t hit_mask = 0;
-    int viol = 0;
-    d2 p_next = my_pts[(int64_t)k_begin * WAVE];                  // point of (k_begin, circle 0), prefetched
-    for (int k = k_begin; k < k_end; ++k) {
-        const bool act = !collided && k < keep;
-        if (!__any(act)) break;                                   // keep is fixed: no lane can become active later
-        const int n = cnt[k];
-        const int64_t base = D.ent_off + (int64_t)k * ent_cap;
-        const f2x8 *chunks = (const f2x8 *)(ent32 + base);
-        const int n_chunks = n / ENT_CHUNK;
-        for (int ci = 0; ci < n_circ; ++ci) {
-            const d2 p = p_next;
-            if (!(ABLATE & 4)) {   // prefetch the next point (next circle, or circle 0 of the next time step)
-                const int cn = ci + 1 < n_circ ? ci + 1 : 0;
-                const int kn = ci + 1 < n_circ ? k : (k + 1 < n_total ? k + 1 : k);
-                p_next = my_pts[((int64_t)cn * n_total + kn) * WAVE];
-            }
-            if (n_chunks == 0 || (ABLATE & 8)) continue;
-            const float fx = (float)(p.x - ox0), fy = (float)(p.y - oy0);
-            const float thr = filter_threshold(sq_max, fx, fy);
-            for (int c0 = 0; c0 < n_chunks; c0 += 32) {            // 32 chunks per pass: one bit per chunk and lane
-                const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // even: lists are padded to chunk pairs
-                const f2x8 *cp = chunks + c0;
-                uint32_t near_bits = 0;                            // chunk c0+i within the threshold -> bit nb-1-i
-                // Branch-free hot loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns
-                // out of order, so a compiler-placed wait for the chunk in use would also wait for the prefetch
-                // behind it; the loads are therefore inline asm (invisible to the waitcnt pass) and each buffer
-                // is waited for right before its own use, one chunk of arithmetic after its load was issued.
-                // The last pair prefetches one chunk past the list (allocated slack, never used).
-                f16 ca, cb;
-                sload_chunk<0>(ca, cp);
-                swait_chunk(ca);
-                for (int c = 0; c < nb; c += 2) {
-                    if (!(ABLATE & 1)) sload_chunk<64>(cb, cp);
-                    if (!(ABLATE & 2)) near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(ca, fx, fy) <= thr);
-                    if (!(ABLATE & 1)) swait_chunk(cb); else cb = ca;
-                    if (!(ABLATE & 1)) sload_chunk<128>(ca, cp);
-                    if (!(ABLATE & 2)) near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(cb, fx, fy) <= thr);
-                    if (!(ABLATE & 1)) swait_chunk(ca);
-                    cp += 2;
-                }
-                if (!act || collided) near_bits = 0;
-                if (__any(near_bits != 0)) {                       // rare: exact float64 re-check, lane by lane
-                    while (near_bits != 0 && !collided) {
-                        const int hb = 31 - __clz((int)near_bits);  // highest bit = earliest chunk
-                        near_bits &= ~(1u << hb);
-                        const int64_t e = base + (int64_t)(c0 + nb - 1 - hb) * ENT_CHUNK;
-                        bool hard = false;
-                        exact_chunk(ent64 + e, ent_sid + e, p.x, p.y, P.sq_r, sq_dyn, max_viol, hit_mask, viol, hard);
-                        if (hard) {                                // static obstacle, or more samples than allowed
-                            collided = true;
-                            if (viol <= max_viol) static_hit = true;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (pending && hit_mask != 0) atomicOr(cand_hit + slot, (unsigned long long)hit_mask);
-    if (pending && static_hit) cand_status[slot] = FOT_ST_COLLISION;
-}
-
 // ---------------------------------------------------------------------------
 // selection + output
 // ---------------------------------------------------------------------------
@@ -547,8 +432,7 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
          const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
          const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
          const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
-         const uint8_t *__restrict__ cand_keep, const unsigned long long *__restrict__ cand_hit,
-         fot_result *__restrict__ out, int n_inst)
+         const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
 {
     const int inst = blockIdx.x;
     if (inst >= n_inst) return;
@@ -577,8 +461,6 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
     for (int idx = lane; idx < S.n_cand; idx += WAVE) {
         const int64_t slot = (int64_t)D.cand_off + idx;
         int st = cand_status[slot];
-        // chance constraint over the prediction samples that hit (frenet_planner.py:1113-1124)
-        if (st == ST_PENDING && D.ent_cap != 0 && __popcll(cand_hit[slot]) > D.max_viol) st = FOT_ST_COLLISION;
         st = final_status(st, cand_vlast[slot], cand_travel[slot], D.max_stop);
         cand_status[slot] = (uint8_t)st;
 #pragma unroll
@@ -877,63 +759,42 @@ int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc,
 }
 
 int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                     LonInfo *lon_info, double *lon_tab, int n_inst, int max_lon, hipStream_t st)
+                     LonInfo *lon_info, double *lon_tab, float *prof_box, int n_inst, int max_lon, hipStream_t st)
 {
     if (n_inst <= 0 || max_lon <= 0) return 0;
     dim3 grid((unsigned)max_lon, (unsigned)n_inst);
-    k_lon_table<<<grid, WAVE, 0, st>>>(P, sp, desc, state, lon_info, lon_tab);
+    k_lon_table<<<grid, WAVE, 0, st>>>(P, sp, desc, state, lon_info, lon_tab, prof_box);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
-                    const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
-                    CandArrays c, d2 *pts, float *wave_box, hipStream_t st)
-{
-    if (n_waves <= 0) return 0;
-    const int wpb = 256 / WAVE;
-    k_evaluate<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, state, lon_info, lon_tab, wave_inst, wave_base,
-                                                         n_waves, c.cost, c.v_last, c.travel, c.status, c.keep, c.hit,
-                                                         pts, wave_box);
-    FOT_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_cull(const DevParams *P, const InstDesc *desc, int n_inst, int n_total, const float *wave_box,
-                const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, hipStream_t st)
+int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
+                const float *prof_box, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
+                hipStream_t st)
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
     const int groups = (n_total + 7) / 8;
     const int64_t q_pad = ((int64_t)n_inst * groups + 7) / 8 * 8;          // groups, padded so that every XCD slot exists
     const unsigned grid = (unsigned)(q_pad * 8);
     if (dtype == FOT_F32)
-        k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, n_inst, wave_box, (const float *)static_xy,
+        k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const float *)static_xy,
                                              (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid);
     else
-        k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, n_inst, wave_box, (const double *)static_xy,
+        k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const double *)static_xy,
                                               (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_collide(const DevParams *P, const InstDesc *desc, const int32_t *wave_inst, const int32_t *wave_base,
-                   int n_waves, EntryArrays e, const d2 *pts, CandArrays c, hipStream_t st)
+int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+                    const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
+                    EntryArrays e, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
-    static const int ablate = getenv("FOT_COLLIDE_ABLATE") ? atoi(getenv("FOT_COLLIDE_ABLATE")) : 0;
-#define FOT_COLLIDE_LAUNCH(A) k_collide<A><<<n_waves, COLLIDE_SLICES * WAVE, 0, st>>>( \
-        P, desc, wave_inst, wave_base, n_waves, e.cnt, e.e32, e.e64, e.sid, pts, c.status, c.keep, c.hit)
-    switch (ablate) {
-    case 1: FOT_COLLIDE_LAUNCH(1); break;
-    case 2: FOT_COLLIDE_LAUNCH(2); break;
-    case 3: FOT_COLLIDE_LAUNCH(3); break;
-    case 4: FOT_COLLIDE_LAUNCH(4); break;
-    case 7: FOT_COLLIDE_LAUNCH(7); break;
-    case 8: FOT_COLLIDE_LAUNCH(8); break;
-    case 12: FOT_COLLIDE_LAUNCH(12); break;
-    default: FOT_COLLIDE_LAUNCH(0); break;
-    }
-#undef FOT_COLLIDE_LAUNCH
+    const int wpb = 256 / WAVE;
+    k_evaluate<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, state, lon_info, lon_tab, wave_inst, wave_base,
+                                                         n_waves, e.cnt, e.e32, e.e64, e.sid, c.cost, c.v_last,
+                                                         c.travel, c.status, c.keep);
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -943,7 +804,7 @@ int launch_select(const DevParams *P, const InstDesc *desc, const InstState *sta
 {
     if (n_inst <= 0) return 0;
     k_select<<<n_inst, WAVE, 0, st>>>(P, desc, state, lon_info, lon_tab, c.cost, c.v_last, c.travel, c.status,
-                                     c.keep, c.hit, out, n_inst);
+                                     c.keep, out, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }

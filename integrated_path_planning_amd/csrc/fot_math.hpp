@@ -426,9 +426,11 @@ FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d,
     }
 }
 
-// Sink::put(k, circle, x, y) receives the collision points of the kept prefix; Sink::row_done(k) is
-// called once per time step by EVERY lane of the wave (n_loop is wave-uniform, >= n_t), so that it
-// may use cross-lane operations.
+// Sink protocol (every call site is reached with a wave-uniform k):
+//   row_begin(k)                  once per time step, by every lane of the wave (n_loop is wave-uniform, >= n_t)
+//   put(k, circle, x, y, alive)   collision point of sample k of the kept prefix; alive == false when the candidate
+//                                 has already failed a check, i.e. can no longer end as "collision check outstanding"
+// and collided() tells whether the points handed over so far violate the (chance) constraint.
 template <class Sink>
 FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const double *lon_tab,
                                const double *q, int n_loop, Sink &sink, CandResult &out)
@@ -442,6 +444,7 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
     check_init(acc);
 
     for (int k = 0; k < n_loop; ++k) {
+      sink.row_begin(k);
       if (k < n_t) {
         double d, d_d, d_dd, d_ddd;
         lat_sample(q, k, L.n_eval, P.dt, d, d_d, d_dd, d_ddd);
@@ -459,16 +462,17 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
             ps.v = c.v; ps.a = c.a; ps.d = d; ps.s = ls.s;
             check_sample(P, D, acc, k, ps, true, true);
             if (k == 0) s_first = ls.s;
+            const bool alive = !singular && acc.finite_ok
+                               && !(acc.f_speed || acc.f_accel || acc.f_curv || acc.f_lat || acc.f_road);
             if (P.has_footprint) {
                 for (int ci = 0; ci < P.n_circ; ++ci)
-                    sink.put(k, ci, c.x + P.circ_off[ci] * c.cos_t, c.y + P.circ_off[ci] * c.sin_t);
+                    sink.put(k, ci, c.x + P.circ_off[ci] * c.cos_t, c.y + P.circ_off[ci] * c.sin_t, alive);
             } else {
-                sink.put(k, 0, c.x, c.y);
+                sink.put(k, 0, c.x, c.y, alive);
             }
             v_last = c.v; s_last = ls.s;
         }
       }
-      sink.row_done(k);
     }
 
     int keep = n_t;
@@ -482,7 +486,8 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
     const double lon = P.k_j * L.Js + P.k_t * Jt + P.k_s_dot * (dv * dv);
     out.cost = P.k_lat * lat + P.k_lon * lon;
 
-    const int st = check_status(D, acc, keep);
+    int st = check_status(D, acc, keep);
+    if (st == ST_PENDING && sink.collided()) st = FOT_ST_COLLISION;       // only candidates that pass everything else
     out.status = st;
     out.keep = keep;
     out.v_last = v_last;
@@ -593,6 +598,35 @@ FOT_HD bool cull_inside(const Box32 &b, float m, float fx, float fy)
     return fx >= b.x0 - m && fx <= b.x1 + m && fy >= b.y0 - m && fy <= b.y1 + m;
 }
 
+// Bounding box (float32, instance-local frame) of the sample-k points of ALL lateral candidates of one
+// longitudinal profile.  The quintic is affine in its target offset di (lat_coeffs), so at a fixed time the
+// candidates' points lie on the segment of the path normal between the two extreme offsets; brake-ladder
+// profiles have the single offset d0.  Footprint circle centres lie within max|circ_off| of these points, which
+// box_footprint_slack() adds to the cull margin.  NaN points (beyond the path end) are never kept and are skipped.
+FOT_HD Box32 profile_box(const DevParams &P, const double *fr, bool brake, const TimeInfo &ti, const LonSample &ls,
+                         int k, int n_eval, double ox, double oy)
+{
+    Box32 b = box_empty();
+    const int n_side = brake ? 1 : 2;
+    for (int e = 0; e < n_side; ++e) {
+        const double di = brake ? fr[3] : (e == 0 ? -(double)P.n_side : (double)(P.n_di - 1 - P.n_side)) * P.d_road_w;
+        double q[6], d, u0, u1, u2;
+        lat_coeffs(fr, di, ti, q);
+        lat_sample(q, k, n_eval, P.dt, d, u0, u1, u2);
+        const double x = ls.rx - ls.sin_r * d, y = ls.ry + ls.cos_r * d;
+        if (x == x && y == y) box_add(b, (float)(x - ox), (float)(y - oy));
+    }
+    return b;
+}
+
+FOT_HD float box_footprint_slack(const DevParams &P)
+{
+    float m = 0.0f;
+    if (P.has_footprint)
+        for (int c = 0; c < P.n_circ; ++c) m = fmaxf(m, (float)fabs(P.circ_off[c]) * 1.000001f);
+    return m;
+}
+
 constexpr int ENT_CHUNK = 8;                                                // entries per broad-phase chunk
 constexpr int SID_STATIC = 255;                                             // entry is a static obstacle
 // float32 entries are stored chunk-wise as structure of arrays, x[8] then y[8] (64 B): neighbouring
@@ -646,34 +680,42 @@ FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py,
     }
 }
 
-// per-candidate check against the culled entry lists (same decision as collide_candidate)
-// cnt[k]: entries of time step k (multiple of 8); entry arrays hold D.ent_cap slots per k
-template <class Source>
-FOT_HD bool collide_entries(const DevParams &P, const InstDesc &D, const int32_t *cnt, const f2 *e32, const d2 *e64,
-                            const uint8_t *sid, int keep, const Source &src)
-{
-    const int n_circ = P.has_footprint ? P.n_circ : 1;
-    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
-    uint64_t hit_mask = 0;
-    int viol = 0;
-    bool collided = false;
-    for (int k = 0; k < keep && !collided; ++k) {
+// Collision state of one candidate, fed sample by sample from evaluate_candidate and tested against the culled
+// entry lists of its instance (same decision as collide_candidate).  cnt[k]: entries of time step k (multiple of 8);
+// the entry arrays hold ent_cap slots per k.  This is the portable form; k_evaluate's sink is the same logic with
+// the chunk walk on scalar loads.
+struct EntryCollider {
+    const int32_t *cnt;                  // [n_total] of this instance, nullptr: no obstacles
+    const f2 *e32; const d2 *e64; const uint8_t *sid;                       // of this instance
+    int ent_cap, max_viol;
+    double ox, oy, sq_static, sq_dyn, sq_max;
+    uint64_t hit_mask;
+    int viol;
+    bool hit;
+    FOT_HD void init(const DevParams &P, const InstDesc &D)
+    {
+        ent_cap = D.ent_cap; max_viol = D.max_viol;
+        ox = D.ego.x; oy = D.ego.y;
+        sq_static = P.sq_r;
+        sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+        sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
+        hit_mask = 0; viol = 0; hit = false;
+    }
+    FOT_HD void row_begin(int) {}
+    FOT_HD void put(int k, int, double px, double py, bool alive)
+    {
+        if (!cnt || !alive || hit) return;
         const int n = cnt[k];
-        const int64_t base = (int64_t)k * D.ent_cap;
-        for (int ci = 0; ci < n_circ && !collided; ++ci) {
-            double px, py;
-            src.get(k, ci, px, py);
-            const float fx = (float)(px - D.ego.x), fy = (float)(py - D.ego.y);
-            const float thr = filter_threshold(sq_max, fx, fy);
-            for (int c = 0; c < n && !collided; c += ENT_CHUNK) {
-                if (min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy) > thr) continue;
-                exact_chunk(e64 + base + c, sid + base + c, px, py, P.sq_r, sq_dyn, D.max_viol, hit_mask, viol, collided);
-            }
+        const int64_t base = (int64_t)k * ent_cap;
+        const float fx = (float)(px - ox), fy = (float)(py - oy);
+        const float thr = filter_threshold(sq_max, fx, fy);
+        for (int c = 0; c < n && !hit; c += ENT_CHUNK) {
+            if (min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy) > thr) continue;
+            exact_chunk(e64 + base + c, sid + base + c, px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
         }
     }
-    return collided;
-}
+    FOT_HD bool collided() const { return hit; }
+};
 
 // ---------------------------------------------------------------------------
 // selection (reference: frenet_planner.py:307-324, 1235-1259)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Kernel trace + HBM counters of the default bench workload, on the GPU box.  Three separate rocprofv3 runs
+# (kernel trace; FETCH_SIZE; WRITE_SIZE -- the two TCC counters do not fit one pass), the program itself after `--`.
+# Outputs under gpurun_out/prof_<tag>/; scripts/pmc_summary.py condenses them into profiles/.
+set -e
+TAG=${1:-run}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+ARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency --no-parity"
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 $ARGS > "$OUT/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o run -- python3 $ARGS > "$OUT/fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o run -- python3 $ARGS > "$OUT/write.log" 2>&1
+python3 scripts/pmc_summary.py "$OUT" "$TAG"

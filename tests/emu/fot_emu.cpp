@@ -17,15 +17,12 @@
 using namespace fot;
 
 namespace {
+// records the collision points of a candidate; never reports a collision (kinematic status only)
 struct VecSink {
-    std::vector<d2> *pts; int n_total; double ox, oy;
-    std::vector<Box32> *boxes;                      // per time step, merged over all candidates of the instance
-    void put(int k, int ci, double x, double y)
-    {
-        d2 v; v.x = x; v.y = y; (*pts)[(size_t)ci * n_total + k] = v;
-        box_add((*boxes)[k], (float)(x - ox), (float)(y - oy));
-    }
-    void row_done(int) {}
+    std::vector<d2> *pts; int n_total;
+    void row_begin(int) {}
+    void put(int k, int ci, double x, double y, bool) { d2 v; v.x = x; v.y = y; (*pts)[(size_t)ci * n_total + k] = v; }
+    bool collided() const { return false; }
 };
 struct VecSource {
     const d2 *pts; int n_total;
@@ -88,6 +85,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         }
         // --- k_lon_table
         const int n_grid_lon = P.n_ti * D.n_tv;
+        std::vector<Box32> boxes((size_t)P.n_total, box_empty());           // k_lon_table: per profile, merged by k_cull
         for (int slot = 0; slot < n_grid_lon + S.n_brake; ++slot) {
             LonInfo Li;
             if (slot < n_grid_lon) {
@@ -101,9 +99,12 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             }
             double *tab = lon_tab.data() + (size_t)(D.lon_off + slot) * (LON_FIELDS * FOT_MAX_NT);
             double js = 0.0, sd_last = 0.0;
+            const bool brake = slot >= n_grid_lon;
+            const TimeInfo &lat_ti = brake ? P.brake[slot - n_grid_lon] : P.ti[slot / D.n_tv];
             for (int k = 0; k < Li.n_t; ++k) {
                 LonSample ls; double sddd;
                 make_lon_sample(sp, Li, k, P.dt, ls, sddd);
+                box_merge(boxes[k], profile_box(P, S.frenet0, brake, lat_ti, ls, k, Li.n_eval, D.ego.x, D.ego.y));
                 tab[0 * FOT_MAX_NT + k] = ls.s; tab[1 * FOT_MAX_NT + k] = ls.sd; tab[2 * FOT_MAX_NT + k] = ls.sdd;
                 tab[3 * FOT_MAX_NT + k] = ls.rx; tab[4 * FOT_MAX_NT + k] = ls.ry;
                 tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
@@ -112,22 +113,6 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             }
             Li.Js = js; Li.sd_last = sd_last;
             lon_info[D.lon_off + slot] = Li;
-        }
-        // --- k_evaluate: every candidate, points kept per candidate, boxes merged per time step
-        const size_t per_cand = (size_t)P.n_circ * P.n_total;
-        std::vector<d2> all_pts(per_cand * (size_t)std::max(S.n_cand, 1));
-        std::vector<Box32> boxes((size_t)P.n_total, box_empty());
-        std::vector<CandResult> res((size_t)std::max(S.n_cand, 1));
-        std::vector<d2> pts(per_cand);
-        for (int idx = 0; idx < S.n_cand; ++idx) {
-            const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
-            const LonInfo &Li = lon_info[D.lon_off + cd.lon_slot];
-            const double *tab = lon_tab.data() + (size_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
-            double q[6];
-            lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
-            VecSink sink = { &pts, P.n_total, D.ego.x, D.ego.y, &boxes };
-            evaluate_candidate(P, D, Li, tab, q, P.n_total, sink, res[idx]);
-            std::copy(pts.begin(), pts.end(), all_pts.begin() + per_cand * idx);
         }
         // --- k_cull: entry lists per time step
         ObstacleView obs;
@@ -147,7 +132,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             for (int k = 0; k < P.n_total; ++k) {
                 const Box32 &bx = boxes[k];
                 if (!(bx.x0 <= bx.x1)) continue;
-                const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, bx);
+                const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, bx) + box_footprint_slack(P);
                 const int n_dyn = D.dyn_mode != FOT_DYN_NONE ? D.S * D.P : 0;
                 const int row = k < D.T - 1 ? k : D.T - 1;
                 int count = 0;
@@ -164,19 +149,36 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 cnt[k] = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);
             }
         }
-        // --- k_collide + k_select
+        // --- k_evaluate (collision test inside, against the entry lists) + k_select
+        const size_t per_cand = (size_t)P.n_circ * P.n_total;
+        std::vector<d2> pts(per_cand);
         int cnt_st[8] = { 0 };
         ScanBest best = { INFINITY, -1 };
         int best_keep = 0;
         for (int idx = 0; idx < S.n_cand; ++idx) {
-            const CandResult &r = res[idx];
-            int st = r.status;
-            if (st == ST_PENDING && D.ent_cap > 0) {
-                VecSource src = { all_pts.data() + per_cand * idx, P.n_total };
-                const bool hit = collide_entries(P, D, cnt.data(), e32.data(), e64.data(), sid.data(), r.keep, src);
-                if (hit != collide_candidate(P, D, obs, r.keep, src)) return -100;   // broad phase vs definition
-                if (hit) st = FOT_ST_COLLISION;
+            const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+            const LonInfo &Li = lon_info[D.lon_off + cd.lon_slot];
+            const double *tab = lon_tab.data() + (size_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+            double q[6];
+            lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+            EntryCollider ec;
+            ec.init(P, D);
+            ec.cnt = D.ent_cap > 0 ? cnt.data() : nullptr;
+            ec.e32 = e32.data(); ec.e64 = e64.data(); ec.sid = sid.data();
+            CandResult r;
+            evaluate_candidate(P, D, Li, tab, q, P.n_total, ec, r);
+            {   // broad phase + in-loop test vs the definition on the recorded points
+                VecSink vs = { &pts, P.n_total };
+                CandResult rk;
+                evaluate_candidate(P, D, Li, tab, q, P.n_total, vs, rk);
+                int want = rk.status;
+                if (want == ST_PENDING && D.ent_cap > 0) {
+                    VecSource src = { pts.data(), P.n_total };
+                    if (collide_candidate(P, D, obs, rk.keep, src)) want = FOT_ST_COLLISION;
+                }
+                if (want != r.status || rk.keep != r.keep) return -100;
             }
+            int st = r.status;
             st = final_status(st, r.v_last, r.travel, D.max_stop);
             if (st < 8) cnt_st[st]++;
             if (idx < cand_cap && inst == 0) {
