@@ -67,13 +67,13 @@ struct Workspace {
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
     DevBuf dState, dLonInfo, dLonTab;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
-    DevBuf dProfBox, dEntCnt, dEnt32, dEnt64, dEntSid;   // broad phase: profile boxes + culled entry lists
+    DevBuf dProfBox, dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: profile boxes + culled entry lists
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
         DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dLonTab, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
-                           &dProfBox, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
+                           &dProfBox, &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
         for (DevBuf *b : bufs) b->release();
         staging.release();
         if (staging_done) (void)hipEventDestroy(staging_done);
@@ -82,7 +82,7 @@ struct Workspace {
     }
 };
 
-constexpr int FOT_LANES = 4;                  // lanes available; lanes_cfg of them are used (FOT_LANES env, default 2)
+constexpr int FOT_LANES = 4;                  // lanes available; lanes_cfg of them are used (FOT_LANES env, default 1)
 constexpr int FOT_SPLIT_MIN_INSTANCES = 32;  // smaller batches run as one piece on the caller's stream
 
 struct fot_handle {
@@ -96,7 +96,7 @@ struct fot_handle {
     DevBuf dSpline;
     bool has_path = false;
     Workspace ws[FOT_LANES];
-    int lanes_cfg = 2;                       // sub-batches a large batch is split into
+    int lanes_cfg = 1;                       // sub-batches a large batch is split into
     int lanes_used = 0;                      // lanes of the most recent plan call
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
@@ -238,6 +238,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
     HIP_TRY(h, w.dEnt64.ensure(sizeof(d2) * n_ent));
     HIP_TRY(h, w.dEntSid.ensure(n_ent));
+    HIP_TRY(h, w.dWaveRng.ensure(sizeof(uint32_t) * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
 
     HIP_TRY(h, hipMemcpyAsync(w.dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipEventRecord(w.staging_done, st));
@@ -254,7 +255,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
 
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
-    ea.sid = w.dEntSid.as<uint8_t>();
+    ea.sid = w.dEntSid.as<uint8_t>(); ea.rng = w.dWaveRng.as<uint32_t>();
     {
         ProfScope ps(h, 0, st);
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, st));
@@ -272,7 +273,8 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     {
         ProfScope ps(h, 3, st);
         LAUNCH_TRY(h, launch_evaluate(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                      w.dLonTab.as<double>(), d_wave_inst, d_wave_base, L.n_waves, ea, ca, st));
+                                      w.dLonTab.as<double>(), (int)L.n_lon, P.n_total, d_wave_inst, d_wave_base,
+                                      L.n_waves, ea, ca, st));
     }
     {
         ProfScope ps(h, 4, st);

@@ -18,6 +18,7 @@ struct EntryArrays {
     f2 *e32;           // instance-local float32 coordinates
     d2 *e64;           // exact coordinates
     uint8_t *sid;      // prediction sample of the entry, SID_STATIC for static obstacles
+    uint32_t *rng;     // [n_waves][n_total] chunk range of each candidate wave: c_lo << 16 | c_hi
 };
 
 // every launcher returns 0 or the hipError_t of the launch
@@ -29,8 +30,8 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
                 const float *prof_box, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
                 hipStream_t st);
 int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
-                    const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
-                    EntryArrays e, CandArrays c, hipStream_t st);
+                    const double *lon_tab, int n_lon, int n_total, const int32_t *wave_inst,
+                    const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
                   const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,

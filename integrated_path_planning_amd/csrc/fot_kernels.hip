@@ -232,28 +232,55 @@ __device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float 
 // wave-uniform (instance, time step), so one chunk (8 obstacles, 64 B) is one s_load_dwordx16 shared by the 64
 // candidates of the wave; each lane keeps the float32 minimum squared distance of the chunk and only chunks that
 // come within the conservative threshold are re-checked in float64, so the decision is the reference's.
+// Scalar registers are the scarce resource of k_evaluate (two 16-register chunk buffers): the sink keeps only
+// what the per-chunk loop needs, the exact re-check fetches its constants where it runs.
 struct FusedSink {
-    const int32_t *cnt;                  // [n_total] of this instance; nullptr: nothing to collide with
+    const DevParams *Pp;
+    const InstDesc *Dp;
+    const uint32_t *rng;                 // [n_total] strip ranges of this wave; nullptr: nothing to collide with
     const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
     const d2 *e64;
     const uint8_t *sid;
-    int ent_cap, max_viol;
-    double ox, oy, sq_static, sq_dyn, sq_max;
+    int chunks_per_k;                    // ent_cap / 8
+    double oxd, oyd;
+    FilterConst fc;
     uint64_t hit_mask;
     int viol;
     bool hit;
-    int n_chunks;                        // of the current time step
+    int c_lo, n_chunks;                  // chunk range of the current time step
+    uint32_t pf;                         // destination of the warm-up loads below, reserved until they have landed
 
-    __device__ __forceinline__ void row_begin(int k) { n_chunks = cnt ? cnt[k] / ENT_CHUNK : 0; }
+    // Reads the range of time step k and touches the first cache lines of its chunks, so that they are on their
+    // way into the scalar cache while the sample arithmetic runs.  The loads are hand-issued and their (unused)
+    // destination register stays tied to the sink until pf_wait(): a scalar load retires at any later time, and
+    // must not land in a register the compiler has meanwhile given to something else.
+    __device__ __forceinline__ void row_begin(int k)
+    {
+        const uint32_t r = rng ? rng[k] : 0u;
+        c_lo = (int)(r >> 16);
+        n_chunks = (int)(r & 0xffffu) - c_lo;
+        if (n_chunks > 0) {
+            const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
+            asm volatile("s_load_dword %0, %1, 0x0\n\t"
+                         "s_load_dword %0, %1, 0x40\n\t"
+                         "s_load_dword %0, %1, 0x80\n\t"
+                         "s_load_dword %0, %1, 0xc0"
+                         : "=s"(pf) : "s"(row) : "memory");
+        } else {
+            pf = 0;
+        }
+    }
+
+    // end of the time step, reached by every lane: the warm-up loads have landed, pf may be reused
+    __device__ __forceinline__ void row_end(int) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf) : : "memory"); }
 
     __device__ __forceinline__ void put(int k, int, double px, double py, bool alive)
     {
         if (n_chunks == 0) return;                                // wave-uniform
         if (!alive || hit) return;                                // lanes whose collision outcome is already settled
-        const float fx = (float)(px - ox), fy = (float)(py - oy);
-        const float thr = filter_threshold(sq_max, fx, fy);
-        const int64_t base = (int64_t)k * ent_cap;
-        const f2x8 *row = chunks + (int64_t)k * (ent_cap / ENT_CHUNK);
+        const float fx = (float)(px - oxd), fy = (float)(py - oyd);
+        const float thr = filter_threshold(fc, fx, fy);
+        const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
         for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
             const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // even: lists are padded to chunk pairs
             const f2x8 *cp = row + c0;
@@ -275,32 +302,85 @@ struct FusedSink {
                 swait_chunk(ca);
                 cp += 2;
             }
-            while (near_bits != 0 && !hit) {                      // rare: exact float64 re-check
-                const int hb = 31 - __clz((int)near_bits);         // highest bit = earliest chunk
-                near_bits &= ~(1u << hb);
-                const int64_t e = base + (int64_t)(c0 + nb - 1 - hb) * ENT_CHUNK;
-                exact_chunk(e64 + e, sid + e, px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
-            }
+            if (near_bits != 0) exact(k, c0, nb, near_bits, px, py);
+        }
+    }
+
+    // rare: exact float64 re-check of the chunks whose float32 distance came within the threshold
+    __device__ __forceinline__ void exact(int k, int c0, int nb, uint32_t near_bits, double px, double py)
+    {
+        const DevParams &P = *Pp;
+        const InstDesc &D = *Dp;
+        const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+        const int64_t base = ((int64_t)k * chunks_per_k + c_lo) * ENT_CHUNK;
+        while (near_bits != 0 && !hit) {
+            const int hb = 31 - __clz((int)near_bits);             // highest bit = earliest chunk
+            near_bits &= ~(1u << hb);
+            const int64_t e = base + (int64_t)(c0 + nb - 1 - hb) * ENT_CHUNK;
+            exact_chunk(e64 + e, sid + e, px, py, P.sq_r, sq_dyn, D.max_viol, hit_mask, viol, hit);
         }
     }
 
     __device__ __forceinline__ bool collided() const { return hit; }
 };
 
-__global__ void __launch_bounds__(256)
+// Longitudinal tables of the block's candidates, staged in LDS: the 64 candidates of a wave share two or three
+// longitudinal profiles, whose rows every sample step would otherwise fetch from L2/HBM (two dependent round
+// trips per step).  Layout [profile][k][field]: one row is 80 contiguous bytes.
+constexpr int EVAL_WG = 256;
+constexpr int EVAL_LDS_PROFILES = 10;                             // 256 candidates / 29 offsets per profile + 1
+extern __shared__ double s_lon[];
+
+struct StagedTab {
+    int lds_row0;                        // index of this lane's profile row 0 in s_lon, or -1: not staged
+    const double *glob;                  // [field][FOT_MAX_NT] in HBM
+    __device__ __forceinline__ void load(int k, LonSample &L) const
+    {
+        if (lds_row0 >= 0) {
+            const double *r = s_lon + lds_row0 + k * LON_FIELDS;
+            L.s = r[0]; L.sd = r[1]; L.sdd = r[2]; L.rx = r[3]; L.ry = r[4];
+            L.cos_r = r[5]; L.sin_r = r[6]; L.kr = r[7]; L.dkr = r[8]; L.inv_sd = r[9];
+        } else {
+            load_lon_sample(glob, k, L);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(EVAL_WG)
 k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-           const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
+           const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab, int n_lon,
            const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
-           const int32_t *__restrict__ ent_cnt, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
+           const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
            const uint8_t *__restrict__ ent_sid,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
            uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep)
 {
+    const DevParams &P = *Pp;
+    const int n_total = P.n_total;
+    // --- stage the profiles [g_lo, g_lo + EVAL_LDS_PROFILES) of the global profile index space; g_lo is the
+    //     profile of the block's first candidate (block-uniform)
+    const int wave_first = blockIdx.x * (EVAL_WG / WAVE);
+    int g_lo = 0;
+    {
+        const int inst0 = wave_inst[wave_first];                  // wave_first < n_waves by construction of the grid
+        const InstDesc &D0 = desc[inst0];
+        const InstState &S0 = state[inst0];
+        const int idx0 = wave_base[wave_first];
+        g_lo = D0.lon_off + (S0.c2f_ok && idx0 < S0.n_cand ? decode_candidate(P, D0, S0.frenet0, idx0).lon_slot : 0);
+    }
+    const int n_stage = n_lon - g_lo < EVAL_LDS_PROFILES ? n_lon - g_lo : EVAL_LDS_PROFILES;
+    const int per_prof = LON_FIELDS * n_total;
+    for (int i = threadIdx.x; i < n_stage * per_prof; i += EVAL_WG) {
+        const int p = i / per_prof, rem = i - p * per_prof;
+        const int f = rem / n_total, k = rem - f * n_total;       // k fastest: coalesced reads of one field
+        s_lon[(p * n_total + k) * LON_FIELDS + f] = lon_tab[((int64_t)(g_lo + p) * LON_FIELDS + f) * FOT_MAX_NT + k];
+    }
+    __syncthreads();
+
     // wave index through readfirstlane: everything derived from it (instance, descriptor) is wave-uniform -> SGPRs
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(wave_first + (threadIdx.x / WAVE)));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & (WAVE - 1);
-    const DevParams &P = *Pp;
     const int inst = wave_inst[wave];
     const InstDesc &D = desc[inst];
     const InstState &S = state[inst];
@@ -313,24 +393,27 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
         return;
     }
     const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
-    const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
-    const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+    const int g = D.lon_off + cd.lon_slot;
+    const LonInfo L = lon_info[g];
+    StagedTab tab;
+    tab.lds_row0 = (unsigned)(g - g_lo) < (unsigned)n_stage ? (g - g_lo) * n_total * LON_FIELDS : -1;
+    tab.glob = lon_tab + (int64_t)g * (LON_FIELDS * FOT_MAX_NT);
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
 
     FusedSink sink;
-    sink.cnt = D.ent_cap != 0 ? ent_cnt + (int64_t)inst * P.n_total : nullptr;
+    sink.Pp = Pp; sink.Dp = &D;
+    sink.rng = D.ent_cap != 0 ? wave_rng + (int64_t)wave * n_total : nullptr;
     sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
     sink.e64 = ent64 + D.ent_off;
     sink.sid = ent_sid + D.ent_off;
-    sink.ent_cap = D.ent_cap; sink.max_viol = D.max_viol;
-    sink.ox = D.ego.x; sink.oy = D.ego.y;
-    sink.sq_static = P.sq_r;
-    sink.sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    sink.sq_max = sink.sq_dyn > P.sq_r ? sink.sq_dyn : P.sq_r;
-    sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0;
+    sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
+    sink.oxd = D.ego.x; sink.oyd = D.ego.y;
+    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    sink.fc = filter_const(sq_dyn > P.sq_r ? sq_dyn : P.sq_r);
+    sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
     CandResult r;
-    evaluate_candidate(P, D, L, tab, q, P.n_total, sink, r);
+    evaluate_candidate(P, D, L, tab, q, n_total, sink, r);
     cand_cost[slot] = r.cost;
     cand_vlast[slot] = r.v_last;
     cand_travel[slot] = r.travel;
@@ -342,15 +425,24 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 // collision broad phase: entry lists
 // ---------------------------------------------------------------------------
 
-// One wave per (time step k, instance).  Entries of k: static obstacles first, then the dynamic obstacles of time
-// row min(k, T-1) in (sample, pedestrian) order, compacted to those inside the candidates' bounding box of k
-// (merged over the instance's longitudinal profiles) grown by the collision radius, FAR32-padded to chunk pairs.
+// One wave per (time step k, instance).  Entries of k: the static obstacles and the dynamic obstacles of time row
+// min(k, T-1) that lie inside the candidates' bounding box of k (merged over the instance's longitudinal profiles)
+// grown by the collision radius, ordered by bin along the longer side of the box (counting sort through LDS
+// atomics), FAR32-padded to chunk pairs.  Then, per candidate wave of the instance, the chunk range its own
+// profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
+constexpr int CULL_CACHE = 4096;
+constexpr uint8_t BIN_OUT = 255;
+
 template <typename T>
 __global__ void __launch_bounds__(WAVE)
 k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
        int n_inst, const float *__restrict__ prof_box, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
-       int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid)
+       int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
+       uint32_t *__restrict__ wave_rng)
 {
+    __shared__ int s_cnt[CULL_BINS + 1];                         // pass 1: entries per bin; pass 2: write cursors
+    __shared__ int s_start[CULL_BINS + 1];
+    __shared__ uint8_t s_bin[CULL_CACHE];                        // bin of obstacle i (BIN_OUT: culled), first CULL_CACHE
     const DevParams &P = *Pp;
     // XCD-aware block -> (instance, time step) map.  Workgroups are dealt round-robin over the 8 XCDs
     // (blocks b and b+8 share one), and 8 consecutive time steps of one pedestrian share a cache line of
@@ -366,61 +458,112 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     if (D.ent_cap == 0) return;
     const InstState &S = state[inst];
     const int lane = threadIdx.x;
+    const int n_grid_lon = P.n_ti * D.n_tv;
     // box of time step k over all longitudinal profiles of the instance
     Box32 b = box_empty();
-    const int n_prof = S.c2f_ok ? P.n_ti * D.n_tv + S.n_brake : 0;
+    const int n_prof = S.c2f_ok ? n_grid_lon + S.n_brake : 0;
+    const float *pbox = prof_box + ((int64_t)D.lon_off * P.n_total + k) * 4;      // + slot * n_total * 4
     for (int w = lane; w < n_prof; w += WAVE) {
-        const float4 v = *(const float4 *)(prof_box + ((int64_t)(D.lon_off + w) * P.n_total + k) * 4);
+        const float4 v = *(const float4 *)(pbox + (int64_t)w * P.n_total * 4);
         Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
         box_merge(b, o);
     }
     b.x0 = wave_min_f32(b.x0); b.y0 = wave_min_f32(b.y0);
     b.x1 = wave_max_f32(b.x1); b.y1 = wave_max_f32(b.y1);
     const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
-    int count = 0;
-    if (b.x0 <= b.x1) {
-        const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-        const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, b) + box_footprint_slack(P);
-        const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
-        const int n_dyn = dyn_on ? D.S * D.P : 0;
-        const int total = D.n_static + n_dyn;
-        const int row = k < D.T - 1 ? k : D.T - 1;
-        for (int i0 = 0; i0 < total; i0 += WAVE) {
-            const int i = i0 + lane;
-            bool inside = false;
-            d2 o; o.x = 0.0; o.y = 0.0;
-            int sid = SID_STATIC;
-            if (i < total) {
-                if (i < D.n_static) {
-                    const int64_t in = D.static_off + i;
-                    o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
-                } else {
-                    const int j = i - D.n_static;                 // j = s*P + p
-                    const int64_t in = D.dyn_off + (int64_t)j * D.T + row;
-                    o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
-                    sid = j / D.P;
-                }
-                inside = cull_inside(b, margin, (float)(o.x - D.ego.x), (float)(o.y - D.ego.y));
-            }
-            const unsigned long long mask = __ballot(inside);
-            if (inside) {
-                const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-                ent32_store(ent32, base + pos, (float)(o.x - D.ego.x), (float)(o.y - D.ego.y));
-                ent64[base + pos] = o;
-                ent_sid[base + pos] = (uint8_t)sid;
-            }
-            count += __popcll(mask);
-        }
-        const int padded = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);   // whole chunk pairs (k_collide)
-        if (lane < padded - count) {
-            d2 o; o.x = INFINITY; o.y = INFINITY;
-            ent32_store(ent32, base + count + lane, FAR32, FAR32);
-            ent64[base + count + lane] = o;
-            ent_sid[base + count + lane] = SID_STATIC;
-        }
-        count = padded;
+    uint32_t *rng = wave_rng + (int64_t)D.wave0 * P.n_total + k;                  // + wave * n_total
+    if (!(b.x0 <= b.x1)) {                                       // no candidate has a sample k
+        if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = 0;
+        for (int w = lane; w < D.n_waves; w += WAVE) rng[(int64_t)w * P.n_total] = 0u;
+        return;
     }
-    if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = count;
+    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
+    const float slack = box_footprint_slack(P);
+    const float margin = cull_margin(sq_max, b) + slack;
+    const BinMap bm = bin_map(b, margin);
+    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
+    const int n_dyn = dyn_on ? D.S * D.P : 0;
+    const int total = D.n_static + n_dyn;
+    const int row = k < D.T - 1 ? k : D.T - 1;
+    if (lane <= CULL_BINS) s_cnt[lane] = 0;
+    __syncthreads();
+    // obstacle i of this time step: exact coordinates, sample id, float32 local coordinates, inside test, bin
+    auto fetch = [&](int i, d2 &o, int &sid, float &fx, float &fy, int &bin) -> bool {
+        o.x = 0.0; o.y = 0.0; sid = SID_STATIC; fx = 0.0f; fy = 0.0f; bin = 0;
+        if (i >= total) return false;
+        if (i < D.n_static) {
+            const int64_t in = D.static_off + i;
+            o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
+        } else {
+            const int j = i - D.n_static;                         // j = s*P + p
+            const int64_t in = D.dyn_off + (int64_t)j * D.T + row;
+            o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
+            sid = j / D.P;
+        }
+        fx = (float)(o.x - D.ego.x); fy = (float)(o.y - D.ego.y);
+        if (!cull_inside(b, margin, fx, fy)) return false;
+        bin = bin_of(bm, fx, fy);
+        return true;
+    };
+    for (int i0 = 0; i0 < total; i0 += WAVE) {                   // pass 1: histogram
+        d2 o; int sid, bin; float fx, fy;
+        const bool in = fetch(i0 + lane, o, sid, fx, fy, bin);
+        if (in) atomicAdd(&s_cnt[bin], 1);
+        if (i0 + lane < CULL_CACHE) s_bin[i0 + lane] = in ? (uint8_t)bin : BIN_OUT;
+    }
+    __syncthreads();
+    // exclusive prefix over the bins (lane = bin; lane CULL_BINS ends with the total)
+    int c = lane < CULL_BINS ? s_cnt[lane] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int t = __shfl_up(incl, off, WAVE);
+        if (lane >= off) incl += t;
+    }
+    const int start = incl - c;                                  // lanes >= CULL_BINS: total
+    __syncthreads();
+    if (lane <= CULL_BINS) { s_start[lane] = start; s_cnt[lane] = start; }
+    __syncthreads();
+    const int count = s_start[CULL_BINS];
+    for (int i0 = 0; i0 < total; i0 += WAVE) {                   // pass 2: scatter (order inside a bin is irrelevant)
+        d2 o; int sid, bin; float fx, fy;
+        const int i = i0 + lane;
+        if (i < CULL_CACHE && (i >= total || s_bin[i] == BIN_OUT)) continue;      // culled in pass 1: nothing to read
+        if (fetch(i, o, sid, fx, fy, bin)) {
+            const int pos = atomicAdd(&s_cnt[bin], 1);
+            ent32_store(ent32, base + pos, fx, fy);
+            ent64[base + pos] = o;
+            ent_sid[base + pos] = (uint8_t)sid;
+        }
+    }
+    const int padded = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);        // whole chunk pairs (k_evaluate)
+    if (lane < padded - count) {
+        d2 o; o.x = INFINITY; o.y = INFINITY;
+        ent32_store(ent32, base + count + lane, FAR32, FAR32);
+        ent64[base + count + lane] = o;
+        ent_sid[base + count + lane] = SID_STATIC;
+    }
+    if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = padded;
+    // chunk range of every candidate wave of the instance
+    for (int w = lane; w < D.n_waves; w += WAVE) {
+        uint32_t r = 0u;
+        const int idx0 = w * WAVE;
+        if (idx0 < S.n_cand) {
+            const int idx1 = idx0 + WAVE - 1 < S.n_cand - 1 ? idx0 + WAVE - 1 : S.n_cand - 1;
+            int s0, s1;
+            wave_profile_span(P, D, n_grid_lon, idx0, idx1, s0, s1);
+            Box32 wb = box_empty();
+            for (int sl = s0; sl <= s1; ++sl) {
+                const float4 v = *(const float4 *)(pbox + (int64_t)sl * P.n_total * 4);
+                Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
+                box_merge(wb, o);
+            }
+            const float wm = cull_margin(sq_max, wb) + slack;
+            r = strip_range(bm, wb, wm, [&](int bb) { return s_start[bb]; });
+        }
+        rng[(int64_t)w * P.n_total] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -778,23 +921,24 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
     const unsigned grid = (unsigned)(q_pad * 8);
     if (dtype == FOT_F32)
         k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const float *)static_xy,
-                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid);
+                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng);
     else
         k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const double *)static_xy,
-                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid);
+                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
-                    const double *lon_tab, const int32_t *wave_inst, const int32_t *wave_base, int n_waves,
-                    EntryArrays e, CandArrays c, hipStream_t st)
+                    const double *lon_tab, int n_lon, int n_total, const int32_t *wave_inst,
+                    const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
-    const int wpb = 256 / WAVE;
-    k_evaluate<<<(n_waves + wpb - 1) / wpb, 256, 0, st>>>(P, desc, state, lon_info, lon_tab, wave_inst, wave_base,
-                                                         n_waves, e.cnt, e.e32, e.e64, e.sid, c.cost, c.v_last,
-                                                         c.travel, c.status, c.keep);
+    const int wpb = EVAL_WG / WAVE;
+    const size_t lds = sizeof(double) * EVAL_LDS_PROFILES * LON_FIELDS * (size_t)n_total;
+    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, desc, state, lon_info, lon_tab, n_lon, wave_inst,
+                                                                wave_base, n_waves, e.rng, e.e32, e.e64, e.sid,
+                                                                c.cost, c.v_last, c.travel, c.status, c.keep);
     FOT_LAUNCH_CHECK();
     return 0;
 }

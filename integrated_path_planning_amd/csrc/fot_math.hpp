@@ -357,47 +357,56 @@ struct PathSample {
     double x, y, cos_t, sin_t, kappa, v, a, d, s;
 };
 
+// The per-candidate flags live in ONE per-lane word (bit per flag) rather than in one wave mask each: eleven
+// 64-bit lane masks would not fit the scalar register file next to the collision chunk buffers of k_evaluate.
+enum : uint32_t {
+    CK_NONFINITE = 1u, CK_NANSTEP = 2u, CK_SPEED = 4u, CK_ACCEL = 8u, CK_CURV = 16u, CK_LAT = 32u, CK_ROAD = 64u,
+    CK_SINGULAR = 128u, CK_SEEN_NAN = 256u,
+    CK_FAILED = CK_NONFINITE | CK_SPEED | CK_ACCEL | CK_CURV | CK_LAT | CK_ROAD | CK_SINGULAR
+};
+
 struct CheckAcc {
-    bool finite_ok, nan_step, f_speed, f_accel, f_curv, f_lat, f_road;
+    uint32_t fl;                         // CK_* bits
     double max_step2;                    // largest squared step between consecutive samples
     PathSample prev;
 };
 
 FOT_HD void check_init(CheckAcc &c)
 {
-    c.finite_ok = true; c.nan_step = false;
-    c.f_speed = c.f_accel = c.f_curv = c.f_lat = c.f_road = false;
+    c.fl = 0;
     c.max_step2 = -INFINITY;
     c.prev.x = c.prev.y = c.prev.kappa = c.prev.v = c.prev.a = c.prev.d = c.prev.s = 0.0;
     c.prev.cos_t = 1.0; c.prev.sin_t = 0.0;
 }
+
+FOT_HD void check_flag(CheckAcc &c, bool cond, uint32_t bit) { c.fl |= cond ? bit : 0u; }
 
 // k = index of the sample inside the path; has_geo / has_d: the low-speed rules and the road test
 // only apply when the caller's path carries the arrays they read (:1013-1022, :982)
 FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int k, const PathSample &p,
                          bool has_geo, bool has_d)
 {
-    if (!(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa))) c.finite_ok = false;        // :944-946
+    check_flag(c, !(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa)), CK_NONFINITE);     // :944-946
     if (k > 0) {
         const double sx = p.x - c.prev.x, sy = p.y - c.prev.y;                                // :953-956
         const double step2 = sx * sx + sy * sy;
-        if (isnan(step2)) c.nan_step = true;
+        check_flag(c, isnan(step2), CK_NANSTEP);
         if (step2 > c.max_step2) c.max_step2 = step2;
-        if (p.v > D.lim_speed) c.f_speed = true;                                              // :964
-        if (fabs(p.a) > D.lim_accel) c.f_accel = true;                                        // :966
+        check_flag(c, p.v > D.lim_speed, CK_SPEED);                                           // :964
+        check_flag(c, fabs(p.a) > D.lim_accel, CK_ACCEL);                                     // :966
         if (p.v > 0.5) {                                                                       // LOW_SPEED_CURVATURE_GATE
-            if (fabs(p.kappa) > D.lim_curv) c.f_curv = true;
+            check_flag(c, fabs(p.kappa) > D.lim_curv, CK_CURV);
         } else if (has_geo) {
             const double dd = fabs(p.d - c.prev.d);
             const double d_s = fabs(p.s - c.prev.s);
-            if (dd > fmax(1.5 * d_s, 0.02)) c.f_curv = true;                                  // lateral slip
+            check_flag(c, dd > fmax(1.5 * d_s, 0.02), CK_CURV);                               // lateral slip
             const double sn = p.sin_t * c.prev.cos_t - p.cos_t * c.prev.sin_t;                // sin/cos of the yaw step
             const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
             const double dyaw = fabs(atan2(sn, cs));
-            if (dyaw > fmax(D.lim_curv * sqrt(step2), 0.1)) c.f_curv = true;                  // yaw-step cap
+            check_flag(c, dyaw > fmax(D.lim_curv * sqrt(step2), 0.1), CK_CURV);               // yaw-step cap
         }
-        if (p.v * p.v * fabs(p.kappa) > D.lim_lat) c.f_lat = true;                            // :975
-        if (has_d && fabs(p.d) > P.max_road_width + 1e-9) c.f_road = true;                    // :982
+        check_flag(c, p.v * p.v * fabs(p.kappa) > D.lim_lat, CK_LAT);                         // :975
+        check_flag(c, has_d && fabs(p.d) > P.max_road_width + 1e-9, CK_ROAD);                 // :982
     }
     c.prev = p;
 }
@@ -405,12 +414,13 @@ FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int
 // first failing category in the reference's order; ST_PENDING = collision check outstanding
 FOT_HD int check_status(const InstDesc &D, const CheckAcc &c, int keep)
 {
-    if (keep == 0 || !c.finite_ok || (!c.nan_step && sqrt(c.max_step2) > D.step_limit)) return FOT_ST_DROPPED;
-    if (c.f_speed) return FOT_ST_SPEED;
-    if (c.f_accel) return FOT_ST_ACCEL;
-    if (c.f_curv) return FOT_ST_CURVATURE;
-    if (c.f_lat) return FOT_ST_LAT_ACCEL;
-    if (c.f_road) return FOT_ST_ROAD;
+    if (keep == 0 || (c.fl & CK_NONFINITE) || (!(c.fl & CK_NANSTEP) && sqrt(c.max_step2) > D.step_limit))
+        return FOT_ST_DROPPED;
+    if (c.fl & CK_SPEED) return FOT_ST_SPEED;
+    if (c.fl & CK_ACCEL) return FOT_ST_ACCEL;
+    if (c.fl & CK_CURV) return FOT_ST_CURVATURE;
+    if (c.fl & CK_LAT) return FOT_ST_LAT_ACCEL;
+    if (c.fl & CK_ROAD) return FOT_ST_ROAD;
     return ST_PENDING;
 }
 
@@ -427,17 +437,22 @@ FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d,
 }
 
 // Sink protocol (every call site is reached with a wave-uniform k):
-//   row_begin(k)                  once per time step, by every lane of the wave (n_loop is wave-uniform, >= n_t)
+//   row_begin(k), row_end(k)      once per time step, by every lane of the wave (n_loop is wave-uniform, >= n_t)
 //   put(k, circle, x, y, alive)   collision point of sample k of the kept prefix; alive == false when the candidate
 //                                 has already failed a check, i.e. can no longer end as "collision check outstanding"
 // and collided() tells whether the points handed over so far violate the (chance) constraint.
-template <class Sink>
-FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const double *lon_tab,
+// Tab::load(k, LonSample&) returns row k of the candidate's longitudinal table (GlobalTab: straight from HBM).
+struct GlobalTab {
+    const double *tab;
+    FOT_HD void load(int k, LonSample &L) const { load_lon_sample(tab, k, L); }
+};
+
+template <class Tab, class Sink>
+FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
                                const double *q, int n_loop, Sink &sink, CandResult &out)
 {
     const int n_t = L.n_t;
     double Jp = 0.0, d_last = 0.0;
-    bool singular = false, seen_nan = false;
     int first_nan = -1;
     double v_last = 0.0, s_last = 0.0, s_first = 0.0;
     CheckAcc acc;
@@ -451,19 +466,18 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
         Jp += d_ddd * d_ddd;
         d_last = d;
         LonSample ls;
-        load_lon_sample(lon_tab, k, ls);
+        lon_tab.load(k, ls);
         CartSample c;
         frenet_to_cart(ls, d, d_d, d_dd, c);
-        if (isfinite(c.omkd) && c.omkd <= 0.05) singular = true;        // SINGULARITY_EPS, any sample
-        if (!seen_nan && isnan(c.x)) { seen_nan = true; first_nan = k; }
-        if (!seen_nan) {
+        check_flag(acc, isfinite(c.omkd) && c.omkd <= 0.05, CK_SINGULAR);   // SINGULARITY_EPS, any sample
+        if (!(acc.fl & CK_SEEN_NAN) && isnan(c.x)) { acc.fl |= CK_SEEN_NAN; first_nan = k; }
+        if (!(acc.fl & CK_SEEN_NAN)) {
             PathSample ps;
             ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
             ps.v = c.v; ps.a = c.a; ps.d = d; ps.s = ls.s;
             check_sample(P, D, acc, k, ps, true, true);
             if (k == 0) s_first = ls.s;
-            const bool alive = !singular && acc.finite_ok
-                               && !(acc.f_speed || acc.f_accel || acc.f_curv || acc.f_lat || acc.f_road);
+            const bool alive = (acc.fl & CK_FAILED) == 0;
             if (P.has_footprint) {
                 for (int ci = 0; ci < P.n_circ; ++ci)
                     sink.put(k, ci, c.x + P.circ_off[ci] * c.cos_t, c.y + P.circ_off[ci] * c.sin_t, alive);
@@ -473,11 +487,12 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
             v_last = c.v; s_last = ls.s;
         }
       }
+      sink.row_end(k);
     }
 
     int keep = n_t;
-    if (seen_nan) keep = first_nan >= 2 ? first_nan : 0;
-    if (singular) keep = 0;
+    if (acc.fl & CK_SEEN_NAN) keep = first_nan >= 2 ? first_nan : 0;
+    if (acc.fl & CK_SINGULAR) keep = 0;
 
     const double Jd = d_last * d_last;
     const double dv = D.target_speed - L.sd_last;
@@ -487,7 +502,7 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
     out.cost = P.k_lat * lat + P.k_lon * lon;
 
     int st = check_status(D, acc, keep);
-    if (st == ST_PENDING && sink.collided()) st = FOT_ST_COLLISION;       // only candidates that pass everything else
+    if (st == ST_PENDING && sink.collided()) st = FOT_ST_COLLISION;       // only candidates that pass everything else       // only candidates that pass everything else
     out.status = st;
     out.keep = keep;
     out.v_last = v_last;
@@ -627,7 +642,61 @@ FOT_HD float box_footprint_slack(const DevParams &P)
     return m;
 }
 
-constexpr int ENT_CHUNK = 8;                                                // entries per broad-phase chunk
+// ---- strips: entry lists are ordered by bin along the longer side of the box, so that the 64 candidates of one
+// wave (two or three neighbouring longitudinal profiles: a short stretch of road) only walk the chunks of the bins
+// their own points can reach.  bin_of() is monotone in the coordinate, which is all the range argument needs.
+constexpr int CULL_BINS = 32;
+constexpr int ENT_CHUNK_ = 8;                                               // == ENT_CHUNK (declared below)
+
+struct BinMap {
+    int axis;                            // 0: bins along x, 1: along y
+    float lo, inv_w;
+};
+
+FOT_HD BinMap bin_map(const Box32 &b, float margin)
+{
+    BinMap m;
+    m.axis = (b.y1 - b.y0) > (b.x1 - b.x0) ? 1 : 0;
+    const float lo = (m.axis ? b.y0 : b.x0) - margin, hi = (m.axis ? b.y1 : b.x1) + margin;
+    m.lo = lo;
+    m.inv_w = (float)CULL_BINS / fmaxf(hi - lo, 1e-6f);
+    return m;
+}
+
+FOT_HD int bin_of_value(const BinMap &m, float v)
+{
+    const float t = (v - m.lo) * m.inv_w;
+    return t >= (float)(CULL_BINS - 1) ? CULL_BINS - 1 : (t > 0.0f ? (int)t : 0);
+}
+
+FOT_HD int bin_of(const BinMap &m, float x, float y) { return bin_of_value(m, m.axis ? y : x); }
+
+// Chunk range [c_lo, c_hi) of a list ordered by bin (bin_start[b] = first entry of bin b, bin_start[CULL_BINS] =
+// entries) that holds every entry a point of box `wb` could touch; both ends even (k_evaluate walks chunk pairs)
+// and within the pair-padded list.  Packed as c_lo << 16 | c_hi; 0 = nothing to test.
+template <class StartFn>
+FOT_HD uint32_t strip_range(const BinMap &m, const Box32 &wb, float margin, const StartFn &bin_start)
+{
+    if (!(wb.x0 <= wb.x1)) return 0u;
+    const float lo = (m.axis ? wb.y0 : wb.x0) - margin, hi = (m.axis ? wb.y1 : wb.x1) + margin;
+    const int b_lo = bin_of_value(m, lo), b_hi = bin_of_value(m, hi);
+    const int e_lo = bin_start(b_lo), e_hi = bin_start(b_hi + 1);
+    if (e_hi <= e_lo) return 0u;
+    const int c_lo = (e_lo / ENT_CHUNK_) & ~1, c_hi = ((e_hi + ENT_CHUNK_ - 1) / ENT_CHUNK_ + 1) & ~1;
+    return ((uint32_t)c_lo << 16) | (uint32_t)c_hi;
+}
+
+// longitudinal-profile slots [first, last] covered by the candidates [idx0, idx1] of an instance
+FOT_HD void wave_profile_span(const DevParams &P, const InstDesc &D, int n_tv_grid_lon, int idx0, int idx1,
+                              int &first, int &last)
+{
+    const int per_prof = P.n_di;
+    first = idx0 < D.n_grid ? idx0 / per_prof : n_tv_grid_lon + (idx0 - D.n_grid);
+    last = idx1 < D.n_grid ? idx1 / per_prof : n_tv_grid_lon + (idx1 - D.n_grid);
+}
+
+constexpr int ENT_CHUNK = 8;
+static_assert(ENT_CHUNK == 8, "strip_range assumes 8-entry chunks");                                                // entries per broad-phase chunk
 constexpr int SID_STATIC = 255;                                             // entry is a static obstacle
 // float32 entries are stored chunk-wise as structure of arrays, x[8] then y[8] (64 B): neighbouring
 // obstacles sit in neighbouring registers, which is what the packed-float32 arithmetic of k_collide wants
@@ -658,12 +727,20 @@ FOT_HD float min_sqdist32_8(const f2x8 &c, float fx, float fy)
 // Rounding the two points to float32 moves each coordinate difference by at most
 // 2^-24 (2|p| + R + |d|); with |d| <= R = sqrt(sq) the squared distance moves by less than
 // 4 (R+1) e, e = 2^-23 (|px| + |py| + 2R + 6); the three float32 roundings of the sum add 2^-22 relative.
-FOT_HD float filter_threshold(double sq, float px, float py)
+struct FilterConst { float sq, r; };       // (float)sq and sqrt((float)sq) + 1, fixed per instance
+
+FOT_HD FilterConst filter_const(double sq)
 {
-    const float r = sqrtf((float)sq) + 1.0f;
-    const float e = (fabsf(px) + fabsf(py) + 2.0f * r + 4.0f) * 1.1920929e-7f;
-    return ((float)sq + 4.0f * r * e) * 1.000002f + 1e-30f;
+    FilterConst f; f.sq = (float)sq; f.r = sqrtf((float)sq) + 1.0f; return f;
 }
+
+FOT_HD float filter_threshold(const FilterConst &f, float px, float py)
+{
+    const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 4.0f) * 1.1920929e-7f;
+    return (f.sq + 4.0f * f.r * e) * 1.000002f + 1e-30f;
+}
+
+FOT_HD float filter_threshold(double sq, float px, float py) { return filter_threshold(filter_const(sq), px, py); }
 
 // exact float64 test of one chunk (the reference's test); updates the per-sample hit state
 FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py, double sq_static, double sq_dyn,
@@ -685,7 +762,7 @@ FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py,
 // the entry arrays hold ent_cap slots per k.  This is the portable form; k_evaluate's sink is the same logic with
 // the chunk walk on scalar loads.
 struct EntryCollider {
-    const int32_t *cnt;                  // [n_total] of this instance, nullptr: no obstacles
+    const uint32_t *rng;                 // [n_total] strip ranges of this candidate's wave, nullptr: no obstacles
     const f2 *e32; const d2 *e64; const uint8_t *sid;                       // of this instance
     int ent_cap, max_viol;
     double ox, oy, sq_static, sq_dyn, sq_max;
@@ -702,14 +779,15 @@ struct EntryCollider {
         hit_mask = 0; viol = 0; hit = false;
     }
     FOT_HD void row_begin(int) {}
+    FOT_HD void row_end(int) {}
     FOT_HD void put(int k, int, double px, double py, bool alive)
     {
-        if (!cnt || !alive || hit) return;
-        const int n = cnt[k];
+        if (!rng || !alive || hit) return;
+        const int c_lo = (int)(rng[k] >> 16), c_hi = (int)(rng[k] & 0xffffu);
         const int64_t base = (int64_t)k * ent_cap;
         const float fx = (float)(px - ox), fy = (float)(py - oy);
         const float thr = filter_threshold(sq_max, fx, fy);
-        for (int c = 0; c < n && !hit; c += ENT_CHUNK) {
+        for (int c = c_lo * ENT_CHUNK; c < c_hi * ENT_CHUNK && !hit; c += ENT_CHUNK) {
             if (min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy) > thr) continue;
             exact_chunk(e64 + base + c, sid + base + c, px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
         }

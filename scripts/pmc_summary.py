@@ -56,6 +56,16 @@ def main():
         pmc[k] = {"launches_fetch_pass": fetch.get(k, (0, 0))[1], "launches_write_pass": write.get(k, (0, 0))[1],
                   "FETCH_SIZE_bytes_per_launch": fb, "WRITE_SIZE_bytes_per_launch": wb}
         traffic[k] = {"fetch_bytes_reported": fb, "write_bytes": wb, "hbm_bytes_gfx950_corrected": 2.0 * fb + wb}
+    for path in glob.glob(os.path.join(root, "sq", "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                if k.startswith("k_"):
+                    a = acc[k][row["Counter_Name"]]
+                    a[0] += float(row["Counter_Value"]); a[1] += 1
+        for k, cs in acc.items():
+            pmc.setdefault(k, {}).update({c: v[0] / v[1] for c, v in cs.items() if v[1]})
     json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))

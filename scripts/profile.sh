@@ -9,7 +9,8 @@ mkdir -p "$OUT"
 ARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency --no-parity"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run -- python3 $ARGS > "$OUT/trace.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o run -- python3 $ARGS > "$OUT/fetch.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o run -- python3 $ARGS > "$OUT/write.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 $ARGS > "$OUT/trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- python3 $ARGS > "$OUT/fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- python3 $ARGS > "$OUT/write.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d "$OUT/sq" -o run -- python3 $ARGS > "$OUT/sq.log" 2>&1
 python3 scripts/pmc_summary.py "$OUT" "$TAG"

@@ -21,6 +21,7 @@ namespace {
 struct VecSink {
     std::vector<d2> *pts; int n_total;
     void row_begin(int) {}
+    void row_end(int) {}
     void put(int k, int ci, double x, double y, bool) { d2 v; v.x = x; v.y = y; (*pts)[(size_t)ci * n_total + k] = v; }
     bool collided() const { return false; }
 };
@@ -86,6 +87,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         // --- k_lon_table
         const int n_grid_lon = P.n_ti * D.n_tv;
         std::vector<Box32> boxes((size_t)P.n_total, box_empty());           // k_lon_table: per profile, merged by k_cull
+        std::vector<Box32> pbox((size_t)(n_grid_lon + S.n_brake + 1) * P.n_total, box_empty());
         for (int slot = 0; slot < n_grid_lon + S.n_brake; ++slot) {
             LonInfo Li;
             if (slot < n_grid_lon) {
@@ -104,7 +106,8 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             for (int k = 0; k < Li.n_t; ++k) {
                 LonSample ls; double sddd;
                 make_lon_sample(sp, Li, k, P.dt, ls, sddd);
-                box_merge(boxes[k], profile_box(P, S.frenet0, brake, lat_ti, ls, k, Li.n_eval, D.ego.x, D.ego.y));
+                pbox[(size_t)slot * P.n_total + k] = profile_box(P, S.frenet0, brake, lat_ti, ls, k, Li.n_eval, D.ego.x, D.ego.y);
+                box_merge(boxes[k], pbox[(size_t)slot * P.n_total + k]);
                 tab[0 * FOT_MAX_NT + k] = ls.s; tab[1 * FOT_MAX_NT + k] = ls.sd; tab[2 * FOT_MAX_NT + k] = ls.sdd;
                 tab[3 * FOT_MAX_NT + k] = ls.rx; tab[4 * FOT_MAX_NT + k] = ls.ry;
                 tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
@@ -127,26 +130,51 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         std::vector<f2> e32(cap * P.n_total + 16, farq);
         std::vector<d2> e64(cap * P.n_total + 16, infq);
         std::vector<uint8_t> sid(cap * P.n_total + 16, SID_STATIC);
+        const int n_waves_inst = (S.n_cand + WAVE - 1) / WAVE;
+        std::vector<uint32_t> rng((size_t)std::max(n_waves_inst, 1) * P.n_total, 0u);
         if (D.ent_cap > 0) {
             const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+            const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
             for (int k = 0; k < P.n_total; ++k) {
                 const Box32 &bx = boxes[k];
                 if (!(bx.x0 <= bx.x1)) continue;
-                const float margin = cull_margin(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, bx) + box_footprint_slack(P);
+                const float margin = cull_margin(sq_max, bx) + box_footprint_slack(P);
+                const BinMap bm = bin_map(bx, margin);
                 const int n_dyn = D.dyn_mode != FOT_DYN_NONE ? D.S * D.P : 0;
                 const int row = k < D.T - 1 ? k : D.T - 1;
-                int count = 0;
+                struct Ent { d2 o; float fx, fy; int sid, bin; };
+                std::vector<Ent> ents;
                 for (int i = 0; i < D.n_static + n_dyn; ++i) {
-                    d2 o; int sd = SID_STATIC;
-                    if (i < D.n_static) o = obs.static_at(i);
-                    else { const int j = i - D.n_static; o = obs.dyn_at(j / D.P, j % D.P, row, D.P, D.T); sd = j / D.P; }
-                    const float fx = (float)(o.x - D.ego.x), fy = (float)(o.y - D.ego.y);
-                    if (!cull_inside(bx, margin, fx, fy)) continue;
-                    ent32_store(e32.data(), (int64_t)cap * k + count, fx, fy);
-                    e64[cap * k + count] = o; sid[cap * k + count] = (uint8_t)sd;
-                    ++count;
+                    Ent e; e.sid = SID_STATIC;
+                    if (i < D.n_static) e.o = obs.static_at(i);
+                    else { const int j = i - D.n_static; e.o = obs.dyn_at(j / D.P, j % D.P, row, D.P, D.T); e.sid = j / D.P; }
+                    e.fx = (float)(e.o.x - D.ego.x); e.fy = (float)(e.o.y - D.ego.y);
+                    if (!cull_inside(bx, margin, e.fx, e.fy)) continue;
+                    e.bin = bin_of(bm, e.fx, e.fy);
+                    ents.push_back(e);
                 }
+                std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.bin < b.bin; });
+                int bin_start[CULL_BINS + 1];
+                for (int b = 0, i = 0; b <= CULL_BINS; ++b) {
+                    while (i < (int)ents.size() && ents[i].bin < b) ++i;
+                    bin_start[b] = i;
+                }
+                for (size_t i = 0; i < ents.size(); ++i) {
+                    ent32_store(e32.data(), (int64_t)cap * k + (int64_t)i, ents[i].fx, ents[i].fy);
+                    e64[cap * k + i] = ents[i].o; sid[cap * k + i] = (uint8_t)ents[i].sid;
+                }
+                const int count = (int)ents.size();
                 cnt[k] = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);
+                for (int w = 0; w < n_waves_inst; ++w) {
+                    int s0, s1;
+                    wave_profile_span(P, D, n_grid_lon, w * WAVE, std::min(w * WAVE + WAVE - 1, S.n_cand - 1), s0, s1);
+                    Box32 wb = box_empty();
+                    for (int sl = s0; sl <= s1; ++sl) box_merge(wb, pbox[(size_t)sl * P.n_total + k]);
+                    const float wm = cull_margin(sq_max, wb) + box_footprint_slack(P);
+                    const uint32_t r = strip_range(bm, wb, wm, [&](int b) { return bin_start[b]; });
+                    if ((int)(r & 0xffffu) * ENT_CHUNK > cnt[k]) return -101;          // range must stay inside the padded list
+                    rng[(size_t)w * P.n_total + k] = r;
+                }
             }
         }
         // --- k_evaluate (collision test inside, against the entry lists) + k_select
@@ -163,14 +191,14 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
             EntryCollider ec;
             ec.init(P, D);
-            ec.cnt = D.ent_cap > 0 ? cnt.data() : nullptr;
+            ec.rng = D.ent_cap > 0 ? rng.data() + (size_t)(idx / WAVE) * P.n_total : nullptr;
             ec.e32 = e32.data(); ec.e64 = e64.data(); ec.sid = sid.data();
             CandResult r;
-            evaluate_candidate(P, D, Li, tab, q, P.n_total, ec, r);
+            evaluate_candidate(P, D, Li, GlobalTab{ tab }, q, P.n_total, ec, r);
             {   // broad phase + in-loop test vs the definition on the recorded points
                 VecSink vs = { &pts, P.n_total };
                 CandResult rk;
-                evaluate_candidate(P, D, Li, tab, q, P.n_total, vs, rk);
+                evaluate_candidate(P, D, Li, GlobalTab{ tab }, q, P.n_total, vs, rk);
                 int want = rk.status;
                 if (want == ST_PENDING && D.ent_cap > 0) {
                     VecSource src = { pts.data(), P.n_total };
