@@ -64,6 +64,28 @@ __device__ __forceinline__ ScanBest wave_argmin(ScanBest b)
     return b;
 }
 
+// refine_nearest (fot_math.hpp) with the three probes of a round on three lanes: same arithmetic, a third of the
+// dependent spline evaluations.  The result is uniform across the wave.
+__device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, double x, double y, double best_s, int lane)
+{
+    const double s_end = sp.s[sp.n - 1];
+    const int role = lane % 3;                                    // 0 left, 1 centre, 2 right
+    double ds = 0.2;
+    for (int it = 0; it < 20; ++it) {
+        const double s_left = fmax(0.0, best_s - ds);
+        const double s_right = fmin(s_end, best_s + ds);
+        const double s_mine = role == 0 ? s_left : (role == 1 ? best_s : s_right);
+        double px, py;
+        spline_xy(sp, s_mine, px, py);
+        const double dist = hypot(x - px, y - py);
+        const double dist_left = __shfl(dist, 0, WAVE), dist_curr = __shfl(dist, 1, WAVE), dist_right = __shfl(dist, 2, WAVE);
+        if (dist_left < dist_curr && dist_left < dist_right) best_s = s_left;
+        else if (dist_right < dist_curr && dist_right < dist_left) best_s = s_right;
+        else ds *= 0.5;
+    }
+    return best_s;
+}
+
 __global__ void __launch_bounds__(WAVE)
 k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
                InstState *__restrict__ state, int n_inst)
@@ -98,7 +120,7 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *
             ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
             best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
         }
-        best_s = refine_nearest(sp, x, y, best_s);            // uniform across the wave
+        best_s = refine_nearest_wave(sp, x, y, best_s, lane);
         const double new_prev_s = best_s;
 
         double fr[6], ref[6];
@@ -193,6 +215,15 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__r
 // candidate evaluation
 // ---------------------------------------------------------------------------
 
+// a wave-uniform double as an opaque scalar-register value
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    asm volatile("" : "+s"(lo), "+s"(hi));                       // opaque: a register value, not a re-loadable address
+    return __hiloint2double(hi, lo);
+}
+
 typedef float f16 __attribute__((ext_vector_type(16)));           // one chunk = 8 (x, y) pairs in 16 SGPRs
 
 // s_load_dwordx16 of the chunk OFF bytes behind src, NOT waited for (see FusedSink::put)
@@ -237,7 +268,7 @@ __device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float 
 struct FusedSink {
     const DevParams *Pp;
     const InstDesc *Dp;
-    const uint32_t *rng;                 // [n_total] strip ranges of this wave; nullptr: nothing to collide with
+    uint32_t my_rng;                     // lane k: strip range of time step k of this wave (0: nothing to test)
     const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
     const d2 *e64;
     const uint8_t *sid;
@@ -249,6 +280,8 @@ struct FusedSink {
     bool hit;
     int c_lo, n_chunks;                  // chunk range of the current time step
     uint32_t pf;                         // destination of the warm-up loads below, reserved until they have landed
+    bool no_warm;
+    bool any_fatal;                      // max_viol == 0: the first violation rejects the candidate
 
     // Reads the range of time step k and touches the first cache lines of its chunks, so that they are on their
     // way into the scalar cache while the sample arithmetic runs.  The loads are hand-issued and their (unused)
@@ -256,10 +289,10 @@ struct FusedSink {
     // must not land in a register the compiler has meanwhile given to something else.
     __device__ __forceinline__ void row_begin(int k)
     {
-        const uint32_t r = rng ? rng[k] : 0u;
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)my_rng, k);
         c_lo = (int)(r >> 16);
         n_chunks = (int)(r & 0xffffu) - c_lo;
-        if (n_chunks > 0) {
+        if (n_chunks > 0 && !no_warm) {
             const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
             asm volatile("s_load_dword %0, %1, 0x0\n\t"
                          "s_load_dword %0, %1, 0x40\n\t"
@@ -280,6 +313,8 @@ struct FusedSink {
         if (!alive || hit) return;                                // lanes whose collision outcome is already settled
         const float fx = (float)(px - oxd), fy = (float)(py - oyd);
         const float thr = filter_threshold(fc, fx, fy);
+        const float thr_sure = any_fatal ? filter_threshold_sure(fc, fx, fy) : -1.0f;
+        bool sure = false;                                        // some obstacle is certainly within its radius
         const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
         for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
             const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // even: lists are padded to chunk pairs
@@ -295,13 +330,19 @@ struct FusedSink {
             swait_chunk(ca);
             for (int c = 0; c < nb; c += 2) {
                 sload_chunk<64>(cb, cp);
-                near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(ca, fx, fy) <= thr);
+                const float ma = min_sqdist32_f16(ca, fx, fy);
+                near_bits = (near_bits << 1) | (uint32_t)(ma <= thr);
+                sure |= ma <= thr_sure;
                 swait_chunk(cb);
                 sload_chunk<128>(ca, cp);
-                near_bits = (near_bits << 1) | (uint32_t)(min_sqdist32_f16(cb, fx, fy) <= thr);
+                const float mb = min_sqdist32_f16(cb, fx, fy);
+                near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
+                sure |= mb <= thr_sure;
                 swait_chunk(ca);
                 cp += 2;
             }
+            // a single violation is fatal (no chance constraint budget): a certain float32 hit settles the candidate
+            if (sure) { hit = true; return; }
             if (near_bits != 0) exact(k, c0, nb, near_bits, px, py);
         }
     }
@@ -327,8 +368,9 @@ struct FusedSink {
 // Longitudinal tables of the block's candidates, staged in LDS: the 64 candidates of a wave share two or three
 // longitudinal profiles, whose rows every sample step would otherwise fetch from L2/HBM (two dependent round
 // trips per step).  Layout [profile][k][field]: one row is 80 contiguous bytes.
-constexpr int EVAL_WG = 256;
-constexpr int EVAL_LDS_PROFILES = 10;                             // 256 candidates / 29 offsets per profile + 1
+constexpr int EVAL_WG = WAVES_PER_GROUP * WAVE;
+constexpr int EVAL_LDS_BYTES = 52 * 1024;                         // three workgroups per CU within 160 KB of LDS
+constexpr int EVAL_LDS_PROFILES_MAX = 16;
 extern __shared__ double s_lon[];
 
 struct StagedTab {
@@ -343,13 +385,17 @@ struct StagedTab {
         } else {
             load_lon_sample(glob, k, L);
         }
+        // the row is in registers from here on: what follows (the sink's scalar warm-up loads) must not sit
+        // between these reads and the wait for them
+        asm volatile("" : "+v"(L.s), "+v"(L.sd), "+v"(L.sdd), "+v"(L.rx), "+v"(L.ry), "+v"(L.cos_r), "+v"(L.sin_r),
+                          "+v"(L.kr), "+v"(L.dkr), "+v"(L.inv_sd));
     }
 };
 
 __global__ void __launch_bounds__(EVAL_WG)
 k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-           const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab, int n_lon,
-           const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
+           const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab, int n_lon, int lds_profiles,
+           int ablate, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
            const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
            const uint8_t *__restrict__ ent_sid,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
@@ -357,8 +403,8 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 {
     const DevParams &P = *Pp;
     const int n_total = P.n_total;
-    // --- stage the profiles [g_lo, g_lo + EVAL_LDS_PROFILES) of the global profile index space; g_lo is the
-    //     profile of the block's first candidate (block-uniform)
+    // --- stage the profiles [g_lo, g_lo + lds_profiles) of the global profile index space; g_lo is the profile
+    //     of the block's first candidate (block-uniform; a block never spans two instances)
     const int wave_first = blockIdx.x * (EVAL_WG / WAVE);
     int g_lo = 0;
     {
@@ -368,7 +414,7 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
         const int idx0 = wave_base[wave_first];
         g_lo = D0.lon_off + (S0.c2f_ok && idx0 < S0.n_cand ? decode_candidate(P, D0, S0.frenet0, idx0).lon_slot : 0);
     }
-    const int n_stage = n_lon - g_lo < EVAL_LDS_PROFILES ? n_lon - g_lo : EVAL_LDS_PROFILES;
+    const int n_stage = n_lon - g_lo < lds_profiles ? n_lon - g_lo : lds_profiles;
     const int per_prof = LON_FIELDS * n_total;
     for (int i = threadIdx.x; i < n_stage * per_prof; i += EVAL_WG) {
         const int p = i / per_prof, rem = i - p * per_prof;
@@ -387,6 +433,9 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int idx = wave_base[wave] + lane;                    // candidate index inside the instance
     const int64_t slot = (int64_t)D.cand_off + idx;
     const bool live = S.c2f_ok && idx < S.n_cand;
+    // lane k holds the strip range of time step k (read back with v_readlane): loaded while every lane of the
+    // wave is still active, padding lanes included
+    const uint32_t my_rng = D.ent_cap != 0 && lane < n_total && !(ablate & 1) ? wave_rng[(int64_t)wave * n_total + lane] : 0u;
     if (!live) {                                               // padding lane: never counted
         cand_status[slot] = 255;
         cand_keep[slot] = 0;
@@ -403,17 +452,26 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 
     FusedSink sink;
     sink.Pp = Pp; sink.Dp = &D;
-    sink.rng = D.ent_cap != 0 ? wave_rng + (int64_t)wave * n_total : nullptr;
+    sink.my_rng = my_rng;
     sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
     sink.e64 = ent64 + D.ent_off;
     sink.sid = ent_sid + D.ent_off;
     sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
     sink.oxd = D.ego.x; sink.oyd = D.ego.y;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    sink.fc = filter_const(sq_dyn > P.sq_r ? sq_dyn : P.sq_r);
-    sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
+    sink.fc = filter_const(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
+    sink.any_fatal = D.max_viol == 0;
+    sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0; sink.no_warm = (ablate & 2) != 0;
+    // loop constants as opaque register values: the compiler then keeps (or lane-spills) them instead of
+    // re-fetching each one from the parameter blocks, behind a scalar-memory wait, in every time step
+    LoopConst lc = loop_const(P, D);
+    lc.dt = uniform_f64(lc.dt); lc.lim_speed = uniform_f64(lc.lim_speed); lc.lim_accel = uniform_f64(lc.lim_accel);
+    lc.lim_curv = uniform_f64(lc.lim_curv); lc.lim_lat = uniform_f64(lc.lim_lat);
+    lc.road_lim = uniform_f64(lc.road_lim);                    // (wherever the compiler had put them)
+    lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
+    asm volatile("" : "+s"(lc.n_circ_fp));
     CandResult r;
-    evaluate_candidate(P, D, L, tab, q, n_total, sink, r);
+    evaluate_candidate(P, D, lc, L, tab, q, n_total, sink, r);
     cand_cost[slot] = r.cost;
     cand_vlast[slot] = r.v_last;
     cand_travel[slot] = r.travel;
@@ -747,11 +805,12 @@ __global__ void k_check_ext(const DevParams *__restrict__ Pp, const InstDesc *__
     const bool has_geo = flags[i] & 1, has_d = flags[i] & 2;
     CheckAcc acc;
     check_init(acc);
+    const LoopConst lc = loop_const(P, D);
     for (int k = 0; k < n; ++k) {
         PathSample ps;
         ps.x = ax[k]; ps.y = ay[k]; ps.cos_t = cos(ayaw[k]); ps.sin_t = sin(ayaw[k]);
         ps.kappa = ac[k]; ps.v = av[k]; ps.a = aa[k]; ps.d = ad[k]; ps.s = as[k];
-        check_sample(P, D, acc, k, ps, has_geo, has_d);
+        check_sample(lc, acc, k, ps, has_geo, has_d);
     }
     int st = check_status(D, acc, n);
     if (st == ST_PENDING && n > 0 && collide_candidate(P, D, obs, n, src)) st = FOT_ST_COLLISION;
@@ -935,8 +994,13 @@ int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *s
 {
     if (n_waves <= 0) return 0;
     const int wpb = EVAL_WG / WAVE;
-    const size_t lds = sizeof(double) * EVAL_LDS_PROFILES * LON_FIELDS * (size_t)n_total;
-    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, desc, state, lon_info, lon_tab, n_lon, wave_inst,
+    const size_t per_prof = sizeof(double) * LON_FIELDS * (size_t)n_total;
+    int lds_profiles = (int)(EVAL_LDS_BYTES / per_prof);
+    if (lds_profiles > EVAL_LDS_PROFILES_MAX) lds_profiles = EVAL_LDS_PROFILES_MAX;
+    const size_t lds = per_prof * (size_t)lds_profiles;
+    static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
+    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, desc, state, lon_info, lon_tab, n_lon, lds_profiles,
+                                                                ablate, wave_inst,
                                                                 wave_base, n_waves, e.rng, e.e32, e.e64, e.sid,
                                                                 c.cost, c.v_last, c.travel, c.status, c.keep);
     FOT_LAUNCH_CHECK();

@@ -357,6 +357,25 @@ struct PathSample {
     double x, y, cos_t, sin_t, kappa, v, a, d, s;
 };
 
+// What the per-sample loop reads of the planner and instance constants, by value: k_evaluate keeps these in
+// registers instead of re-fetching them from the parameter blocks inside the loop.
+struct LoopConst {
+    double dt;
+    double lim_speed, lim_accel, lim_curv, lim_lat;
+    double road_lim;                     // max_road_width + 1e-9 (:982)
+    int n_circ_fp;                       // footprint circles, 0: the single centre circle
+};
+
+FOT_HD LoopConst loop_const(const DevParams &P, const InstDesc &D)
+{
+    LoopConst c;
+    c.dt = P.dt;
+    c.lim_speed = D.lim_speed; c.lim_accel = D.lim_accel; c.lim_curv = D.lim_curv; c.lim_lat = D.lim_lat;
+    c.road_lim = P.road_lim;
+    c.n_circ_fp = P.has_footprint ? P.n_circ : 0;
+    return c;
+}
+
 // The per-candidate flags live in ONE per-lane word (bit per flag) rather than in one wave mask each: eleven
 // 64-bit lane masks would not fit the scalar register file next to the collision chunk buffers of k_evaluate.
 enum : uint32_t {
@@ -383,8 +402,7 @@ FOT_HD void check_flag(CheckAcc &c, bool cond, uint32_t bit) { c.fl |= cond ? bi
 
 // k = index of the sample inside the path; has_geo / has_d: the low-speed rules and the road test
 // only apply when the caller's path carries the arrays they read (:1013-1022, :982)
-FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int k, const PathSample &p,
-                         bool has_geo, bool has_d)
+FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSample &p, bool has_geo, bool has_d)
 {
     check_flag(c, !(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa)), CK_NONFINITE);     // :944-946
     if (k > 0) {
@@ -392,10 +410,10 @@ FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int
         const double step2 = sx * sx + sy * sy;
         check_flag(c, isnan(step2), CK_NANSTEP);
         if (step2 > c.max_step2) c.max_step2 = step2;
-        check_flag(c, p.v > D.lim_speed, CK_SPEED);                                           // :964
-        check_flag(c, fabs(p.a) > D.lim_accel, CK_ACCEL);                                     // :966
+        check_flag(c, p.v > C.lim_speed, CK_SPEED);                                           // :964
+        check_flag(c, fabs(p.a) > C.lim_accel, CK_ACCEL);                                     // :966
         if (p.v > 0.5) {                                                                       // LOW_SPEED_CURVATURE_GATE
-            check_flag(c, fabs(p.kappa) > D.lim_curv, CK_CURV);
+            check_flag(c, fabs(p.kappa) > C.lim_curv, CK_CURV);
         } else if (has_geo) {
             const double dd = fabs(p.d - c.prev.d);
             const double d_s = fabs(p.s - c.prev.s);
@@ -403,10 +421,10 @@ FOT_HD void check_sample(const DevParams &P, const InstDesc &D, CheckAcc &c, int
             const double sn = p.sin_t * c.prev.cos_t - p.cos_t * c.prev.sin_t;                // sin/cos of the yaw step
             const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
             const double dyaw = fabs(atan2(sn, cs));
-            check_flag(c, dyaw > fmax(D.lim_curv * sqrt(step2), 0.1), CK_CURV);               // yaw-step cap
+            check_flag(c, dyaw > fmax(C.lim_curv * sqrt(step2), 0.1), CK_CURV);               // yaw-step cap
         }
-        check_flag(c, p.v * p.v * fabs(p.kappa) > D.lim_lat, CK_LAT);                         // :975
-        check_flag(c, has_d && fabs(p.d) > P.max_road_width + 1e-9, CK_ROAD);                 // :982
+        check_flag(c, p.v * p.v * fabs(p.kappa) > C.lim_lat, CK_LAT);                         // :975
+        check_flag(c, has_d && fabs(p.d) > C.road_lim, CK_ROAD);                 // :982
     }
     c.prev = p;
 }
@@ -448,8 +466,8 @@ struct GlobalTab {
 };
 
 template <class Tab, class Sink>
-FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
-                               const double *q, int n_loop, Sink &sink, CandResult &out)
+FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LoopConst &C, const LonInfo &L,
+                               const Tab &lon_tab, const double *q, int n_loop, Sink &sink, CandResult &out)
 {
     const int n_t = L.n_t;
     double Jp = 0.0, d_last = 0.0;
@@ -459,14 +477,16 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
     check_init(acc);
 
     for (int k = 0; k < n_loop; ++k) {
+      // table row first (every lane: rows past n_t exist and are ignored), then the sink's per-step prologue:
+      // k_evaluate issues its scalar warm-up loads there, after the row has arrived
+      LonSample ls;
+      lon_tab.load(k, ls);
       sink.row_begin(k);
       if (k < n_t) {
         double d, d_d, d_dd, d_ddd;
-        lat_sample(q, k, L.n_eval, P.dt, d, d_d, d_dd, d_ddd);
+        lat_sample(q, k, L.n_eval, C.dt, d, d_d, d_dd, d_ddd);
         Jp += d_ddd * d_ddd;
         d_last = d;
-        LonSample ls;
-        lon_tab.load(k, ls);
         CartSample c;
         frenet_to_cart(ls, d, d_d, d_dd, c);
         check_flag(acc, isfinite(c.omkd) && c.omkd <= 0.05, CK_SINGULAR);   // SINGULARITY_EPS, any sample
@@ -475,11 +495,11 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LonI
             PathSample ps;
             ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
             ps.v = c.v; ps.a = c.a; ps.d = d; ps.s = ls.s;
-            check_sample(P, D, acc, k, ps, true, true);
+            check_sample(C, acc, k, ps, true, true);
             if (k == 0) s_first = ls.s;
             const bool alive = (acc.fl & CK_FAILED) == 0;
-            if (P.has_footprint) {
-                for (int ci = 0; ci < P.n_circ; ++ci)
+            if (C.n_circ_fp > 0) {
+                for (int ci = 0; ci < C.n_circ_fp; ++ci)
                     sink.put(k, ci, c.x + P.circ_off[ci] * c.cos_t, c.y + P.circ_off[ci] * c.sin_t, alive);
             } else {
                 sink.put(k, 0, c.x, c.y, alive);
@@ -727,12 +747,16 @@ FOT_HD float min_sqdist32_8(const f2x8 &c, float fx, float fy)
 // Rounding the two points to float32 moves each coordinate difference by at most
 // 2^-24 (2|p| + R + |d|); with |d| <= R = sqrt(sq) the squared distance moves by less than
 // 4 (R+1) e, e = 2^-23 (|px| + |py| + 2R + 6); the three float32 roundings of the sum add 2^-22 relative.
-struct FilterConst { float sq, r; };       // (float)sq and sqrt((float)sq) + 1, fixed per instance
+struct FilterConst { float sq, r, sq_lo; }; // (float)sq, sqrt((float)sq) + 1, and the smaller squared radius rounded down
 
-FOT_HD FilterConst filter_const(double sq)
+FOT_HD FilterConst filter_const(double sq, double sq_min)
 {
-    FilterConst f; f.sq = (float)sq; f.r = sqrtf((float)sq) + 1.0f; return f;
+    FilterConst f; f.sq = (float)sq; f.r = sqrtf((float)sq) + 1.0f;
+    f.sq_lo = (float)sq_min * 0.9999999f;
+    return f;
 }
+
+FOT_HD FilterConst filter_const(double sq) { return filter_const(sq, sq); }
 
 FOT_HD float filter_threshold(const FilterConst &f, float px, float py)
 {
@@ -741,6 +765,15 @@ FOT_HD float filter_threshold(const FilterConst &f, float px, float py)
 }
 
 FOT_HD float filter_threshold(double sq, float px, float py) { return filter_threshold(filter_const(sq), px, py); }
+
+// The converse bound: a pair whose float32 squared distance is <= this value has a float64 squared distance <= the
+// SMALLER of the two squared radii, whatever the obstacle's kind -- a certain hit that needs no float64 re-check.
+// (A float32 value below sq means |d| < R + 1, so the same rounding bound applies; <= 0 when nothing is certain.)
+FOT_HD float filter_threshold_sure(const FilterConst &f, float px, float py)
+{
+    const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 4.0f) * 1.1920929e-7f;
+    return (f.sq_lo - 4.0f * f.r * e) * 0.999998f - 1e-30f;
+}
 
 // exact float64 test of one chunk (the reference's test); updates the per-sample hit state
 FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py, double sq_static, double sq_dyn,
@@ -786,9 +819,12 @@ struct EntryCollider {
         const int c_lo = (int)(rng[k] >> 16), c_hi = (int)(rng[k] & 0xffffu);
         const int64_t base = (int64_t)k * ent_cap;
         const float fx = (float)(px - ox), fy = (float)(py - oy);
-        const float thr = filter_threshold(sq_max, fx, fy);
+        const FilterConst fc = filter_const(sq_max, sq_dyn < sq_static ? sq_dyn : sq_static);
+        const float thr = filter_threshold(fc, fx, fy), thr_sure = filter_threshold_sure(fc, fx, fy);
         for (int c = c_lo * ENT_CHUNK; c < c_hi * ENT_CHUNK && !hit; c += ENT_CHUNK) {
-            if (min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy) > thr) continue;
+            const float m = min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy);
+            if (m > thr) continue;
+            if (max_viol == 0 && m <= thr_sure) { hit = true; break; }      // certain hit: one violation is fatal
             exact_chunk(e64 + base + c, sid + base + c, px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
         }
     }

@@ -57,6 +57,7 @@ inline int build_dev_params(const fot_params &p, DevParams &P, std::string &err)
     P.max_speed = p.max_speed; P.max_accel = p.max_accel; P.max_curvature = p.max_curvature;
     P.max_lat_accel = p.max_lat_accel;
     P.dt = p.dt; P.d_road_w = p.d_road_w; P.max_road_width = p.max_road_width; P.min_t = p.min_t; P.d_t_s = p.d_t_s;
+    P.road_lim = p.max_road_width + 1e-9;
     P.k_j = p.k_j; P.k_t = p.k_t; P.k_d = p.k_d; P.k_s_dot = p.k_s_dot; P.k_lat = p.k_lat; P.k_lon = p.k_lon;
     P.chance_epsilon = p.chance_epsilon;
 
@@ -217,7 +218,9 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         D.n_grid = P.n_ti * D.n_tv * P.n_di;
         D.n_cand_max = D.n_grid + P.n_brake;
 
-        const int n_waves_i = (D.n_cand_max + WAVE - 1) / WAVE;
+        // whole k_evaluate workgroups per instance (the workgroup stages one instance's tables); the padding
+        // waves have no candidates and leave at once
+        const int n_waves_i = ((D.n_cand_max + WAVE - 1) / WAVE + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP * WAVES_PER_GROUP;
         if (L.n_slots + (int64_t)n_waves_i * WAVE > 0x7fffffffLL) { err = "batch too large"; return FOT_ERR_UNSUPPORTED; }
         D.cand_off = (int32_t)L.n_slots;
         D.wave0 = (int32_t)L.wave_inst.size();

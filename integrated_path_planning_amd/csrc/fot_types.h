@@ -13,6 +13,7 @@
 namespace fot {
 
 constexpr int WAVE = 64;                 // gfx950 wavefront
+constexpr int WAVES_PER_GROUP = 4;       // waves of one k_evaluate workgroup; instances are padded to whole groups
 constexpr int LON_FIELDS = 10;           // s, s_d, s_dd, rx, ry, cos_r, sin_r, kappa_r, dkappa_r, (spare: s_ddd)
 constexpr int ST_PENDING = FOT_ST_OK;    // passed the kinematic checks, collision check outstanding
 
@@ -36,6 +37,7 @@ struct DevParams {
     double k_j, k_t, k_d, k_s_dot, k_lat, k_lon;
     double sq_r, sq_r_dyn;               // squared combined radii (frenet_planner.py:1172-1175)
     double chance_epsilon;
+    double road_lim;                     // max_road_width + 1e-9 (frenet_planner.py:982)
     double circ_off[FOT_MAX_CIRCLES];
     int32_t n_ti, n_di, n_side, n_brake; // n_brake = valid ladder entries
     int32_t n_total;                     // round(max_t/dt)+1

@@ -56,7 +56,8 @@ def main():
         pmc[k] = {"launches_fetch_pass": fetch.get(k, (0, 0))[1], "launches_write_pass": write.get(k, (0, 0))[1],
                   "FETCH_SIZE_bytes_per_launch": fb, "WRITE_SIZE_bytes_per_launch": wb}
         traffic[k] = {"fetch_bytes_reported": fb, "write_bytes": wb, "hbm_bytes_gfx950_corrected": 2.0 * fb + wb}
-    for path in glob.glob(os.path.join(root, "sq", "**", "*counter_collection.csv"), recursive=True):
+    for path in (glob.glob(os.path.join(root, "sq", "**", "*counter_collection.csv"), recursive=True)
+                 + glob.glob(os.path.join(root, "sq2", "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
         with open(path) as f:
             for row in csv.DictReader(f):

@@ -194,11 +194,11 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             ec.rng = D.ent_cap > 0 ? rng.data() + (size_t)(idx / WAVE) * P.n_total : nullptr;
             ec.e32 = e32.data(); ec.e64 = e64.data(); ec.sid = sid.data();
             CandResult r;
-            evaluate_candidate(P, D, Li, GlobalTab{ tab }, q, P.n_total, ec, r);
+            evaluate_candidate(P, D, loop_const(P, D), Li, GlobalTab{ tab }, q, P.n_total, ec, r);
             {   // broad phase + in-loop test vs the definition on the recorded points
                 VecSink vs = { &pts, P.n_total };
                 CandResult rk;
-                evaluate_candidate(P, D, Li, GlobalTab{ tab }, q, P.n_total, vs, rk);
+                evaluate_candidate(P, D, loop_const(P, D), Li, GlobalTab{ tab }, q, P.n_total, vs, rk);
                 int want = rk.status;
                 if (want == ST_PENDING && D.ent_cap > 0) {
                     VecSource src = { pts.data(), P.n_total };

@@ -188,6 +188,24 @@ def test_full_size_deterministic_and_batch_independent(config4):
         assert bytes(alone.records)[:rb] == ref[j * rb:(j + 1) * rb]
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_lane_split_gives_identical_records(config4, lanes, monkeypatch):
+    """FOT_LANES > 1 splits a large batch over internal streams; the records, the candidate tables and the debug
+    entry points (which must find the lane an instance ran on) are those of the single-stream run."""
+    bp, reqs, pb, res, kw = config4
+    monkeypatch.setenv("FOT_LANES", str(lanes))
+    split = BatchPlanner(waypoints=WP, **kw)                     # the knob is read when the handle is created
+    monkeypatch.delenv("FOT_LANES")
+    got = split.plan_packed(pb)
+    assert bytes(got.records) == bytes(res.records)
+    bp.plan_packed(pb)
+    for inst in (0, 100, 128, 200, 255):
+        a, b = split.candidates(inst), bp.candidates(inst)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y, err_msg=f"inst {inst}")
+    split.close()
+
+
 def test_full_size_selected_path_is_feasible_and_minimal(config4):
     """The selected candidate is 'ok' in the candidate table and no 'ok' candidate is cheaper or earlier at
     equal cost (first strict minimum, frenet_planner.py:1254-1257)."""
