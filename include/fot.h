@@ -230,10 +230,12 @@ int fot_resample_predictions(fot_handle *h, const fot_resample_params *rp, int32
                              double staleness, void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out,
                              double *sample_dist, void *stream);
 /* TrajectoryPredictor.predict_cv (:188-231): obs_last / obs_prev [P][2] host (obs_prev NULL = zero velocity)
- * -> out [P][T][2] with the same prepend / memory-space conventions */
+ * -> out [P][T][2] with the same prepend / memory-space conventions.  obs_dtype FOT_F32: the observations are float32
+ * (what PedestrianObserver.get_observation hands over, observer.py:134) and the velocity is formed in float32 as NumPy
+ * does for float32 arrays; FOT_F64: float64 observations, float64 velocity. */
 int fot_predict_cv(fot_handle *h, const fot_resample_params *rp, int32_t pred_len, int32_t P,
-                   const double *obs_last, const double *obs_prev, const double *current, double staleness,
-                   void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream);
+                   const void *obs_last, const void *obs_prev, int32_t obs_dtype, const double *current,
+                   double staleness, void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream);
 
 /* ---- compute_safety_metrics_static (data_structures.py:301-388) for n egos in one launch ----
  * ego [n][4] = x, y, yaw, v; pedestrians of ego i: ped_pos / ped_vel [ped_off[i] .. ped_off[i+1])[2]  (host arrays).

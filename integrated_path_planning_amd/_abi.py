@@ -139,8 +139,8 @@ def lib():
     L.fot_resample_n_dense.argtypes = [C.POINTER(ResampleParams), C.c_int32]
     L.fot_resample_predictions.argtypes = [vp, C.POINTER(ResampleParams), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32,
                                            dp, dp, C.c_double, vp, C.c_int32, C.c_int32, ip, dp, vp]
-    L.fot_predict_cv.argtypes = [vp, C.POINTER(ResampleParams), C.c_int32, C.c_int32, dp, dp, dp, C.c_double, vp,
-                                 C.c_int32, C.c_int32, ip, vp]
+    L.fot_predict_cv.argtypes = [vp, C.POINTER(ResampleParams), C.c_int32, C.c_int32, vp, vp, C.c_int32, dp,
+                                 C.c_double, vp, C.c_int32, C.c_int32, ip, vp]
     L.fot_safety_metrics_batch.argtypes = [vp, C.c_int32, dp, ip, dp, dp, C.c_double, C.c_double, C.c_int32, C.POINTER(Safety)]
     L.fot_profile_enable.argtypes = [vp, C.c_int]
     L.fot_profile_read.argtypes = [vp, C.c_int, ip, dp]

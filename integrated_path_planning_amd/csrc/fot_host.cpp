@@ -394,8 +394,12 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipEventCreateWithFlags(&h->fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    for (Workspace &w : h->ws) {
-        if ((e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    for (int l = 0; l < FOT_LANES; ++l) {
+        Workspace &w = h->ws[l];
+        // lane streams only when the handle splits batches; lane 0 of a single-lane handle runs on the caller's stream
+        if (h->lanes_cfg > 1 && l < h->lanes_cfg &&
+            (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+        if (l >= h->lanes_cfg) continue;
         if ((e = hipEventCreateWithFlags(&w.staging_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
@@ -568,11 +572,22 @@ int fot_resample_predictions(fot_handle *h, const fot_resample_params *rp, int32
 }
 
 int fot_predict_cv(fot_handle *h, const fot_resample_params *rp, int32_t pred_len, int32_t P,
-                   const double *obs_last, const double *obs_prev, const double *current, double staleness,
-                   void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream)
+                   const void *obs_last, const void *obs_prev, int32_t obs_dtype, const double *current,
+                   double staleness, void *out, int32_t out_dtype, int32_t on_device, int32_t *T_out, void *stream)
 {
-    return resample_common(h, rp, 1, 1, pred_len, P, obs_prev, FOT_F64, obs_last, current, staleness, out, out_dtype,
-                           on_device, T_out, nullptr, stream);
+    if (!h) return FOT_ERR_INVALID;
+    if (obs_dtype == FOT_F64)
+        return resample_common(h, rp, 1, 1, pred_len, P, obs_prev, FOT_F64, (const double *)obs_last, current, staleness,
+                               out, out_dtype, on_device, T_out, nullptr, stream);
+    if (obs_dtype != FOT_F32) return fail(h, FOT_ERR_INVALID, "obs_dtype");
+    // float32 observations travel widened (exact); cv mode 2 forms the velocity in float32
+    const size_t n = 2 * (size_t)(P > 0 ? P : 0);
+    std::vector<double> last(n), prev(n);
+    for (size_t i = 0; i < n && obs_last; ++i) last[i] = (double)((const float *)obs_last)[i];
+    for (size_t i = 0; i < n && obs_prev; ++i) prev[i] = (double)((const float *)obs_prev)[i];
+    return resample_common(h, rp, 2, 1, pred_len, P, obs_prev ? prev.data() : nullptr, FOT_F64,
+                           obs_last ? last.data() : nullptr, current, staleness, out, out_dtype, on_device, T_out,
+                           nullptr, stream);
 }
 
 int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const int32_t *ped_off,

@@ -825,7 +825,7 @@ __global__ void k_check_ext(const DevParams *__restrict__ Pp, const InstDesc *__
 struct ResampleArgs {
     double sgan_dt, sim_dt, staleness;
     int S, pred_len, P, n_dense, T;          // T = n_dense + prepend
-    int has_anchor, prepend, cv;             // cv: sources are (obs_prev, obs_last) -> constant velocity
+    int has_anchor, prepend, cv;             // cv: sources are (obs_prev, obs_last) -> constant velocity; 2: float32 obs
 };
 
 // one thread per (sample, pedestrian, axis); out[s][p][k][axis]
@@ -841,7 +841,11 @@ __global__ void k_resample(ResampleArgs A, const TI *__restrict__ pred, const do
     dst += 2 * A.prepend;
     if (A.cv) {                                                     // predict_cv (:188-231)
         const double cur = anchor[2 * p + ax];                      // obs_last
-        const double vel = pred ? (cur - (double)pred[2 * p + ax]) / A.sgan_dt : 0.0;   // obs_prev
+        double vel = 0.0;
+        if (pred && A.cv == 2)                                      // float32 observations: float32 velocity (:216)
+            vel = (double)(((float)cur - (float)pred[2 * p + ax]) / (float)A.sgan_dt);
+        else if (pred)
+            vel = (cur - (double)pred[2 * p + ax]) / A.sgan_dt;     // obs_prev
         for (int i = 0; i < A.n_dense; ++i) {
             const double t = (A.sim_dt + (double)i * A.sim_dt) + A.staleness;
             dst[2 * i] = (TO)(cur + vel * t);

@@ -64,9 +64,14 @@ class PredictionResampler:
         res = out[0] if single else out
         return (res, dist) if want_sample_dist else res
 
-    def predict_cv(self, obs_traj: np.ndarray, staleness: float = 0.0, current: Optional[np.ndarray] = None):
-        """obs_traj [obs_len, P, 2] (absolute) -> [P, T, 2]; velocity from the last two samples (:203-217)."""
-        obs = np.asarray(obs_traj, dtype=np.float64)
+    def predict_cv(self, obs_traj: np.ndarray, staleness: float = 0.0, current: Optional[np.ndarray] = None,
+                   float32_observations: bool = False):
+        """obs_traj [obs_len, P, 2] (absolute) -> [P, T, 2]; velocity from the last two samples (:203-217).
+
+        float32_observations: round the observations to float32 first and form the velocity in float32 -- what the
+        reference does when the observer hands over its float tensors (observer.py:134)."""
+        dt = np.float32 if float32_observations else np.float64
+        obs = np.asarray(obs_traj).astype(dt)
         P = obs.shape[1]
         last = np.ascontiguousarray(obs[-1])
         prev = np.ascontiguousarray(obs[-2]) if obs.shape[0] >= 2 else None
@@ -74,8 +79,9 @@ class PredictionResampler:
         out = np.zeros((P, T, 2))
         t_out = C.c_int32(0)
         _abi.check(self.engine._h, self._lib.fot_predict_cv(
-            self.engine._h, C.byref(self.params), self.pred_len, P, _host_pd(last), _host_pd(prev), _host_pd(current),
-            float(staleness), out.ctypes.data, _abi.F64, 0, C.byref(t_out), None))
+            self.engine._h, C.byref(self.params), self.pred_len, P, last.ctypes.data,
+            None if prev is None else prev.ctypes.data, _abi.F32 if float32_observations else _abi.F64,
+            _host_pd(current), float(staleness), out.ctypes.data, _abi.F64, 0, C.byref(t_out), None))
         return out
 
     @staticmethod

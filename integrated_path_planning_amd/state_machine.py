@@ -167,8 +167,10 @@ class SpeculativePlanningCycle:
             nxt = sm.update(False, metrics, ego_speed)
         return out
 
-    def execute(self, ego_state, static_obstacles, dynamic_obstacles, current_metrics: Dict[str, Any],
-                dynamic_obstacles_distribution=None, replan_attempts_used: int = 0) -> CycleResult:
+    def prepare(self, ego_state, static_obstacles, dynamic_obstacles, current_metrics: Dict[str, Any],
+                dynamic_obstacles_distribution=None, replan_attempts_used: int = 0):
+        """The requests of every escalation level this step can reach (first = the current state's), and the ladder
+        they were built from.  Requests after the first chain their nearest-point cache on the one before."""
         pl = self.planner
         budget = max(self.max_replan_attempts - replan_attempts_used, 0)
         ladder = self._ladder(current_metrics, ego_state.v)[: 1 + budget]
@@ -181,15 +183,18 @@ class SpeculativePlanningCycle:
                 prev_s=None if j else getattr(pl.converter, "_prev_s", None), chain_prev_s=bool(j),
                 overrides=cfg.constraint_overrides, max_stop_distance=cfg.max_stop_distance,
                 static=static_obstacles, dyn=dynamic_obstacles, dist=dynamic_obstacles_distribution))
-        res = pl.engine.plan_batch(reqs)
+        return ladder, reqs, budget
 
-        # replay of integrated_simulator.py:576-653 on the speculative results
+    def finish(self, ladder, budget, res, base: int, ego_state, current_metrics: Dict[str, Any]) -> CycleResult:
+        """Replay of integrated_simulator.py:576-653 on the speculative results res.records[base + j]."""
+        pl = self.planner
+
         def adopt(j):
-            rec = res.records[j]
+            rec = res.records[base + j]
             if not np.isnan(rec.new_prev_s):
                 pl.converter._prev_s = float(rec.new_prev_s)
-            pl.last_check_stats = res.stats(j)
-            path = res.path(j)
+            pl.last_check_stats = res.stats(base + j)
+            path = res.path(base + j)
             if path is not None:
                 pl._last_kappa = float(rec.new_last_kappa)
             return path
@@ -209,3 +214,10 @@ class SpeculativePlanningCycle:
             sm_output = new_output
             new_output = self.sm.update(False, current_metrics, ego_speed=ego_state.v)
         return CycleResult(path, 1 + retries, retries, states, new_output)
+
+    def execute(self, ego_state, static_obstacles, dynamic_obstacles, current_metrics: Dict[str, Any],
+                dynamic_obstacles_distribution=None, replan_attempts_used: int = 0) -> CycleResult:
+        ladder, reqs, budget = self.prepare(ego_state, static_obstacles, dynamic_obstacles, current_metrics,
+                                            dynamic_obstacles_distribution, replan_attempts_used)
+        res = self.planner.engine.plan_batch(reqs)
+        return self.finish(ladder, budget, res, 0, ego_state, current_metrics)

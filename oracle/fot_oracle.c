@@ -981,11 +981,26 @@ int orc_process_prediction(double sgan_dt, double sim_dt, double plan_horizon, i
 int orc_predict_cv(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
                    const double *obs_last, const double *obs_prev, double staleness, double *out)
 {
+    return orc_predict_cv_obs(sgan_dt, sim_dt, plan_horizon, pred_len, P, obs_last, obs_prev, 0, staleness, out);
+}
+
+/* obs_f32: the observations were float32 tensors (observer.py:134) -- positions rounded to float32 and the velocity
+ * (p_curr - p_prev) / sgan_dt evaluated in float32 (NumPy: float32 array / Python float), :203-217 */
+int orc_predict_cv_obs(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
+                       const double *obs_last, const double *obs_prev, int obs_f32, double staleness, double *out)
+{
     int n_dense = orc_n_dense(sgan_dt, sim_dt, plan_horizon, pred_len);
     for (int p = 0; p < P; ++p)
         for (int ax = 0; ax < 2; ++ax) {
             double cur = obs_last[2 * p + ax];
             double vel = obs_prev ? (cur - obs_prev[2 * p + ax]) / sgan_dt : 0.0;
+            if (obs_f32) {
+                volatile float c32 = (float)cur, p32 = obs_prev ? (float)obs_prev[2 * p + ax] : 0.0f;
+                volatile float d32 = c32 - p32;
+                volatile float v32 = d32 / (float)sgan_dt;
+                cur = (double)c32;
+                vel = obs_prev ? (double)v32 : 0.0;
+            }
             for (int i = 0; i < n_dense; ++i) {
                 double t = (sim_dt + (double)i * sim_dt) + staleness;
                 out[((size_t)p * n_dense + i) * 2 + ax] = cur + vel * t;

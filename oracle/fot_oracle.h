@@ -150,6 +150,8 @@ int orc_process_prediction(double sgan_dt, double sim_dt, double plan_horizon, i
 /* predict_cv (:188-231): obs_last, obs_prev [P][2] (obs_prev NULL: zero velocity) -> out [P][n_dense][2] */
 int orc_predict_cv(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
                    const double *obs_last, const double *obs_prev, double staleness, double *out);
+int orc_predict_cv_obs(double sgan_dt, double sim_dt, double plan_horizon, int pred_len, int P,
+                       const double *obs_last, const double *obs_prev, int obs_f32, double staleness, double *out);
 /* predict_single_best (:338-351): samples [S][P][T][2] -> index of the sample closest to the sample mean */
 int orc_best_sample(int S, int P, int T, const double *samples, double *dist_out);
 

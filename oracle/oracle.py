@@ -117,6 +117,8 @@ def lib():
         L.orc_n_dense.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
         L.orc_process_prediction.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, dp]
         L.orc_predict_cv.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, dp]
+        L.orc_predict_cv_obs.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.c_int,
+                                         C.c_double, dp]
         L.orc_best_sample.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
         L.orc_safety_metrics.argtypes = [C.POINTER(Params), C.c_double, C.c_double, dp, C.c_int, dp, dp, dp]
         L.orc_safety_metrics.restype = None
@@ -337,14 +339,16 @@ def process_prediction(pred, anchor=None, staleness=0.0, sgan_dt=0.4, sim_dt=0.1
     return out
 
 
-def predict_cv(obs_last, obs_prev=None, staleness=0.0, pred_len=12, sgan_dt=0.4, sim_dt=0.1, plan_horizon=5.0):
+def predict_cv(obs_last, obs_prev=None, staleness=0.0, pred_len=12, sgan_dt=0.4, sim_dt=0.1, plan_horizon=5.0,
+               float32_observations=False):
     last = np.ascontiguousarray(obs_last, dtype=np.float64)
     prev = None if obs_prev is None else np.ascontiguousarray(obs_prev, dtype=np.float64)
     P = last.shape[0]
     n = lib().orc_n_dense(sgan_dt, sim_dt, plan_horizon, pred_len)
     out = np.zeros((P, n, 2))
-    lib().orc_predict_cv(sgan_dt, sim_dt, plan_horizon, pred_len, P, _dp(last), None if prev is None else _dp(prev),
-                         float(staleness), _dp(out))
+    lib().orc_predict_cv_obs(sgan_dt, sim_dt, plan_horizon, pred_len, P, _dp(last),
+                             None if prev is None else _dp(prev), 1 if float32_observations else 0, float(staleness),
+                             _dp(out))
     return out
 
 

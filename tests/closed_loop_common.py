@@ -1,0 +1,135 @@
+"""Shared by the CPU and GPU closed-loop episode tests: fixture access, an oracle-backed stand-in engine
+(test infrastructure: lets the host logic of BatchedClosedLoop run where there is no GPU) and the comparison."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+
+from conftest import GOLDEN_DIR
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.data_structures import FrenetPath
+from oracle import oracle as orc
+
+STATE_NAMES = {0: "NORMAL", 1: "CAUTION", 2: "EMERGENCY"}
+
+
+def load_episodes():
+    z = np.load(os.path.join(GOLDEN_DIR, "closed_loop", "scenario01_cv_episode.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["meta"] = json.loads(str(d["meta"]))
+    return d
+
+
+def scenario_config(meta):
+    return dict(meta["config"])
+
+
+class OracleEngine:
+    """BatchPlanner's methods on top of the CPU oracle -- for tests only."""
+
+    def __init__(self, cfg):
+        c = SimpleNamespace(**cfg)
+        self.params = orc.make_params(
+            max_speed=c.ego_max_speed, max_accel=c.ego_max_accel, max_curvature=c.ego_max_curvature,
+            max_lat_accel=cfg.get("ego_max_lat_accel", 3.0), dt=c.dt, d_road_w=c.d_road_w, max_road_width=c.max_road_width,
+            robot_radius=cfg.get("ego_radius", 1.0), obstacle_radius=c.obstacle_radius, min_t=cfg.get("min_t", 4.0),
+            max_t=cfg.get("max_t", 5.0), d_t_s=cfg.get("d_t_s", 5.0 / 3.6), k_j=c.k_j, k_t=c.k_t, k_d=c.k_d,
+            k_s_dot=c.k_s_dot, k_lat=c.k_lat, k_lon=c.k_lon, chance_epsilon=cfg.get("chance_epsilon", 0.0),
+            collision_margin_inflation=cfg.get("collision_margin_inflation", 1.0))
+        self.sp = orc.Spline(np.asarray(c.reference_waypoints_x, float), np.asarray(c.reference_waypoints_y, float))
+        self.calls = 0
+
+    def path_coeffs(self):
+        return self.sp.coeffs()
+
+    def plan_batch(self, reqs):
+        outs = []
+        prev = None
+        for r in reqs:
+            ps = prev if r.chain_prev_s else r.prev_s
+            ego = orc.make_ego(r.x, r.y, r.yaw, r.v, r.a, last_kappa=r.last_kappa, prev_s=ps)
+            o = orc.plan(self.params, self.sp, ego, r.target_speed, r.overrides, r.max_stop_distance,
+                         static=r.static, dyn=r.dyn, dist=r.dist)
+            prev = o.new_prev_s
+            outs.append(o)
+            self.calls += 1
+        recs = [SimpleNamespace(new_prev_s=o.new_prev_s, new_last_kappa=o.new_last_kappa, status=o.status) for o in outs]
+
+        def path(j):
+            o = outs[j]
+            if o.status != 0:
+                return None
+            fp = FrenetPath(**{f: list(o.path[f]) for f in _abi.PATH_FIELDS})
+            fp.cost = float(o.cost)
+            return fp
+
+        return SimpleNamespace(records=recs, stats=lambda j: outs[j].stats, path=path)
+
+    def safety_metrics(self, egos, pos, vel, ego_radius, ped_radius, use_footprint=True):
+        out = np.zeros(len(egos), dtype=[("min_distance", "f8"), ("ttc", "f8"), ("clearance", "f8"),
+                                         ("clearance_ahead", "f8"), ("collision", "i4")])
+        for i, e in enumerate(egos):
+            m = orc.safety_metrics(self.params, ego_radius, ped_radius, e, pos[i], vel[i])
+            out[i] = (m["min_distance"], m["ttc"], m["clearance"], m["clearance_ahead"], int(m["collision"]))
+        return out
+
+    def frenet_states(self, reqs):
+        nps = []
+        for r in reqs:
+            ego = orc.make_ego(r.x, r.y, r.yaw, r.v, r.a, last_kappa=0.0, prev_s=r.prev_s)
+            nps.append(orc.cartesian_to_frenet_state(self.sp, ego)[3])
+        return None, None, np.array(nps), None
+
+
+class OracleResampler:
+    def __init__(self, cfg):
+        self.kw = dict(pred_len=cfg["pred_len"], sgan_dt=0.4, sim_dt=cfg["dt"], plan_horizon=cfg.get("max_t", 5.0))
+
+    def predict_cv(self, obs_traj, staleness=0.0, current=None, float32_observations=False):
+        obs = np.asarray(obs_traj)
+        return orc.predict_cv(obs[-1], obs[-2] if obs.shape[0] >= 2 else None, staleness,
+                              float32_observations=float32_observations, **self.kw)
+
+
+def assert_episode_matches(hist, termination, ep, name, tol=1e-6):
+    """hist: List[StepRecord] of one episode; ep: fixture dict; name: variant prefix."""
+    meta = ep["meta"]["variants"][name]
+    pre = name + "_"
+    assert termination == meta["termination"], f"{name}: ended with {termination}, reference {meta['termination']}"
+    assert len(hist) == meta["steps"], f"{name}: {len(hist)} steps, reference {meta['steps']}"
+    ego = np.array([[r.ego.x, r.ego.y, r.ego.yaw, r.ego.v, r.ego.a, r.ego.jerk] for r in hist])
+    want = ep[pre + "ego"]
+    for col, f in enumerate(("x", "y", "yaw", "v", "a", "jerk")):
+        np.testing.assert_allclose(ego[:, col], want[:, col], rtol=tol, atol=tol * (100 if f == "jerk" else 1),
+                                   err_msg=f"{name} ego {f}")
+    np.testing.assert_allclose([r.time for r in hist], ep[pre + "times"], atol=1e-9)
+    states = [r.ego.state.name for r in hist]
+    assert states == [STATE_NAMES[int(s)] for s in ep[pre + "state"]], f"{name} state sequence"
+    m = np.array([[r.metrics["min_distance"], r.metrics["ttc"], r.metrics["clearance"], r.metrics["clearance_ahead"],
+                   float(r.metrics["collision"]), r.metrics.get("n_collision_rejected", -1)] for r in hist])
+    np.testing.assert_allclose(m[:, :4], ep[pre + "metrics"][:, :4], rtol=tol, atol=tol, err_msg=f"{name} metrics")
+    np.testing.assert_array_equal(m[:, 4:], ep[pre + "metrics"][:, 4:], err_msg=f"{name} collision / rejected counts")
+    plen = np.array([len(r.planned_path.x) if r.planned_path is not None else 0 for r in hist])
+    np.testing.assert_array_equal(plen, ep[pre + "planned_len"], err_msg=f"{name} planned path lengths")
+    cost = np.array([r.planned_path.cost if r.planned_path is not None else np.inf for r in hist])
+    np.testing.assert_allclose(cost, ep[pre + "planned_cost"], rtol=tol, err_msg=f"{name} planned cost")
+    for i, r in enumerate(hist):
+        if r.planned_path is not None:
+            np.testing.assert_allclose(r.planned_path.x, ep[pre + "planned_x"][i, :plen[i]], atol=tol, err_msg=f"{name} step {i}")
+            np.testing.assert_allclose(r.planned_path.y, ep[pre + "planned_y"][i, :plen[i]], atol=tol, err_msg=f"{name} step {i}")
+        shape = list(r.predicted_trajectories.shape) if r.predicted_trajectories is not None else [0, 0, 0]
+        assert shape == list(ep[pre + "pred_shape"][i]), f"{name} step {i} prediction shape"
+        if r.predicted_trajectories is not None:
+            np.testing.assert_allclose(r.predicted_trajectories[0, :3].ravel(), ep[pre + "pred_first"][i], rtol=1e-12,
+                                       atol=1e-12, err_msg=f"{name} step {i} prediction values")
+
+
+def assert_npz_layout(arrays, meta_keys, n_steps):
+    """trajectory.npz: the reference's keys, dtypes and shapes (integrated_simulator.py:959-982)."""
+    assert set(arrays) == set(meta_keys)
+    for k, (dtype, shape) in meta_keys.items():
+        a = arrays[k]
+        assert str(a.dtype) == dtype, f"{k}: dtype {a.dtype}, reference {dtype}"
+        assert list(a.shape) == shape, f"{k}: shape {a.shape}, reference {shape}"
+    assert len(arrays["times"]) == n_steps

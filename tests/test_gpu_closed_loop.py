@@ -1,0 +1,50 @@
+"""SURVEY 8(f4) on the GPU: whole reference episodes free-running through BatchedClosedLoop on libfot -- every step one
+prediction launch, two safety-metric launches, one plan batch with all escalation levels of all episodes, one
+nearest-point launch."""
+import time
+
+import numpy as np
+import pytest
+
+from closed_loop_common import assert_episode_matches, assert_npz_layout, load_episodes, scenario_config
+from integrated_path_planning_amd.closed_loop import BatchedClosedLoop
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def episodes():
+    return load_episodes()
+
+
+def test_three_episodes_in_lock_step_match_the_reference(episodes, tmp_path):
+    """274-step run to the goal (20 emergency stops, all three vehicle states) and two runs that end in a collision,
+    advanced together: each must equal its own reference episode step by step."""
+    cfg = scenario_config(episodes["meta"])
+    names = ("base", "fast", "shift")
+    sim = BatchedClosedLoop(cfg, [episodes[n + "_ped_traj"] for n in names])
+    t0 = time.perf_counter()
+    hists = sim.run()
+    wall = time.perf_counter() - t0
+    for h, ep, n in zip(hists, sim.episodes, names):
+        assert_episode_matches(h, ep.termination_reason, episodes, n)
+    files = sim.save_results(str(tmp_path))
+    for f, n in zip(files, names):
+        z = np.load(f, allow_pickle=True)                  # object arrays as in the reference's file; written just above
+        assert_npz_layout({k: z[k] for k in z.files}, episodes["meta"]["variants"][n]["npz_keys"],
+                          episodes["meta"]["variants"][n]["steps"])
+    sim.close()
+    print(f"3 episodes, {sum(len(h) for h in hists)} episode-steps in {wall:.2f} s")
+
+
+def test_replicated_episodes_are_identical(episodes):
+    """32 copies of one episode in one batch: every copy must reproduce the reference (batch independence)."""
+    cfg = scenario_config(episodes["meta"])
+    sim = BatchedClosedLoop(cfg, [episodes["shift_ped_traj"]] * 32)
+    hists = sim.run()
+    for i in (0, 13, 31):
+        assert_episode_matches(hists[i], sim.episodes[i].termination_reason, episodes, "shift")
+    x0 = [r.ego.x for r in hists[0]]
+    for h in hists[1:]:
+        assert [r.ego.x for r in h] == x0
+    sim.close()
