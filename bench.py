@@ -245,6 +245,23 @@ def main():
         latency["f2_three_level_cycle"] = {"one_launch_p50_ms": float(np.percentile(np.array(t_spec) * 1e3, 50)),
                                            "three_calls_p50_ms": float(np.percentile(np.array(t_seq) * 1e3, 50))}
         p3.close()
+        # row f4: whole closed-loop episodes in lock-step (fixture = pedestrian tracks + scenario of the reference run)
+        epi = os.path.join(ROOT, "tests", "golden", "closed_loop", "scenario01_cv_episode.npz")
+        if os.path.exists(epi):
+            from integrated_path_planning_amd.closed_loop import BatchedClosedLoop
+            z = np.load(epi, allow_pickle=False)
+            cfg_ = json.loads(str(z["meta"]))["config"]
+            n_epi = 64
+            with BatchedClosedLoop(cfg_, [z["base_ped_traj"]] * n_epi, device=local_rank) as loop:
+                t1 = time.perf_counter()
+                hists = loop.run()
+                wall = time.perf_counter() - t1
+            steps_ = len(hists[0])
+            latency["f4_closed_loop"] = {
+                "episodes": n_epi, "lock_steps": steps_, "ms_per_lock_step": wall / steps_ * 1e3,
+                "episode_steps_per_s": n_epi * steps_ / wall,
+                "note": "scenario_01 (1261-candidate lattice, 14 pedestrians, cv predictor), 64 copies advanced together; "
+                        "the reference simulator takes ~131 ms per step of ONE episode in the build container"}
         ts = []
         for _ in range(5):
             t1 = time.perf_counter()
