@@ -260,7 +260,8 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         }
         const int64_t per_k = (int64_t)D.n_static + (D.dyn_mode != FOT_DYN_NONE ? (int64_t)D.S * D.P : 0);
         if (per_k > 0) {
-            if (per_k > (1 << 24)) { err = "too many obstacle points in one instance"; return FOT_ERR_UNSUPPORTED; }
+            // chunk indices travel as 16 bits (strip_range): at most 65534 chunks of 8 entries per time step
+            if (per_k > 65534 * 8) { err = "too many obstacle points in one instance"; return FOT_ERR_UNSUPPORTED; }
             D.ent_cap = (int32_t)((per_k + 15) & ~(int64_t)15);          // whole chunk pairs
             D.ent_off = L.n_entries;
             L.n_entries += (int64_t)D.ent_cap * P.n_total;

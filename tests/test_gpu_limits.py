@@ -1,0 +1,84 @@
+"""Sizes at and beyond the comfortable range: obstacle sets larger than k_cull's LDS cache and than one 32-chunk pass of
+the broad phase, the longest horizon the build supports, a chance-constraint budget with many samples -- all against
+the oracle, candidate table included."""
+import numpy as np
+import pytest
+
+from helpers import TIGHT, assert_record_matches_oracle, oracle_plan_for_request
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.batch import PlanRequest
+from integrated_path_planning_amd.footprint import EgoFootprint
+from integrated_path_planning_amd.planner import BatchPlanner
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+WX, WY = np.linspace(0.0, 120.0, 13), np.zeros(13)
+
+
+def _check(bp, params, sp, reqs):
+    res = bp.plan_batch(reqs)
+    for i, rq in enumerate(reqs):
+        want = oracle_plan_for_request(orc, params, sp, rq, table=True)
+        cost, status, keep, nt = bp.candidates(i)
+        np.testing.assert_array_equal(status, want.cand_status, err_msg=f"inst {i}")
+        np.testing.assert_array_equal(keep, want.cand_keep, err_msg=f"inst {i}")
+        np.testing.assert_allclose(cost, want.cand_cost, rtol=TIGHT, atol=TIGHT)
+        assert_record_matches_oracle(res.records[i], want, label=f"inst {i}")
+    return res
+
+
+def test_dense_static_crowd_many_chunk_passes():
+    """3000 static points in the corridor: ~100 chunks per time step (more than one 32-chunk pass), every strip full."""
+    kw = dict(dt=0.2, max_road_width=3.0, d_road_w=1.0, robot_radius=0.3, obstacle_radius=0.1, max_t=4.4)
+    rng = np.random.default_rng(5)
+    pts = np.column_stack([rng.uniform(5, 60, 3000), rng.uniform(-6, 6, 3000)])
+    pts = pts[np.abs(pts[:, 1]) > 0.2]                       # a free lane along the centre line, crowded either side
+    bp = BatchPlanner(waypoints=(WX, WY), **kw)
+    reqs = [PlanRequest(2.0, 0.1, 0.0, 6.0, 0.0, target_speed=7.0, static=pts),
+            PlanRequest(10.0, -0.4, 0.05, 3.0, 0.5, target_speed=5.0, static=pts[::2])]
+    res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
+    assert res.records[0].stats[_abi.ST_COLLISION] > 0
+
+
+def test_distribution_larger_than_cull_cache_with_budget():
+    """64 samples x 80 pedestrians = 5120 points per step (k_cull re-fetches past its 4096-entry LDS cache), eps = 0.1
+    -> up to 6 violating samples allowed: the exact per-sample counting path, with a 3-circle footprint."""
+    fp = EgoFootprint.multi_circle(4.5, 1.8, 3)
+    kw = dict(dt=0.2, max_road_width=2.0, d_road_w=1.0, robot_radius=1.0, obstacle_radius=0.2, chance_epsilon=0.1)
+    okw = dict(kw, footprint_offsets=list(fp.offsets), footprint_radius=fp.radius)
+    rng = np.random.default_rng(9)
+    S, P, T = 64, 80, 26
+    p0 = np.column_stack([rng.uniform(0, 70, P), rng.uniform(-12, 12, P)])
+    vel = rng.normal(0, 1.0, (S, P, 1, 2))
+    dist = p0[None, :, None, :] + vel * (np.arange(T) * 0.2)[None, None, :, None]
+    bp = BatchPlanner(waypoints=(WX, WY), footprint=fp, **kw)
+    reqs = [PlanRequest(3.0, 0.0, 0.0, 5.0, 0.0, target_speed=6.0, dist=dist),
+            PlanRequest(20.0, 0.5, 0.0, 7.0, -0.5, target_speed=8.0, dist=dist[:, ::3])]
+    _check(bp, orc.make_params(**okw), orc.Spline(WX, WY), reqs)
+
+
+def test_longest_horizon_64_samples():
+    """max_t = 6.3 s at dt = 0.1 s: 64 samples per candidate, the limit of the build (FOT_MAX_NT)."""
+    kw = dict(dt=0.1, min_t=5.9, max_t=6.3, max_road_width=1.0, d_road_w=0.5, robot_radius=1.0, obstacle_radius=0.2)
+    rng = np.random.default_rng(2)
+    dyn = np.array([12.0, 1.0]) + rng.normal(0, 3.0, (18, 1, 2)) + np.cumsum(rng.normal(0, 0.08, (18, 64, 2)), axis=1)
+    bp = BatchPlanner(waypoints=(WX, WY), **kw)
+    reqs = [PlanRequest(1.0, 0.2, 0.0, 6.0, 0.2, target_speed=7.0, dyn=dyn)]
+    res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
+    if res.records[0].status == _abi.PLAN_OK:
+        assert res.records[0].n_keep <= 64
+    with pytest.raises(Exception):
+        BatchPlanner(waypoints=(WX, WY), **dict(kw, max_t=6.4))          # 65 samples: rejected loudly, not planned slowly
+
+
+def test_empty_and_degenerate_inputs():
+    kw = dict(dt=0.2)
+    bp = BatchPlanner(waypoints=(WX, WY), **kw)
+    params, sp = orc.make_params(**kw), orc.Spline(WX, WY)
+    assert len(bp.plan_batch([])) == 0
+    reqs = [PlanRequest(5.0, 0.0, 0.0, 5.0, 0.0),                                      # no obstacles at all
+            PlanRequest(5.0, 0.0, 0.0, 5.0, 0.0, static=np.empty((0, 2)), dyn=np.empty((0, 0, 2))),
+            PlanRequest(5.0, 0.0, 0.0, 5.0, 0.0, dyn=np.full((3, 1, 2), 1e6)),          # everything far away, T = 1
+            PlanRequest(500.0, 300.0, 0.0, 5.0, 0.0, static=np.array([[500.0, 300.0]]))]  # ego far off the path
+    _check(bp, params, sp, reqs)
