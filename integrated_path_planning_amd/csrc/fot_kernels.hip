@@ -64,6 +64,27 @@ __device__ __forceinline__ ScanBest wave_argmin(ScanBest b)
     return b;
 }
 
+// The reference spline (9 coefficient arrays of n knots) copied into LDS: the nearest-point search and the segment
+// lookups are chains of dependent reads of these arrays, each an L2 round trip otherwise.  Paths with more knots than
+// the launch reserved LDS for (lds_knots) stay in HBM.  Dynamic LDS: 9 * lds_knots doubles.
+extern __shared__ double s_spl[];
+constexpr int SPLINE_LDS_KNOTS = 512;
+
+__device__ __forceinline__ SplineView stage_spline(const SplineView &g, int lds_knots)
+{
+    if (g.n > lds_knots) return g;
+    const double *src[9] = { g.s, g.ax, g.bx, g.cx, g.dx, g.ay, g.by, g.cy, g.dy };
+    for (int i = threadIdx.x; i < 9 * g.n; i += blockDim.x) {
+        const int a = i / g.n, j = i - a * g.n;
+        s_spl[i] = src[a][j];
+    }
+    __syncthreads();
+    SplineView l = g;
+    l.s = s_spl; l.ax = s_spl + g.n; l.bx = s_spl + 2 * g.n; l.cx = s_spl + 3 * g.n; l.dx = s_spl + 4 * g.n;
+    l.ay = s_spl + 5 * g.n; l.by = s_spl + 6 * g.n; l.cy = s_spl + 7 * g.n; l.dy = s_spl + 8 * g.n;
+    return l;
+}
+
 // refine_nearest (fot_math.hpp) with the three probes of a round on three lanes: same arithmetic, a third of the
 // dependent spline evaluations.  The result is uniform across the wave.
 __device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, double x, double y, double best_s, int lane)
@@ -87,12 +108,13 @@ __device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, doub
 }
 
 __global__ void __launch_bounds__(WAVE)
-k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
+k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *__restrict__ desc,
                InstState *__restrict__ state, int n_inst)
 {
     int inst = blockIdx.x;
     if (inst >= n_inst) return;
     if (desc[inst].ego.has_prev_s == FOT_PREV_S_CHAINED) return;   // handled by the head of its chain
+    const SplineView sp = stage_spline(sp_hbm, lds_knots);
     const DevParams &P = *Pp;
     const int lane = threadIdx.x;
     const double s_end = sp.s[sp.n - 1];
@@ -154,11 +176,12 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *
 // ---------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(WAVE)
-k_lon_table(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
+k_lon_table(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *__restrict__ desc,
             const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, double *__restrict__ lon_tab,
             float *__restrict__ prof_box)
 {
     const DevParams &P = *Pp;
+    const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave of the grid, before any of them leaves
     const int inst = blockIdx.y;
     const InstDesc &D = desc[inst];
     const InstState &S = state[inst];
@@ -489,6 +512,7 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 // atomics), FAR32-padded to chunk pairs.  Then, per candidate wave of the instance, the chunk range its own
 // profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
 constexpr int CULL_CACHE = 4096;
+constexpr int CULL_UNROLL = 4;
 constexpr uint8_t BIN_OUT = 255;
 
 template <typename T>
@@ -546,10 +570,10 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const int row = k < D.T - 1 ? k : D.T - 1;
     if (lane <= CULL_BINS) s_cnt[lane] = 0;
     __syncthreads();
-    // obstacle i of this time step: exact coordinates, sample id, float32 local coordinates, inside test, bin
-    auto fetch = [&](int i, d2 &o, int &sid, float &fx, float &fy, int &bin) -> bool {
-        o.x = 0.0; o.y = 0.0; sid = SID_STATIC; fx = 0.0f; fy = 0.0f; bin = 0;
-        if (i >= total) return false;
+    // obstacle i of this time step: exact coordinates and sample id (the memory access) ...
+    auto load = [&](int i, d2 &o, int &sid) {
+        o.x = 0.0; o.y = 0.0; sid = SID_STATIC;
+        if (i >= total) return;
         if (i < D.n_static) {
             const int64_t in = D.static_off + i;
             o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
@@ -559,16 +583,29 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
             sid = j / D.P;
         }
+    };
+    // ... and its float32 local coordinates, inside test and bin
+    auto classify = [&](int i, const d2 &o, float &fx, float &fy, int &bin) -> bool {
         fx = (float)(o.x - D.ego.x); fy = (float)(o.y - D.ego.y);
-        if (!cull_inside(b, margin, fx, fy)) return false;
+        bin = 0;
+        if (i >= total || !cull_inside(b, margin, fx, fy)) return false;
         bin = bin_of(bm, fx, fy);
         return true;
     };
-    for (int i0 = 0; i0 < total; i0 += WAVE) {                   // pass 1: histogram
-        d2 o; int sid, bin; float fx, fy;
-        const bool in = fetch(i0 + lane, o, sid, fx, fy, bin);
-        if (in) atomicAdd(&s_cnt[bin], 1);
-        if (i0 + lane < CULL_CACHE) s_bin[i0 + lane] = in ? (uint8_t)bin : BIN_OUT;
+    // pass 1: histogram.  The loads of CULL_UNROLL batches are issued together: the time row is a strided gather (one
+    // cache line per obstacle), and the wave would otherwise pay its latency once per batch.
+    for (int i0 = 0; i0 < total; i0 += CULL_UNROLL * WAVE) {
+        d2 o[CULL_UNROLL]; int sid[CULL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CULL_UNROLL; ++u) load(i0 + u * WAVE + lane, o[u], sid[u]);
+#pragma unroll
+        for (int u = 0; u < CULL_UNROLL; ++u) {
+            const int i = i0 + u * WAVE + lane;
+            float fx, fy; int bin;
+            const bool in = classify(i, o[u], fx, fy, bin);
+            if (in) atomicAdd(&s_cnt[bin], 1);
+            if (i < CULL_CACHE) s_bin[i] = in ? (uint8_t)bin : BIN_OUT;
+        }
     }
     __syncthreads();
     // exclusive prefix over the bins (lane = bin; lane CULL_BINS ends with the total)
@@ -585,10 +622,11 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __syncthreads();
     const int count = s_start[CULL_BINS];
     for (int i0 = 0; i0 < total; i0 += WAVE) {                   // pass 2: scatter (order inside a bin is irrelevant)
-        d2 o; int sid, bin; float fx, fy;
         const int i = i0 + lane;
         if (i < CULL_CACHE && (i >= total || s_bin[i] == BIN_OUT)) continue;      // culled in pass 1: nothing to read
-        if (fetch(i, o, sid, fx, fy, bin)) {
+        d2 o; int sid, bin; float fx, fy;
+        load(i, o, sid);
+        if (classify(i, o, fx, fy, bin)) {
             const int pos = atomicAdd(&s_cnt[bin], 1);
             ent32_store(ent32, base + pos, fx, fy);
             ent64[base + pos] = o;
@@ -959,7 +997,8 @@ int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc,
                         hipStream_t st)
 {
     if (n_inst <= 0) return 0;
-    k_frenet_state<<<n_inst, WAVE, 0, st>>>(P, sp, desc, state, n_inst);
+    const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
+    k_frenet_state<<<n_inst, WAVE, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -969,7 +1008,9 @@ int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, co
 {
     if (n_inst <= 0 || max_lon <= 0) return 0;
     dim3 grid((unsigned)max_lon, (unsigned)n_inst);
-    k_lon_table<<<grid, WAVE, 0, st>>>(P, sp, desc, state, lon_info, lon_tab, prof_box);
+    const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
+    k_lon_table<<<grid, WAVE, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, lon_info, lon_tab,
+                                                                       prof_box);
     FOT_LAUNCH_CHECK();
     return 0;
 }
