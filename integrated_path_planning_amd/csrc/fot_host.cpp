@@ -65,14 +65,14 @@ struct Workspace {
     bool staging_pending = false;
     PinnedBuf staging;
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
-    DevBuf dState, dLonInfo, dLonTab;
+    DevBuf dState, dLonInfo;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
     DevBuf dProfBox, dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: profile boxes + culled entry lists
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
-        DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dLonTab, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
+        DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
                            &dProfBox, &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
         for (DevBuf *b : bufs) b->release();
         staging.release();
@@ -225,7 +225,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dMeta.ensure(meta_bytes));
     HIP_TRY(h, w.dState.ensure(sizeof(InstState) * (size_t)L.n_inst));
     HIP_TRY(h, w.dLonInfo.ensure(sizeof(LonInfo) * (size_t)std::max<int64_t>(L.n_lon, 1)));
-    HIP_TRY(h, w.dLonTab.ensure(sizeof(double) * LON_FIELDS * FOT_MAX_NT * (size_t)std::max<int64_t>(L.n_lon, 1)));
     const size_t slots = (size_t)std::max<int64_t>(L.n_slots, 1);
     HIP_TRY(h, w.dCost.ensure(sizeof(double) * slots));
     HIP_TRY(h, w.dVlast.ensure(sizeof(double) * slots));
@@ -263,7 +262,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     {
         ProfScope ps(h, 1, st);
         LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                       w.dLonTab.as<double>(), w.dProfBox.as<float>(), L.n_inst, L.max_lon, st));
+                                       w.dProfBox.as<float>(), L.n_inst, L.max_lon, st));
     }
     if (L.any_obstacles) {
         ProfScope ps(h, 2, st);
@@ -272,14 +271,13 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     }
     {
         ProfScope ps(h, 3, st);
-        LAUNCH_TRY(h, launch_evaluate(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                      w.dLonTab.as<double>(), (int)L.n_lon, P.n_total, d_wave_inst, d_wave_base,
-                                      L.n_waves, ea, ca, st));
+        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(), P.n_total,
+                                      d_wave_inst, d_wave_base, L.n_waves, ea, ca, st));
     }
     {
         ProfScope ps(h, 4, st);
         LAUNCH_TRY(h, launch_select(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                    w.dLonTab.as<double>(), ca, d_out, L.n_inst, st));
+                                    sv, ca, d_out, L.n_inst, st));
     }
     return FOT_OK;
 }
@@ -758,7 +756,7 @@ int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double 
     HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * 2));
     HIP_TRY(h, hipMemsetAsync(h->dTmpA.p, 0, sizeof(double) * 15 * FOT_MAX_NT, h->stream));
     LAUNCH_TRY(h, launch_debug_path(h->dP.as<DevParams>(), (const InstDesc *)w->dMeta.p, w->dState.as<InstState>(),
-                                    w->dLonInfo.as<LonInfo>(), w->dLonTab.as<double>(), local, index,
+                                    w->dLonInfo.as<LonInfo>(), spline_view(h), local, index,
                                     h->dTmpA.as<double>(), h->dTmpD.as<int32_t>(), h->stream));
     int32_t meta[2] = { 0, 0 };
     HIP_TRY(h, hipMemcpyAsync(arrays, h->dTmpA.p, sizeof(double) * 15 * FOT_MAX_NT, hipMemcpyDeviceToHost, h->stream));

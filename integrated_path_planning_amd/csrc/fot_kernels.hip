@@ -2,8 +2,8 @@
 //
 // Pipeline of one fot_plan_batch (one launch each over the whole batch; every decision in float64):
 //   k_frenet_state : 1 wave / instance: nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
-//   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t), and the
-//                    float32 bounding box of the profile's lateral candidates at that sample (two end points of a
+//   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t) -> profile
+//                    summary (jerk sum, final speed) and the float32 bounding box of the profile's lateral candidates at that sample (two end points of a
 //                    segment: the quintic is affine in its target offset)
 //   k_cull         : 1 wave / (instance, time step): merges the profile boxes, then compacts the obstacles of that
 //                    time row that lie inside the grown box into an entry list (ballot + popcount prefix)
@@ -70,7 +70,7 @@ __device__ __forceinline__ ScanBest wave_argmin(ScanBest b)
 extern __shared__ double s_spl[];
 constexpr int SPLINE_LDS_KNOTS = 512;
 
-__device__ __forceinline__ SplineView stage_spline(const SplineView &g, int lds_knots)
+__device__ __forceinline__ SplineView stage_spline(const SplineView &g, int lds_knots, double *s_spl = fot::s_spl)
 {
     if (g.n > lds_knots) return g;
     const double *src[9] = { g.s, g.ax, g.bx, g.cx, g.dx, g.ay, g.by, g.cy, g.dy };
@@ -177,8 +177,7 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
 
 __global__ void __launch_bounds__(WAVE)
 k_lon_table(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *__restrict__ desc,
-            const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, double *__restrict__ lon_tab,
-            float *__restrict__ prof_box)
+            const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, float *__restrict__ prof_box)
 {
     const DevParams &P = *Pp;
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave of the grid, before any of them leaves
@@ -205,17 +204,11 @@ k_lon_table(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, 
     }
     const int k = threadIdx.x;
     Box32 box = box_empty();
-    double *tab = lon_tab + (int64_t)(D.lon_off + slot) * (LON_FIELDS * FOT_MAX_NT);
     double jerk2 = 0.0, sd_k = 0.0;
     if (k < L.n_t) {
         LonSample ls;
         double sddd;
-        make_lon_sample(sp, L, k, P.dt, ls, sddd);
-        tab[0 * FOT_MAX_NT + k] = ls.s;     tab[1 * FOT_MAX_NT + k] = ls.sd;    tab[2 * FOT_MAX_NT + k] = ls.sdd;
-        tab[3 * FOT_MAX_NT + k] = ls.rx;    tab[4 * FOT_MAX_NT + k] = ls.ry;
-        tab[5 * FOT_MAX_NT + k] = ls.cos_r; tab[6 * FOT_MAX_NT + k] = ls.sin_r;
-        tab[7 * FOT_MAX_NT + k] = ls.kr;    tab[8 * FOT_MAX_NT + k] = ls.dkr;
-        tab[9 * FOT_MAX_NT + k] = ls.inv_sd;
+        make_lon_sample(sp, L, k, P.dt, ls, sddd);          // the rows themselves are rebuilt where they are used
         jerk2 = sddd * sddd;
         sd_k = ls.sd;
         box = profile_box(P, S.frenet0, brake, lat_ti, ls, k, L.n_eval, D.ego.x, D.ego.y);
@@ -388,37 +381,50 @@ struct FusedSink {
     __device__ __forceinline__ bool collided() const { return hit; }
 };
 
-// Longitudinal tables of the block's candidates, staged in LDS: the 64 candidates of a wave share two or three
-// longitudinal profiles, whose rows every sample step would otherwise fetch from L2/HBM (two dependent round
-// trips per step).  Layout [profile][k][field]: one row is 80 contiguous bytes.
+// Longitudinal rows of the block's candidates in LDS: the 64 candidates of a wave share two or three longitudinal
+// profiles.  Layout [profile][k][field], 9 fields = 72 contiguous bytes per row (the arc length s is not in the row:
+// only the low-speed rule and the travelled distance read it, and they rebuild it from the profile's polynomial).
 constexpr int EVAL_WG = WAVES_PER_GROUP * WAVE;
-constexpr int EVAL_LDS_BYTES = 52 * 1024;                         // three workgroups per CU within 160 KB of LDS
+constexpr int EVAL_LDS_BYTES = 53000;                             // three workgroups per CU within 160 KB of LDS
 constexpr int EVAL_LDS_PROFILES_MAX = 16;
 extern __shared__ double s_lon[];
 
+constexpr int ROW_FIELDS = 9;
+
 struct StagedTab {
     int lds_row0;                        // index of this lane's profile row 0 in s_lon, or -1: not staged
-    const double *glob;                  // [field][FOT_MAX_NT] in HBM
+    int g;                               // lanes outside the block's window rebuild the row of profile g on the spot
+    const LonInfo *lon_info;             //   (re-read per step: nothing of it is kept in registers across the loop)
+    SplineView sp;
+    double dt;
     __device__ __forceinline__ void load(int k, LonSample &L) const
     {
         if (lds_row0 >= 0) {
-            const double *r = s_lon + lds_row0 + k * LON_FIELDS;
-            L.s = r[0]; L.sd = r[1]; L.sdd = r[2]; L.rx = r[3]; L.ry = r[4];
-            L.cos_r = r[5]; L.sin_r = r[6]; L.kr = r[7]; L.dkr = r[8]; L.inv_sd = r[9];
+            const double *r = s_lon + lds_row0 + k * ROW_FIELDS;
+            L.s = 0.0; L.sd = r[0]; L.sdd = r[1]; L.rx = r[2]; L.ry = r[3];
+            L.cos_r = r[4]; L.sin_r = r[5]; L.kr = r[6]; L.dkr = r[7]; L.inv_sd = r[8];
         } else {
-            load_lon_sample(glob, k, L);
+            ComputeTab direct;
+            direct.sp = sp; direct.L = lon_info[g]; direct.dt = dt;
+            direct.load(k, L);
         }
         // the row is in registers from here on: what follows (the sink's scalar warm-up loads) must not sit
         // between these reads and the wait for them
-        asm volatile("" : "+v"(L.s), "+v"(L.sd), "+v"(L.sdd), "+v"(L.rx), "+v"(L.ry), "+v"(L.cos_r), "+v"(L.sin_r),
+        asm volatile("" : "+v"(L.sd), "+v"(L.sdd), "+v"(L.rx), "+v"(L.ry), "+v"(L.cos_r), "+v"(L.sin_r),
                           "+v"(L.kr), "+v"(L.dkr), "+v"(L.inv_sd));
+    }
+    __device__ __forceinline__ double s_at(int k) const
+    {
+        ComputeTab direct;
+        direct.sp = sp; direct.L = lon_info[g]; direct.dt = dt;
+        return direct.s_at(k);
     }
 };
 
 __global__ void __launch_bounds__(EVAL_WG)
-k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-           const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab, int n_lon, int lds_profiles,
-           int ablate, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
+k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
+           const InstState *__restrict__ state, const LonInfo *__restrict__ lon_info, int lds_profiles,
+           int lds_knots, int ablate, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
            const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
            const uint8_t *__restrict__ ent_sid,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
@@ -426,23 +432,34 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 {
     const DevParams &P = *Pp;
     const int n_total = P.n_total;
-    // --- stage the profiles [g_lo, g_lo + lds_profiles) of the global profile index space; g_lo is the profile
-    //     of the block's first candidate (block-uniform; a block never spans two instances)
+    // --- the rows of the profiles [g_lo, g_lo + n_stage) of the block's instance, built straight into LDS (no
+    //     table in HBM): g_lo is the profile of the block's first candidate; a block never spans two instances
     const int wave_first = blockIdx.x * (EVAL_WG / WAVE);
-    int g_lo = 0;
+    int g_lo = 0, n_stage = 0;
     {
         const int inst0 = wave_inst[wave_first];                  // wave_first < n_waves by construction of the grid
         const InstDesc &D0 = desc[inst0];
         const InstState &S0 = state[inst0];
         const int idx0 = wave_base[wave_first];
-        g_lo = D0.lon_off + (S0.c2f_ok && idx0 < S0.n_cand ? decode_candidate(P, D0, S0.frenet0, idx0).lon_slot : 0);
+        if (S0.c2f_ok && idx0 < S0.n_cand) {
+            const int slot0 = decode_candidate(P, D0, S0.frenet0, idx0).lon_slot;
+            const int n_prof = P.n_ti * D0.n_tv + S0.n_brake;     // valid profiles of the instance
+            g_lo = D0.lon_off + slot0;
+            n_stage = n_prof - slot0 < lds_profiles ? n_prof - slot0 : lds_profiles;
+        }
     }
-    const int n_stage = n_lon - g_lo < lds_profiles ? n_lon - g_lo : lds_profiles;
-    const int per_prof = LON_FIELDS * n_total;
-    for (int i = threadIdx.x; i < n_stage * per_prof; i += EVAL_WG) {
-        const int p = i / per_prof, rem = i - p * per_prof;
-        const int f = rem / n_total, k = rem - f * n_total;       // k fastest: coalesced reads of one field
-        s_lon[(p * n_total + k) * LON_FIELDS + f] = lon_tab[((int64_t)(g_lo + p) * LON_FIELDS + f) * FOT_MAX_NT + k];
+    const SplineView sp_lds = stage_spline(sp, lds_knots, s_lon + lds_profiles * n_total * ROW_FIELDS);   // behind the rows
+    for (int i = threadIdx.x; i < n_stage * n_total; i += EVAL_WG) {
+        const int p = i / n_total, k = i - p * n_total;
+        const LonInfo Lp = lon_info[g_lo + p];
+        if (k < Lp.n_t) {
+            LonSample ls;
+            double sddd;
+            make_lon_sample(sp_lds, Lp, k, P.dt, ls, sddd);
+            double *r = s_lon + (p * n_total + k) * ROW_FIELDS;
+            r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx; r[3] = ls.ry;
+            r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
+        }
     }
     __syncthreads();
 
@@ -468,8 +485,8 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int g = D.lon_off + cd.lon_slot;
     const LonInfo L = lon_info[g];
     StagedTab tab;
-    tab.lds_row0 = (unsigned)(g - g_lo) < (unsigned)n_stage ? (g - g_lo) * n_total * LON_FIELDS : -1;
-    tab.glob = lon_tab + (int64_t)g * (LON_FIELDS * FOT_MAX_NT);
+    tab.lds_row0 = (unsigned)(g - g_lo) < (unsigned)n_stage ? (g - g_lo) * n_total * ROW_FIELDS : -1;
+    tab.g = g; tab.lon_info = lon_info; tab.sp = sp; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
 
@@ -668,7 +685,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
 
 __global__ void __launch_bounds__(WAVE)
 k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-         const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab,
+         const LonInfo *__restrict__ lon_info, SplineView sp,
          const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
          const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
          const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
@@ -731,7 +748,8 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
     const int keep = cand_keep[(int64_t)D.cand_off + best.idx];
     const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
     const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
-    const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+    ComputeTab tab;
+    tab.sp = sp; tab.L = L; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
     if (lane < keep) {
@@ -755,7 +773,7 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
 
 __global__ void __launch_bounds__(WAVE)
 k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-             const LonInfo *__restrict__ lon_info, const double *__restrict__ lon_tab, int inst, int idx,
+             const LonInfo *__restrict__ lon_info, SplineView sp, int inst, int idx,
              double *__restrict__ out /* [15][FOT_MAX_NT] */, int32_t *__restrict__ meta /* n_t, valid */)
 {
     const DevParams &P = *Pp;
@@ -765,7 +783,8 @@ k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc
     if (!S.c2f_ok || idx < 0 || idx >= S.n_cand) { if (lane == 0) { meta[0] = 0; meta[1] = 0; } return; }
     const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
     const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
-    const double *tab = lon_tab + (int64_t)(D.lon_off + cd.lon_slot) * (LON_FIELDS * FOT_MAX_NT);
+    ComputeTab tab;
+    tab.sp = sp; tab.L = L; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
     if (lane < L.n_t) {
@@ -847,8 +866,8 @@ __global__ void k_check_ext(const DevParams *__restrict__ Pp, const InstDesc *__
     for (int k = 0; k < n; ++k) {
         PathSample ps;
         ps.x = ax[k]; ps.y = ay[k]; ps.cos_t = cos(ayaw[k]); ps.sin_t = sin(ayaw[k]);
-        ps.kappa = ac[k]; ps.v = av[k]; ps.a = aa[k]; ps.d = ad[k]; ps.s = as[k];
-        check_sample(lc, acc, k, ps, has_geo, has_d);
+        ps.kappa = ac[k]; ps.v = av[k]; ps.a = aa[k]; ps.d = ad[k];
+        check_sample(lc, acc, k, ps, has_geo, has_d, [&] { return fabs(as[k] - as[k - 1]); });
     }
     int st = check_status(D, acc, n);
     if (st == ST_PENDING && n > 0 && collide_candidate(P, D, obs, n, src)) st = FOT_ST_COLLISION;
@@ -1004,13 +1023,12 @@ int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc,
 }
 
 int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                     LonInfo *lon_info, double *lon_tab, float *prof_box, int n_inst, int max_lon, hipStream_t st)
+                     LonInfo *lon_info, float *prof_box, int n_inst, int max_lon, hipStream_t st)
 {
     if (n_inst <= 0 || max_lon <= 0) return 0;
     dim3 grid((unsigned)max_lon, (unsigned)n_inst);
     const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
-    k_lon_table<<<grid, WAVE, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, lon_info, lon_tab,
-                                                                       prof_box);
+    k_lon_table<<<grid, WAVE, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, lon_info, prof_box);
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -1033,18 +1051,19 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
     return 0;
 }
 
-int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
-                    const double *lon_tab, int n_lon, int n_total, const int32_t *wave_inst,
+int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
+                    const LonInfo *lon_info, int n_total, const int32_t *wave_inst,
                     const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
     const int wpb = EVAL_WG / WAVE;
-    const size_t per_prof = sizeof(double) * LON_FIELDS * (size_t)n_total;
-    int lds_profiles = (int)(EVAL_LDS_BYTES / per_prof);
+    const size_t per_prof = sizeof(double) * ROW_FIELDS * (size_t)n_total;
+    const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
+    int lds_profiles = (int)((EVAL_LDS_BYTES - sizeof(double) * 9 * (size_t)lds_knots) / per_prof);
     if (lds_profiles > EVAL_LDS_PROFILES_MAX) lds_profiles = EVAL_LDS_PROFILES_MAX;
-    const size_t lds = per_prof * (size_t)lds_profiles;
+    const size_t lds = per_prof * (size_t)lds_profiles + sizeof(double) * 9 * (size_t)lds_knots;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
-    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, desc, state, lon_info, lon_tab, n_lon, lds_profiles,
+    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, sp, desc, state, lon_info, lds_profiles, lds_knots,
                                                                 ablate, wave_inst,
                                                                 wave_base, n_waves, e.rng, e.e32, e.e64, e.sid,
                                                                 c.cost, c.v_last, c.travel, c.status, c.keep);
@@ -1053,19 +1072,19 @@ int launch_evaluate(const DevParams *P, const InstDesc *desc, const InstState *s
 }
 
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
-                  const double *lon_tab, CandArrays c, fot_result *out, int n_inst, hipStream_t st)
+                  SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st)
 {
     if (n_inst <= 0) return 0;
-    k_select<<<n_inst, WAVE, 0, st>>>(P, desc, state, lon_info, lon_tab, c.cost, c.v_last, c.travel, c.status,
+    k_select<<<n_inst, WAVE, 0, st>>>(P, desc, state, lon_info, sp, c.cost, c.v_last, c.travel, c.status,
                                      c.keep, out, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
-                      const double *lon_tab, int inst, int idx, double *out, int32_t *meta, hipStream_t st)
+                      SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st)
 {
-    k_debug_path<<<1, WAVE, 0, st>>>(P, desc, state, lon_info, lon_tab, inst, idx, out, meta);
+    k_debug_path<<<1, WAVE, 0, st>>>(P, desc, state, lon_info, sp, inst, idx, out, meta);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -354,7 +354,7 @@ struct CandResult {
 // kept prefix of a path.  One sample at a time, so the lattice kernel and the external-path entry
 // (fot_check_paths) share the exact same tests.
 struct PathSample {
-    double x, y, cos_t, sin_t, kappa, v, a, d, s;
+    double x, y, cos_t, sin_t, kappa, v, a, d;
 };
 
 // What the per-sample loop reads of the planner and instance constants, by value: k_evaluate keeps these in
@@ -394,15 +394,18 @@ FOT_HD void check_init(CheckAcc &c)
 {
     c.fl = 0;
     c.max_step2 = -INFINITY;
-    c.prev.x = c.prev.y = c.prev.kappa = c.prev.v = c.prev.a = c.prev.d = c.prev.s = 0.0;
+    c.prev.x = c.prev.y = c.prev.kappa = c.prev.v = c.prev.a = c.prev.d = 0.0;
     c.prev.cos_t = 1.0; c.prev.sin_t = 0.0;
 }
 
 FOT_HD void check_flag(CheckAcc &c, bool cond, uint32_t bit) { c.fl |= cond ? bit : 0u; }
 
 // k = index of the sample inside the path; has_geo / has_d: the low-speed rules and the road test
-// only apply when the caller's path carries the arrays they read (:1013-1022, :982)
-FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSample &p, bool has_geo, bool has_d)
+// only apply when the caller's path carries the arrays they read (:1013-1022, :982).  arc_step() returns
+// |s_k - s_{k-1}|; it is only asked for in the low-speed branch.
+template <class ArcStep>
+FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSample &p, bool has_geo, bool has_d,
+                         const ArcStep &arc_step)
 {
     check_flag(c, !(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa)), CK_NONFINITE);     // :944-946
     if (k > 0) {
@@ -416,7 +419,7 @@ FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSampl
             check_flag(c, fabs(p.kappa) > C.lim_curv, CK_CURV);
         } else if (has_geo) {
             const double dd = fabs(p.d - c.prev.d);
-            const double d_s = fabs(p.s - c.prev.s);
+            const double d_s = arc_step();
             check_flag(c, dd > fmax(1.5 * d_s, 0.02), CK_CURV);                               // lateral slip
             const double sn = p.sin_t * c.prev.cos_t - p.cos_t * c.prev.sin_t;                // sin/cos of the yaw step
             const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
@@ -459,10 +462,31 @@ FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d,
 //   put(k, circle, x, y, alive)   collision point of sample k of the kept prefix; alive == false when the candidate
 //                                 has already failed a check, i.e. can no longer end as "collision check outstanding"
 // and collided() tells whether the points handed over so far violate the (chance) constraint.
-// Tab::load(k, LonSample&) returns row k of the candidate's longitudinal table (GlobalTab: straight from HBM).
+// Tab::load(k, LonSample&) returns row k of the candidate's longitudinal profile: state and reference frame at s(t_k).
+// GlobalTab reads a [field][FOT_MAX_NT] table from memory, ComputeTab evaluates the row on the spot (rows past the
+// profile's n_t are never used and come back unspecified).
 struct GlobalTab {
     const double *tab;
     FOT_HD void load(int k, LonSample &L) const { load_lon_sample(tab, k, L); }
+    FOT_HD double s_at(int k) const { return tab[k]; }
+};
+
+struct ComputeTab {
+    SplineView sp;
+    LonInfo L;
+    double dt;
+    FOT_HD void load(int k, LonSample &o) const
+    {
+        double sddd;
+        if (k < L.n_t) make_lon_sample(sp, L, k, dt, o, sddd);
+        else { o.s = o.sd = o.sdd = o.rx = o.ry = o.cos_r = o.sin_r = o.kr = o.dkr = o.inv_sd = 0.0; }
+    }
+    FOT_HD double s_at(int k) const
+    {
+        double s_, u0, u1, u2;
+        lon_sample(L, k, dt, s_, u0, u1, u2);
+        return s_;
+    }
 };
 
 template <class Tab, class Sink>
@@ -472,7 +496,8 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
     const int n_t = L.n_t;
     double Jp = 0.0, d_last = 0.0;
     int first_nan = -1;
-    double v_last = 0.0, s_last = 0.0, s_first = 0.0;
+    double v_last = 0.0;
+    int k_last = -1;                                     // last sample of the kept prefix seen so far
     CheckAcc acc;
     check_init(acc);
 
@@ -494,9 +519,8 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
         if (!(acc.fl & CK_SEEN_NAN)) {
             PathSample ps;
             ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
-            ps.v = c.v; ps.a = c.a; ps.d = d; ps.s = ls.s;
-            check_sample(C, acc, k, ps, true, true);
-            if (k == 0) s_first = ls.s;
+            ps.v = c.v; ps.a = c.a; ps.d = d;
+            check_sample(C, acc, k, ps, true, true, [&] { return fabs(lon_tab.s_at(k) - lon_tab.s_at(k - 1)); });
             const bool alive = (acc.fl & CK_FAILED) == 0;
             if (C.n_circ_fp > 0) {
                 for (int ci = 0; ci < C.n_circ_fp; ++ci)
@@ -504,7 +528,7 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
             } else {
                 sink.put(k, 0, c.x, c.y, alive);
             }
-            v_last = c.v; s_last = ls.s;
+            v_last = c.v; k_last = k;
         }
       }
       sink.row_end(k);
@@ -526,7 +550,7 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
     out.status = st;
     out.keep = keep;
     out.v_last = v_last;
-    out.travel = s_last - s_first;
+    out.travel = k_last >= 0 ? lon_tab.s_at(k_last) - lon_tab.s_at(0) : 0.0;     // NaN is sticky: sample 0 was valid
 }
 
 // ---------------------------------------------------------------------------
@@ -872,14 +896,15 @@ FOT_HD CandDecode decode_candidate(const DevParams &P, const InstDesc &D, const 
 }
 
 // the 15 FrenetPath values of sample k of one candidate (data_structures.py:164-178 order)
-FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const double *lon_tab, const double *q, int k,
+template <class Tab>
+FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const Tab &lon_tab, const double *q, int k,
                          double *o /*[15]*/)
 {
     double s, sd, sdd, sddd, d, d_d, d_dd, d_ddd;
     lon_sample(L, k, P.dt, s, sd, sdd, sddd);
     lat_sample(q, k, L.n_eval, P.dt, d, d_d, d_dd, d_ddd);
     LonSample ls;
-    load_lon_sample(lon_tab, k, ls);
+    lon_tab.load(k, ls);
     CartSample c;
     frenet_to_cart(ls, d, d_d, d_dd, c);
     o[0] = (double)k * P.dt;

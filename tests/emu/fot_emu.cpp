@@ -232,7 +232,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             double *dst[15] = { R.t, R.s, R.s_d, R.s_dd, R.s_ddd, R.d, R.d_d, R.d_dd, R.d_ddd, R.x, R.y, R.yaw, R.v, R.a, R.c };
             for (int k = 0; k < best_keep; ++k) {
                 double o[15];
-                final_sample(P, Li, tab, q, k, o);
+                final_sample(P, Li, GlobalTab{ tab }, q, k, o);
                 for (int f = 0; f < 15; ++f) dst[f][k] = o[f];
             }
             if (best_keep > 1) R.new_last_kappa = R.c[1];
