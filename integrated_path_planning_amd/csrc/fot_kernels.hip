@@ -530,6 +530,7 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
 // profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
 constexpr int CULL_CACHE = 4096;
 constexpr int CULL_UNROLL = 4;
+constexpr int CULL_LIST = 1024;
 constexpr uint8_t BIN_OUT = 255;
 
 template <typename T>
@@ -542,6 +543,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __shared__ int s_cnt[CULL_BINS + 1];                         // pass 1: entries per bin; pass 2: write cursors
     __shared__ int s_start[CULL_BINS + 1];
     __shared__ uint8_t s_bin[CULL_CACHE];                        // bin of obstacle i (BIN_OUT: culled), first CULL_CACHE
+    __shared__ uint32_t s_list[CULL_LIST];                       // indices of the obstacles pass 1 kept (any order)
+    __shared__ int s_nin;
     const DevParams &P = *Pp;
     // XCD-aware block -> (instance, time step) map.  Workgroups are dealt round-robin over the 8 XCDs
     // (blocks b and b+8 share one), and 8 consecutive time steps of one pedestrian share a cache line of
@@ -586,6 +589,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const int total = D.n_static + n_dyn;
     const int row = k < D.T - 1 ? k : D.T - 1;
     if (lane <= CULL_BINS) s_cnt[lane] = 0;
+    if (lane == 0) s_nin = 0;
     __syncthreads();
     // obstacle i of this time step: exact coordinates and sample id (the memory access) ...
     auto load = [&](int i, d2 &o, int &sid) {
@@ -620,7 +624,11 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             const int i = i0 + u * WAVE + lane;
             float fx, fy; int bin;
             const bool in = classify(i, o[u], fx, fy, bin);
-            if (in) atomicAdd(&s_cnt[bin], 1);
+            if (in) {
+                atomicAdd(&s_cnt[bin], 1);
+                const int j = atomicAdd(&s_nin, 1);
+                if (j < CULL_LIST) s_list[j] = (uint32_t)i;
+            }
             if (i < CULL_CACHE) s_bin[i] = in ? (uint8_t)bin : BIN_OUT;
         }
     }
@@ -638,9 +646,14 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     if (lane <= CULL_BINS) { s_start[lane] = start; s_cnt[lane] = start; }
     __syncthreads();
     const int count = s_start[CULL_BINS];
-    for (int i0 = 0; i0 < total; i0 += WAVE) {                   // pass 2: scatter (order inside a bin is irrelevant)
-        const int i = i0 + lane;
-        if (i < CULL_CACHE && (i >= total || s_bin[i] == BIN_OUT)) continue;      // culled in pass 1: nothing to read
+    // pass 2: scatter (order inside a bin is irrelevant).  Normally straight from the list of kept indices -- one
+    // gather for all of them; lists that overflowed fall back to re-scanning the whole time row.
+    const bool listed = count <= CULL_LIST;
+    const int n_pass2 = listed ? count : total;
+    for (int i0 = 0; i0 < n_pass2; i0 += WAVE) {
+        int i = i0 + lane;
+        if (listed) { if (i >= count) continue; i = (int)s_list[i]; }
+        else if (i < CULL_CACHE && (i >= total || s_bin[i] == BIN_OUT)) continue;  // culled in pass 1: nothing to read
         d2 o; int sid, bin; float fx, fy;
         load(i, o, sid);
         if (classify(i, o, fx, fy, bin)) {
