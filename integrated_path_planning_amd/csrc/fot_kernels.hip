@@ -696,27 +696,31 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
 // selection + output
 // ---------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(WAVE)
+constexpr int SELECT_WG = 256;
+
+__global__ void __launch_bounds__(SELECT_WG)
 k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
          const LonInfo *__restrict__ lon_info, SplineView sp,
          const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
          const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
          const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
 {
+    __shared__ int s_cnt[SELECT_WG / WAVE][8];
+    __shared__ ScanBest s_best[SELECT_WG / WAVE];
     const int inst = blockIdx.x;
     if (inst >= n_inst) return;
     const DevParams &P = *Pp;
     const InstDesc &D = desc[inst];
     const InstState &S = state[inst];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     fot_result &R = out[inst];
-    // the record starts out all zero (stores of one wave to one address retire in program order, so the
-    // fields written below win)
-    for (int i = lane; i < (int)(sizeof(fot_result) / sizeof(unsigned long long)); i += WAVE)
+    // the record starts out all zero; the fields are written after the barrier below
+    for (int i = tid; i < (int)(sizeof(fot_result) / sizeof(unsigned long long)); i += SELECT_WG)
         ((unsigned long long *)&R)[i] = 0ull;
 
     if (!S.c2f_ok) {
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
             R.status = FOT_PLAN_C2F_FAILED; R.best_index = -1; R.n_cand = 0; R.n_keep = 0;
             R.cost = INFINITY; R.stats_valid = 0;
             R.new_last_kappa = D.ego.last_kappa; R.new_prev_s = S.new_prev_s;
@@ -725,9 +729,10 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
         return;
     }
 
+    // four waves over the candidates (a quarter of the dependent load rounds of one wave), merged through LDS
     int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     ScanBest best = { INFINITY, -1 };
-    for (int idx = lane; idx < S.n_cand; idx += WAVE) {
+    for (int idx = tid; idx < S.n_cand; idx += SELECT_WG) {
         const int64_t slot = (int64_t)D.cand_off + idx;
         int st = cand_status[slot];
         st = final_status(st, cand_vlast[slot], cand_travel[slot], D.max_stop);
@@ -736,13 +741,23 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
         for (int c = 0; c < 8; ++c) cnt[c] += (st == c) ? 1 : 0;
         if (st == FOT_ST_OK) {
             const double cost = cand_cost[slot];
-            if (cost < best.dist) { best.dist = cost; best.idx = idx; }   // first strict minimum of this lane
+            if (cost < best.dist) { best.dist = cost; best.idx = idx; }   // first strict minimum of this thread
         }
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         for (int off = 32; off >= 1; off >>= 1) cnt[c] += __shfl_xor(cnt[c], off, WAVE);
     best = wave_argmin(best);                                              // lowest index wins ties
+    if (lane == 0) {
+        for (int c = 0; c < 8; ++c) s_cnt[wv][c] = cnt[c];
+        s_best[wv] = best;
+    }
+    __syncthreads();                                                       // also orders the zero fill before the fields
+    if (wv != 0) return;
+    for (int w = 1; w < SELECT_WG / WAVE; ++w) {
+        for (int c = 0; c < 8; ++c) cnt[c] += s_cnt[w][c];
+        scan_merge(best, s_best[w]);
+    }
 
     if (lane == 0) {
         R.status = best.idx >= 0 ? FOT_PLAN_OK : FOT_PLAN_NO_PATH;
@@ -1088,7 +1103,7 @@ int launch_select(const DevParams *P, const InstDesc *desc, const InstState *sta
                   SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st)
 {
     if (n_inst <= 0) return 0;
-    k_select<<<n_inst, WAVE, 0, st>>>(P, desc, state, lon_info, sp, c.cost, c.v_last, c.travel, c.status,
+    k_select<<<n_inst, SELECT_WG, 0, st>>>(P, desc, state, lon_info, sp, c.cost, c.v_last, c.travel, c.status,
                                      c.keep, out, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
