@@ -5,8 +5,8 @@
 //   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t) -> profile
 //                    summary (jerk sum, final speed) and the float32 bounding box of the profile's lateral candidates at that sample (two end points of a
 //                    segment: the quintic is affine in its target offset)
-//   k_cull         : 1 wave / (instance, time step): merges the profile boxes, then compacts the obstacles of that
-//                    time row that lie inside the grown box into an entry list (ballot + popcount prefix)
+//   k_cull         : 1 wave / (instance, 8 consecutive time steps): merges the profile boxes, then sorts the obstacles
+//                    of those time rows that lie inside the grown boxes into per-step entry lists (strips, LDS atomics)
 //   k_evaluate     : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks, and -- while
 //                    the candidate can still pass -- the collision test of each sample against the entry list of
 //                    its time step (wave-uniform chunk walk on scalar loads, float32 broad phase, exact float64
@@ -523,144 +523,170 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
 // collision broad phase: entry lists
 // ---------------------------------------------------------------------------
 
-// One wave per (time step k, instance).  Entries of k: the static obstacles and the dynamic obstacles of time row
+// One workgroup of CULL_KG waves per (instance, group of CULL_KG consecutive time steps); wave w owns step k0 + w.  The caller's prediction tensor is
+// [S][P][T][2]: the T samples of one pedestrian are contiguous, so a lane that takes obstacle (s, p) reads its
+// CULL_KG consecutive samples as one contiguous run -- every fetched sector is used -- and classifies it against the
+// boxes of the group's time steps.  Entries of step k: the static obstacles and the dynamic obstacles of time row
 // min(k, T-1) that lie inside the candidates' bounding box of k (merged over the instance's longitudinal profiles)
 // grown by the collision radius, ordered by bin along the longer side of the box (counting sort through LDS
 // atomics), FAR32-padded to chunk pairs.  Then, per candidate wave of the instance, the chunk range its own
 // profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
-constexpr int CULL_CACHE = 4096;
-constexpr int CULL_UNROLL = 4;
-constexpr int CULL_LIST = 1024;
-constexpr uint8_t BIN_OUT = 255;
+constexpr int CULL_KG = 8;
+constexpr int CULL_LIST = 512;          // kept obstacles per time step remembered between the two passes
+constexpr uint32_t CULL_IDX_MASK = 0xFFFFFu;   // obstacle index (< 2^20, fot_setup.hpp) | bin << 20
 
 template <typename T>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(CULL_KG * WAVE)
 k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
        int n_inst, const float *__restrict__ prof_box, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
-       uint32_t *__restrict__ wave_rng)
+       uint32_t *__restrict__ wave_rng, int ablate)
 {
-    __shared__ int s_cnt[CULL_BINS + 1];                         // pass 1: entries per bin; pass 2: write cursors
-    __shared__ int s_start[CULL_BINS + 1];
-    __shared__ uint8_t s_bin[CULL_CACHE];                        // bin of obstacle i (BIN_OUT: culled), first CULL_CACHE
-    __shared__ uint32_t s_list[CULL_LIST];                       // indices of the obstacles pass 1 kept (any order)
-    __shared__ int s_nin;
+    __shared__ int s_cnt[CULL_KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
+    __shared__ int s_start[CULL_KG][CULL_BINS + 1];
+    __shared__ int s_nin[CULL_KG];
+    __shared__ uint32_t s_list[CULL_KG][CULL_LIST];              // kept obstacles of each step: index | bin << 20
+    __shared__ Box32 s_box[CULL_KG];                             // per-step constants
+    __shared__ BinMap s_bm[CULL_KG];
+    __shared__ float s_margin[CULL_KG];
     const DevParams &P = *Pp;
-    // XCD-aware block -> (instance, time step) map.  Workgroups are dealt round-robin over the 8 XCDs
-    // (blocks b and b+8 share one), and 8 consecutive time steps of one pedestrian share a cache line of
-    // the [S][P][T][2] input, so the 8 time steps of a group are given block ids that are equal mod 8:
-    // the line is fetched into one XCD's L2 once instead of into eight.  Speed only, never correctness.
-    const int groups = (P.n_total + 7) >> 3;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int k_in = slot & 7, q = (slot >> 3) * 8 + xcd;       // q = inst * groups + group
-    const int inst = q / groups, k = (q - inst * groups) * 8 + k_in;
-    if (inst >= n_inst || k >= P.n_total) return;
+    const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
+    const int inst = blockIdx.x / groups, k0 = (blockIdx.x - inst * groups) * CULL_KG;
+    if (inst >= n_inst) return;
     const InstDesc &D = desc[inst];
     if (D.ent_cap == 0) return;
     const InstState &S = state[inst];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);   // this wave's time step inside the group
+    const int nk = P.n_total - k0 < CULL_KG ? P.n_total - k0 : CULL_KG;
     const int n_grid_lon = P.n_ti * D.n_tv;
-    // box of time step k over all longitudinal profiles of the instance
-    Box32 b = box_empty();
     const int n_prof = S.c2f_ok ? n_grid_lon + S.n_brake : 0;
-    const float *pbox = prof_box + ((int64_t)D.lon_off * P.n_total + k) * 4;      // + slot * n_total * 4
-    for (int w = lane; w < n_prof; w += WAVE) {
-        const float4 v = *(const float4 *)(pbox + (int64_t)w * P.n_total * 4);
-        Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
-        box_merge(b, o);
-    }
-    b.x0 = wave_min_f32(b.x0); b.y0 = wave_min_f32(b.y0);
-    b.x1 = wave_max_f32(b.x1); b.y1 = wave_max_f32(b.y1);
-    const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
-    uint32_t *rng = wave_rng + (int64_t)D.wave0 * P.n_total + k;                  // + wave * n_total
-    if (!(b.x0 <= b.x1)) {                                       // no candidate has a sample k
-        if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = 0;
-        for (int w = lane; w < D.n_waves; w += WAVE) rng[(int64_t)w * P.n_total] = 0u;
-        return;
-    }
+    const float *pbox = prof_box + (int64_t)D.lon_off * P.n_total * 4;           // + (slot * n_total + k) * 4
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
     const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     const float slack = box_footprint_slack(P);
-    const float margin = cull_margin(sq_max, b) + slack;
-    const BinMap bm = bin_map(b, margin);
+
+    // wave wv: box of time step k0 + wv over all longitudinal profiles of the instance
+    {
+        Box32 bw = box_empty();
+        if (wv < nk)
+            for (int w = lane; w < n_prof; w += WAVE) {
+                const float4 v = *(const float4 *)(pbox + ((int64_t)w * P.n_total + k0 + wv) * 4);
+                Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
+                box_merge(bw, o);
+            }
+        bw.x0 = wave_min_f32(bw.x0); bw.y0 = wave_min_f32(bw.y0);
+        bw.x1 = wave_max_f32(bw.x1); bw.y1 = wave_max_f32(bw.y1);
+        const float mw = cull_margin(sq_max, bw) + slack;
+        if (lane == 0) { s_box[wv] = bw; s_margin[wv] = mw; s_bm[wv] = bin_map(bw, mw); s_nin[wv] = 0; }
+        if (lane <= CULL_BINS) s_cnt[wv][lane] = 0;
+    }
+    __syncthreads();
     const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
     const int n_dyn = dyn_on ? D.S * D.P : 0;
     const int total = D.n_static + n_dyn;
-    const int row = k < D.T - 1 ? k : D.T - 1;
-    if (lane <= CULL_BINS) s_cnt[lane] = 0;
-    if (lane == 0) s_nin = 0;
+
+    // pass 1 (all waves): histogram per step, kept obstacles remembered.  Lane = (obstacle, step): the 8 lanes of
+    // one obstacle read its 8 consecutive samples -- a contiguous 64-byte run of the caller's [S][P][T][2] tensor --
+    // so a wave-wide load touches 8 such runs instead of 64 scattered cache lines.
+    {
+        const int kl = lane & (CULL_KG - 1), sub = lane / CULL_KG;            // this lane's step and obstacle slot
+        const Box32 bl = s_box[kl];
+        const float ml = s_margin[kl];
+        const BinMap bml = s_bm[kl];
+        const bool live_l = kl < nk && bl.x0 <= bl.x1 && !(ablate & 4);
+        const int row_l = k0 + kl < D.T - 1 ? k0 + kl : D.T - 1;
+        constexpr int PER_WAVE = WAVE / CULL_KG, STRIDE = CULL_KG * PER_WAVE, UNROLL = 4;
+        auto fetch = [&](int i, d2 &o) {
+            o.x = 0.0; o.y = 0.0;
+            if (i >= total) return;
+            if (i < D.n_static) {
+                const int64_t in = D.static_off + i;
+                o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
+            } else {
+                const int64_t in = D.dyn_off + (int64_t)(i - D.n_static) * D.T + row_l;   // i - n_static = s*P + p
+                o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
+            }
+        };
+        for (int i0 = wv * PER_WAVE + sub; i0 < total; i0 += UNROLL * STRIDE) {      // UNROLL gathers in flight per lane
+            d2 o[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) fetch(i0 + u * STRIDE, o[u]);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int i = i0 + u * STRIDE;
+                const float fx = (float)(o[u].x - D.ego.x), fy = (float)(o[u].y - D.ego.y);
+                if (i < total && live_l && cull_inside(bl, ml, fx, fy)) {
+                    const int bin = bin_of(bml, fx, fy);
+                    atomicAdd(&s_cnt[kl][bin], 1);
+                    const int j = atomicAdd(&s_nin[kl], 1);
+                    if (j < CULL_LIST) s_list[kl][j] = (uint32_t)i | ((uint32_t)bin << 20);
+                }
+            }
+        }
+    }
     __syncthreads();
-    // obstacle i of this time step: exact coordinates and sample id (the memory access) ...
-    auto load = [&](int i, d2 &o, int &sid) {
-        o.x = 0.0; o.y = 0.0; sid = SID_STATIC;
-        if (i >= total) return;
+    // wave wv: everything else of time step k0 + wv
+    if (wv >= nk) return;
+    const int kk = wv, k = k0 + wv;
+    {   // exclusive prefix over the bins (lane = bin; entry CULL_BINS ends with the total); cursors = starts
+        const int c = lane < CULL_BINS ? s_cnt[kk][lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int t = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += t;
+        }
+        if (lane <= CULL_BINS) { s_start[kk][lane] = incl - c; s_cnt[kk][lane] = incl - c; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // this wave's LDS writes (other lanes') before the reads below
+    __builtin_amdgcn_wave_barrier();
+    const Box32 bk = s_box[kk];
+    const BinMap bmk = s_bm[kk];
+    const float mk = s_margin[kk];
+    const bool live_k = bk.x0 <= bk.x1;
+    const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
+    uint32_t *rng = wave_rng + (int64_t)D.wave0 * P.n_total + k;                   // + wave * n_total
+    const int count = s_start[kk][CULL_BINS];
+    const int row = k < D.T - 1 ? k : D.T - 1;
+    auto point = [&](int i, d2 &o, int &sid) {                                      // obstacle i at step k
+        sid = SID_STATIC;
         if (i < D.n_static) {
             const int64_t in = D.static_off + i;
             o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
         } else {
-            const int j = i - D.n_static;                         // j = s*P + p
+            const int j = i - D.n_static;
             const int64_t in = D.dyn_off + (int64_t)j * D.T + row;
             o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
             sid = j / D.P;
         }
     };
-    // ... and its float32 local coordinates, inside test and bin
-    auto classify = [&](int i, const d2 &o, float &fx, float &fy, int &bin) -> bool {
-        fx = (float)(o.x - D.ego.x); fy = (float)(o.y - D.ego.y);
-        bin = 0;
-        if (i >= total || !cull_inside(b, margin, fx, fy)) return false;
-        bin = bin_of(bm, fx, fy);
-        return true;
-    };
-    // pass 1: histogram.  The loads of CULL_UNROLL batches are issued together: the time row is a strided gather (one
-    // cache line per obstacle), and the wave would otherwise pay its latency once per batch.
-    for (int i0 = 0; i0 < total; i0 += CULL_UNROLL * WAVE) {
-        d2 o[CULL_UNROLL]; int sid[CULL_UNROLL];
-#pragma unroll
-        for (int u = 0; u < CULL_UNROLL; ++u) load(i0 + u * WAVE + lane, o[u], sid[u]);
-#pragma unroll
-        for (int u = 0; u < CULL_UNROLL; ++u) {
-            const int i = i0 + u * WAVE + lane;
-            float fx, fy; int bin;
-            const bool in = classify(i, o[u], fx, fy, bin);
-            if (in) {
-                atomicAdd(&s_cnt[bin], 1);
-                const int j = atomicAdd(&s_nin, 1);
-                if (j < CULL_LIST) s_list[j] = (uint32_t)i;
-            }
-            if (i < CULL_CACHE) s_bin[i] = in ? (uint8_t)bin : BIN_OUT;
-        }
-    }
-    __syncthreads();
-    // exclusive prefix over the bins (lane = bin; lane CULL_BINS ends with the total)
-    int c = lane < CULL_BINS ? s_cnt[lane] : 0;
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const int t = __shfl_up(incl, off, WAVE);
-        if (lane >= off) incl += t;
-    }
-    const int start = incl - c;                                  // lanes >= CULL_BINS: total
-    __syncthreads();
-    if (lane <= CULL_BINS) { s_start[lane] = start; s_cnt[lane] = start; }
-    __syncthreads();
-    const int count = s_start[CULL_BINS];
-    // pass 2: scatter (order inside a bin is irrelevant).  Normally straight from the list of kept indices -- one
-    // gather for all of them; lists that overflowed fall back to re-scanning the whole time row.
-    const bool listed = count <= CULL_LIST;
-    const int n_pass2 = listed ? count : total;
-    for (int i0 = 0; i0 < n_pass2; i0 += WAVE) {
-        int i = i0 + lane;
-        if (listed) { if (i >= count) continue; i = (int)s_list[i]; }
-        else if (i < CULL_CACHE && (i >= total || s_bin[i] == BIN_OUT)) continue;  // culled in pass 1: nothing to read
-        d2 o; int sid, bin; float fx, fy;
-        load(i, o, sid);
-        if (classify(i, o, fx, fy, bin)) {
-            const int pos = atomicAdd(&s_cnt[bin], 1);
-            ent32_store(ent32, base + pos, fx, fy);
+    // pass 2: scatter into the list (order inside a bin is irrelevant)
+    if (count <= CULL_LIST) {                                    // straight from the remembered indices
+        for (int j = lane; j < ((ablate & 2) ? 0 : count); j += WAVE) {
+            const uint32_t e = s_list[kk][j];
+            const int i = (int)(e & CULL_IDX_MASK), bin = (int)(e >> 20);
+            d2 o; int sid;
+            point(i, o, sid);
+            const int pos = atomicAdd(&s_cnt[kk][bin], 1);
+            ent32_store(ent32, base + pos, (float)(o.x - D.ego.x), (float)(o.y - D.ego.y));
             ent64[base + pos] = o;
             ent_sid[base + pos] = (uint8_t)sid;
+        }
+    } else {                                                     // more kept than remembered: classify the row again
+        for (int i0 = 0; i0 < total; i0 += WAVE) {
+            const int i = i0 + lane;
+            if (i >= total) continue;
+            d2 o; int sid;
+            point(i, o, sid);
+            const float fx = (float)(o.x - D.ego.x), fy = (float)(o.y - D.ego.y);
+            if (live_k && cull_inside(bk, mk, fx, fy)) {
+                const int bin = bin_of(bmk, fx, fy);
+                const int pos = atomicAdd(&s_cnt[kk][bin], 1);
+                ent32_store(ent32, base + pos, fx, fy);
+                ent64[base + pos] = o;
+                ent_sid[base + pos] = (uint8_t)sid;
+            }
         }
     }
     const int padded = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);        // whole chunk pairs (k_evaluate)
@@ -675,18 +701,18 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     for (int w = lane; w < D.n_waves; w += WAVE) {
         uint32_t r = 0u;
         const int idx0 = w * WAVE;
-        if (idx0 < S.n_cand) {
+        if (live_k && idx0 < S.n_cand && !(ablate & 1)) {
             const int idx1 = idx0 + WAVE - 1 < S.n_cand - 1 ? idx0 + WAVE - 1 : S.n_cand - 1;
             int s0, s1;
             wave_profile_span(P, D, n_grid_lon, idx0, idx1, s0, s1);
             Box32 wb = box_empty();
             for (int sl = s0; sl <= s1; ++sl) {
-                const float4 v = *(const float4 *)(pbox + (int64_t)sl * P.n_total * 4);
+                const float4 v = *(const float4 *)(pbox + ((int64_t)sl * P.n_total + k) * 4);
                 Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
                 box_merge(wb, o);
             }
             const float wm = cull_margin(sq_max, wb) + slack;
-            r = strip_range(bm, wb, wm, [&](int bb) { return s_start[bb]; });
+            r = strip_range(bmk, wb, wm, [&](int bb) { return s_start[kk][bb]; });
         }
         rng[(int64_t)w * P.n_total] = r;
     }
@@ -1066,15 +1092,14 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
                 hipStream_t st)
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
-    const int groups = (n_total + 7) / 8;
-    const int64_t q_pad = ((int64_t)n_inst * groups + 7) / 8 * 8;          // groups, padded so that every XCD slot exists
-    const unsigned grid = (unsigned)(q_pad * 8);
+    const unsigned grid = (unsigned)((int64_t)n_inst * ((n_total + CULL_KG - 1) / CULL_KG));
+    static const int ablate = getenv("FOT_CULL_ABLATE") ? atoi(getenv("FOT_CULL_ABLATE")) : 0;   // timing diagnostics
     if (dtype == FOT_F32)
-        k_cull<float><<<grid, WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const float *)static_xy,
-                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng);
+        k_cull<float><<<grid, CULL_KG * WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const float *)static_xy,
+                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, ablate);
     else
-        k_cull<double><<<grid, WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const double *)static_xy,
-                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng);
+        k_cull<double><<<grid, CULL_KG * WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const double *)static_xy,
+                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, ablate);
     FOT_LAUNCH_CHECK();
     return 0;
 }
