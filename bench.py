@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--instances-per-gpu", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="diagnostic builds only (FOT_COLLIDE_ABLATE)")
+    ap.add_argument("--no-parity", action="store_true", help="timing diagnostics only (FOT_EVAL_ABLATE / FOT_CULL_ABLATE builds give wrong results)")
     ap.add_argument("--cpu-instances", type=int, default=256,
                     help="instances of the same workload timed on the CPU oracle (~53 ms each)")
     return ap.parse_args()

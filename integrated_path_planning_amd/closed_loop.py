@@ -159,6 +159,28 @@ class _Cfg:
         self.__dict__.update(d)
 
 
+def expand_static_obstacles(static_obstacles, step: float = 0.5) -> np.ndarray:
+    """Rectangles [x_min, x_max, y_min, y_max] -> boundary points every `step` (integrated_simulator.py:805-832)."""
+    if static_obstacles is None or len(static_obstacles) == 0:
+        return np.empty((0, 2))
+    points = []
+    for rect in static_obstacles:
+        if len(rect) != 4:
+            continue
+        x_min, x_max, y_min, y_max = rect
+        xs = np.arange(x_min, x_max + step, step)
+        ys = np.arange(y_min, y_max + step, step)
+        for x in xs:
+            points.append((x, y_min))
+            points.append((x, y_max))
+        for y in ys:
+            points.append((x_min, y))
+            points.append((x_max, y))
+    if len(points) == 0:
+        return np.empty((0, 2))
+    return np.unique(np.array(points), axis=0)
+
+
 def footprint_from_config(config) -> Optional[EgoFootprint]:
     """src/core/footprint.py footprint_from_config: None = legacy single circle."""
     mode = _cfg(config, "ego_footprint", None)
@@ -188,8 +210,7 @@ class BatchedClosedLoop:
             raise NotImplementedError("only the constant-velocity predictor is part of this build (SURVEY 8 f1)")
         if getattr(c, "distribution_aware_planning", False):
             raise NotImplementedError("the cv predictor yields one sample: no distribution to plan against")
-        if len(getattr(c, "static_obstacles", []) or []) > 0:
-            raise NotImplementedError("static obstacle rectangles: not covered by the closed-loop fixtures yet")
+        self.static_obstacle_points = expand_static_obstacles(getattr(c, "static_obstacles", None), step=0.5)
         # engine / resampler: objects with BatchPlanner's / PredictionResampler's methods; the tests drive the
         # host logic with stand-ins when there is no GPU, the product always builds the libfot handle below
         self._owns_engine = engine is None
@@ -338,7 +359,7 @@ class BatchedClosedLoop:
         t0 = time.perf_counter()
         reqs: List[PlanRequest] = []
         plans = []
-        static = np.empty((0, 2))
+        static = self.static_obstacle_points                          # the same array object for every request: packed once
         for ep, dyn, m in zip(eps, dyns, metrics):
             ep.last_clearance = m.get("clearance_ahead", m.get("clearance", float("inf")))
             ladder, r, budget = ep.cycle.prepare(ep.ego, static, dyn, m)

@@ -743,7 +743,7 @@ constexpr int ENT_CHUNK = 8;
 static_assert(ENT_CHUNK == 8, "strip_range assumes 8-entry chunks");                                                // entries per broad-phase chunk
 constexpr int SID_STATIC = 255;                                             // entry is a static obstacle
 // float32 entries are stored chunk-wise as structure of arrays, x[8] then y[8] (64 B): neighbouring
-// obstacles sit in neighbouring registers, which is what the packed-float32 arithmetic of k_collide wants
+// obstacles sit in neighbouring registers, which is what the packed-float32 arithmetic of k_evaluate wants
 struct alignas(64) f2x8 { float x[ENT_CHUNK]; float y[ENT_CHUNK]; };
 
 FOT_HD void ent32_store(f2 *e32, int64_t pos, float x, float y)

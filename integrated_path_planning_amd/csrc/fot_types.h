@@ -14,7 +14,7 @@ namespace fot {
 
 constexpr int WAVE = 64;                 // gfx950 wavefront
 constexpr int WAVES_PER_GROUP = 4;       // waves of one k_evaluate workgroup; instances are padded to whole groups
-constexpr int LON_FIELDS = 10;           // s, s_d, s_dd, rx, ry, cos_r, sin_r, kappa_r, dkappa_r, (spare: s_ddd)
+constexpr int LON_FIELDS = 10;           // rows of a GlobalTab table: s, s_d, s_dd, rx, ry, cos_r, sin_r, kappa_r, dkappa_r, 1/s_d
 constexpr int ST_PENDING = FOT_ST_OK;    // passed the kinematic checks, collision check outstanding
 
 struct d2 { double x, y; };

@@ -21,8 +21,8 @@ def load_episodes():
     return d
 
 
-def scenario_config(meta):
-    return dict(meta["config"])
+def scenario_config(meta, name="base"):
+    return dict(meta["variants"][name]["config"])
 
 
 class OracleEngine:

@@ -18,7 +18,10 @@ import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STATES = {"NORMAL": 0, "CAUTION": 1, "EMERGENCY": 2}
-VARIANTS = {"base": dict(speed=1.0, dy=0.0), "fast": dict(speed=1.3, dy=0.0), "shift": dict(speed=1.0, dy=1.0)}
+VARIANTS = {"base": dict(scenario="scenario_01", speed=1.0, dy=0.0), "fast": dict(scenario="scenario_01", speed=1.3, dy=0.0),
+            "shift": dict(scenario="scenario_01", speed=1.0, dy=1.0),
+            "walls": dict(scenario="scenario_02", speed=1.0, dy=0.0),        # static obstacle rectangles either side
+            "turn": dict(scenario="scenario_03", speed=1.0, dy=0.0)}         # curved reference path
 
 
 def main():
@@ -40,11 +43,11 @@ def main():
     import src.simulation.integrated_simulator as simmod
     from src.simulation.replay_source import ReplayPedestrianSource
 
-    raw = yaml.safe_load(open(os.path.join(args.ref, "scenarios", "scenario_01.yaml")))
-    peds0 = np.array(raw["ped_initial_states"], dtype=float)
     out = {}
     meta = {"variants": {}, "states": STATES}
     for name, var in VARIANTS.items():
+        raw = yaml.safe_load(open(os.path.join(args.ref, "scenarios", var["scenario"] + ".yaml")))
+        peds0 = np.array(raw["ped_initial_states"], dtype=float)
         cfg = dict(raw)
         cfg.update(ped_initial_states=[], ped_groups=[], sgan_model_path=None, prediction_method="cv",
                    visualization_enabled=False)
@@ -95,15 +98,15 @@ def main():
                                             else [0, 0, 0] for r in h], dtype=np.int32)
         out[pre + "pred_first"] = np.array([r.predicted_trajectories[0, :3].ravel() if r.predicted_trajectories is not None
                                             else np.full(6, np.nan) for r in h])
-        meta["variants"][name] = dict(steps=n, termination=sim.termination_reason, npz_keys=keys, **var)
+        # the RESOLVED configuration (scenario values + the defaults of the reference's SimulationConfig)
+        resolved = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in vars(config).items()}
+        resolved = {k: v for k, v in resolved.items() if isinstance(v, (int, float, str, bool, list)) or v is None}
+        meta["variants"][name] = dict(steps=n, termination=sim.termination_reason, npz_keys=keys, config=resolved,
+                                      ego_radius=float(sim.ego_radius), ped_radius=float(sim.ped_radius),
+                                      n_static_points=int(len(sim.static_obstacle_points)), **var)
         print(name, n, "steps,", sim.termination_reason, "states", np.bincount(out[pre + "state"], minlength=3).tolist(),
               "no path", int((plen == 0).sum()))
-    # the RESOLVED configuration (scenario values + the defaults of the reference's SimulationConfig)
-    resolved = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in vars(config).items()}
-    meta["config"] = {k: v for k, v in resolved.items() if isinstance(v, (int, float, str, bool, list)) or v is None}
-    meta["ped_initial_states"] = peds0.tolist()
-    meta["ego_radius"] = float(sim.ego_radius)
-    meta["ped_radius"] = float(sim.ped_radius)
+    meta["config"] = meta["variants"]["base"]["config"]          # scenario_01, kept for the callers that read it here
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(HERE, "closed_loop", "scenario01_cv_episode.npz")
     np.savez_compressed(path, **out)

@@ -14,9 +14,10 @@ def episodes():
     return load_episodes()
 
 
-@pytest.mark.parametrize("name", ["fast", "shift", "base"])
+@pytest.mark.parametrize("name", ["fast", "shift", "base", "walls", "turn"])
 def test_episodes_free_running(episodes, name):
-    cfg = scenario_config(episodes["meta"])
+    """scenario_01 in three pedestrian scripts, scenario_02 (static obstacle rectangles), scenario_03 (curved path)."""
+    cfg = scenario_config(episodes["meta"], name)
     sim = BatchedClosedLoop(cfg, [episodes[name + "_ped_traj"]], engine=OracleEngine(cfg), resampler=OracleResampler(cfg))
     hist = sim.run()[0]
     assert_episode_matches(hist, sim.episodes[0].termination_reason, episodes, name)

@@ -37,6 +37,16 @@ def test_three_episodes_in_lock_step_match_the_reference(episodes, tmp_path):
     print(f"3 episodes, {sum(len(h) for h in hists)} episode-steps in {wall:.2f} s")
 
 
+@pytest.mark.parametrize("name", ["walls", "turn"])
+def test_other_scenarios_match_the_reference(episodes, name):
+    """scenario_02: corridor of static obstacle rectangles (expanded to boundary points); scenario_03: right turn."""
+    cfg = scenario_config(episodes["meta"], name)
+    with BatchedClosedLoop(cfg, [episodes[name + "_ped_traj"]] * 2) as sim:
+        hists = sim.run()
+        for h, ep in zip(hists, sim.episodes):
+            assert_episode_matches(h, ep.termination_reason, episodes, name)
+
+
 def test_replicated_episodes_are_identical(episodes):
     """32 copies of one episode in one batch: every copy must reproduce the reference (batch independence)."""
     cfg = scenario_config(episodes["meta"])
