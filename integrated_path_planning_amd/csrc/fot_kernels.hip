@@ -85,24 +85,47 @@ __device__ __forceinline__ SplineView stage_spline(const SplineView &g, int lds_
     return l;
 }
 
-// refine_nearest (fot_math.hpp) with the three probes of a round on three lanes: same arithmetic, a third of the
-// dependent spline evaluations.  The result is uniform across the wave.
+// refine_nearest (fot_math.hpp), three rounds per evaluation.  A round compares the distances at s - ds, s, s + ds and
+// either moves left, moves right or halves ds; the next round's probes depend on that outcome.  39 lanes evaluate, in
+// one go, the probes of round r (3 lanes), of round r+1 under each of the 3 outcomes of r (9 lanes) and of round r+2
+// under each of the 9 outcome pairs (27 lanes); the rounds are then resolved from the shuffled distances.  Every lane
+// derives its (s, ds) with the very expressions of the sequential loop, so the result is bit-identical to it -- a
+// third of the dependent spline evaluations.  Uniform across the wave.
+__device__ __forceinline__ void refine_apply(int outcome, double s_end, double &s, double &ds)
+{
+    if (outcome == 0) s = fmax(0.0, s - ds);                      // left probe won
+    else if (outcome == 1) s = fmin(s_end, s + ds);               // right probe won
+    else ds *= 0.5;                                               // centre: halve the step
+}
+
 __device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, double x, double y, double best_s, int lane)
 {
     const double s_end = sp.s[sp.n - 1];
-    const int role = lane % 3;                                    // 0 left, 1 centre, 2 right
+    // role of this lane: depth 0 (lanes 0-2), depth 1 (3-11: outcome o1), depth 2 (12-38: outcomes o1, o2)
+    int depth = 0, o1 = 0, o2 = 0, pos = lane;
+    if (lane >= 12) { const int i = lane - 12; depth = 2; o1 = i / 9; o2 = (i / 3) % 3; pos = i % 3; }
+    else if (lane >= 3) { const int i = lane - 3; depth = 1; o1 = i / 3; pos = i % 3; }
+    if (lane >= 39) { depth = 0; pos = 1; }                       // idle lanes probe the centre (values unused)
     double ds = 0.2;
-    for (int it = 0; it < 20; ++it) {
-        const double s_left = fmax(0.0, best_s - ds);
-        const double s_right = fmin(s_end, best_s + ds);
-        const double s_mine = role == 0 ? s_left : (role == 1 ? best_s : s_right);
+    for (int it = 0; it < 20; it += 3) {
+        double ms = best_s, mds = ds;
+        if (depth >= 1) refine_apply(o1, s_end, ms, mds);
+        if (depth >= 2) refine_apply(o2, s_end, ms, mds);
+        const double probe = pos == 0 ? fmax(0.0, ms - mds) : (pos == 1 ? ms : fmin(s_end, ms + mds));
         double px, py;
-        spline_xy(sp, s_mine, px, py);
+        spline_xy(sp, probe, px, py);
         const double dist = hypot(x - px, y - py);
-        const double dist_left = __shfl(dist, 0, WAVE), dist_curr = __shfl(dist, 1, WAVE), dist_right = __shfl(dist, 2, WAVE);
-        if (dist_left < dist_curr && dist_left < dist_right) best_s = s_left;
-        else if (dist_right < dist_curr && dist_right < dist_left) best_s = s_right;
-        else ds *= 0.5;
+        const int rounds = 20 - it < 3 ? 20 - it : 3;
+        int base = 0, r1 = 0;
+        for (int r = 0; r < rounds; ++r) {
+            const double dist_left = __shfl(dist, base, WAVE), dist_curr = __shfl(dist, base + 1, WAVE),
+                         dist_right = __shfl(dist, base + 2, WAVE);
+            int o = 2;
+            if (dist_left < dist_curr && dist_left < dist_right) o = 0;
+            else if (dist_right < dist_curr && dist_right < dist_left) o = 1;
+            refine_apply(o, s_end, best_s, ds);
+            if (r == 0) { r1 = o; base = 3 + 3 * o; } else base = 12 + 9 * r1 + 3 * o;
+        }
     }
     return best_s;
 }
