@@ -130,16 +130,33 @@ __device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, doub
     return best_s;
 }
 
-__global__ void __launch_bounds__(WAVE)
+constexpr int FRENET_WG = 256;
+
+// arg-min of a sample scan over the whole workgroup (lowest index wins ties); every thread gets the result
+__device__ __forceinline__ ScanBest block_argmin(ScanBest b, ScanBest *s_best)
+{
+    b = wave_argmin(b);
+    __syncthreads();                                              // s_best free again
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_best[threadIdx.x / WAVE] = b;
+    __syncthreads();
+    ScanBest r = s_best[0];
+    for (int w = 1; w < FRENET_WG / WAVE; ++w) scan_merge(r, s_best[w]);
+    return r;
+}
+
+// One workgroup (4 waves) per instance: the sample scans are spread over all threads, the refinement and the Frenet
+// state are uniform values every wave computes alike.
+__global__ void __launch_bounds__(FRENET_WG)
 k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *__restrict__ desc,
                InstState *__restrict__ state, int n_inst)
 {
+    __shared__ ScanBest s_best[FRENET_WG / WAVE];
     int inst = blockIdx.x;
     if (inst >= n_inst) return;
     if (desc[inst].ego.has_prev_s == FOT_PREV_S_CHAINED) return;   // handled by the head of its chain
     const SplineView sp = stage_spline(sp_hbm, lds_knots);
     const DevParams &P = *Pp;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const double s_end = sp.s[sp.n - 1];
     const int n_glob = global_search_count(sp);
     double carry_prev_s = 0.0;                                 // new_prev_s of the previous member of the chain
@@ -155,14 +172,14 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
         if (has_prev) {                                        // cached window +-10 m, 100 samples
             const double s_min = fmax(0.0, prev_s - 10.0);
             const double s_max = fmin(s_end, prev_s + 10.0);
-            ScanBest b = wave_argmin(scan_samples(sp, x, y, s_min, s_max, 100, lane, WAVE, false));
+            ScanBest b = block_argmin(scan_samples(sp, x, y, s_min, s_max, 100, tid, FRENET_WG, false), s_best);
             best_s = b.idx >= 0 ? linspace_at(s_min, s_max, 100, b.idx) : 0.0;
             const bool at_lower = fabs(best_s - s_min) < 1e-3 && s_min > 0.0;
             const bool at_upper = fabs(best_s - s_max) < 1e-3 && s_max < s_end;
             need_global = at_lower || at_upper;
         }
         if (need_global) {
-            ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
+            ScanBest b = block_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, tid, FRENET_WG, true), s_best);
             best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
         }
         best_s = refine_nearest_wave(sp, x, y, best_s, lane);
@@ -174,12 +191,12 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
             double px, py;
             spline_xy(sp, best_s, px, py);
             if (isnan(px) || isnan(py)) {                     // coordinate_converter.py:289-295
-                ScanBest b = wave_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, lane, WAVE, true));
+                ScanBest b = block_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, tid, FRENET_WG, true), s_best);
                 best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
                 ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
             }
         }
-        if (lane == 0) {
+        if (tid == 0) {
             InstState &S = state[inst];
             for (int i = 0; i < 6; ++i) { S.frenet0[i] = ok ? fr[i] : NAN; S.ref0[i] = ok ? ref[i] : NAN; }
             S.new_prev_s = new_prev_s;
@@ -1094,7 +1111,7 @@ int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc,
 {
     if (n_inst <= 0) return 0;
     const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
-    k_frenet_state<<<n_inst, WAVE, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, n_inst);
+    k_frenet_state<<<n_inst, FRENET_WG, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }
