@@ -239,8 +239,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dEntSid.ensure(n_ent));
     HIP_TRY(h, w.dWaveRng.ensure(sizeof(uint32_t) * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
 
-    HIP_TRY(h, hipMemcpyAsync(w.dMeta.p, stg, meta_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipEventRecord(w.staging_done, st));
+    // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
     w.staging_pending = true;
 
     const InstDesc *d_desc = (const InstDesc *)w.dMeta.p;
@@ -257,7 +256,15 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     ea.sid = w.dEntSid.as<uint8_t>(); ea.rng = w.dWaveRng.as<uint32_t>();
     {
         ProfScope ps(h, 0, st);
-        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, st));
+        MetaImport imp;
+        imp.h_desc = (const InstDesc *)stg;
+        imp.h_wave_inst = (const int32_t *)(stg + desc_bytes);
+        imp.h_wave_base = (const int32_t *)(stg + desc_bytes + map_bytes);
+        imp.d_desc = (InstDesc *)w.dMeta.p;
+        imp.d_wave_inst = (int32_t *)((char *)w.dMeta.p + desc_bytes);
+        imp.d_wave_base = (int32_t *)((char *)w.dMeta.p + desc_bytes + map_bytes);
+        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, st));
+        HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
     {
         ProfScope ps(h, 1, st);
@@ -693,12 +700,16 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
     if (!ego) return fail(h, FOT_ERR_INVALID, "ego is NULL");
     std::vector<InstDesc> desc((size_t)n);
     for (int i = 0; i < n; ++i) { desc[i] = InstDesc(); desc[i].ego = ego[i]; }
+    for (int i = n - 1, run = 0; i >= 0; --i) {                 // chain lengths, as build_batch_layout sets them
+        desc[i].n_chained = run;
+        run = desc[i].ego.has_prev_s == FOT_PREV_S_CHAINED ? run + 1 : 0;
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc) * (size_t)n));
     HIP_TRY(h, h->dTmpB.ensure(sizeof(InstState) * (size_t)n));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, desc.data(), sizeof(InstDesc) * (size_t)n, hipMemcpyHostToDevice, h->stream));
     LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), h->dTmpA.as<InstDesc>(),
-                                      h->dTmpB.as<InstState>(), n, h->stream));
+                                      h->dTmpB.as<InstState>(), n, MetaImport(), h->stream));
     std::vector<InstState> st((size_t)n);
     HIP_TRY(h, hipMemcpyAsync(st.data(), h->dTmpB.p, sizeof(InstState) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

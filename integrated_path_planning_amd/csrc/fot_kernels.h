@@ -21,9 +21,17 @@ struct EntryArrays {
     uint32_t *rng;     // [n_waves][n_total] chunk range of each candidate wave: c_lo << 16 | c_hi
 };
 
+// descriptors still in pinned host memory, to be moved into HBM by k_frenet_state (h_desc == nullptr: already there)
+struct MetaImport {
+    const InstDesc *h_desc = nullptr;
+    const int32_t *h_wave_inst = nullptr, *h_wave_base = nullptr;
+    InstDesc *d_desc = nullptr;
+    int32_t *d_wave_inst = nullptr, *d_wave_base = nullptr;
+};
+
 // every launcher returns 0 or the hipError_t of the launch
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
-                        hipStream_t st);
+                        MetaImport imp, hipStream_t st);
 int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
                      LonInfo *lon_info, float *prof_box, int n_inst, int max_lon, hipStream_t st);
 int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,

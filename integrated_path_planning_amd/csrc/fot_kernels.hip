@@ -147,13 +147,38 @@ __device__ __forceinline__ ScanBest block_argmin(ScanBest b, ScanBest *s_best)
 // One workgroup (4 waves) per instance: the sample scans are spread over all threads, the refinement and the Frenet
 // state are uniform values every wave computes alike.
 __global__ void __launch_bounds__(FRENET_WG)
-k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *__restrict__ desc,
-               InstState *__restrict__ state, int n_inst)
+k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *desc,
+               InstState *__restrict__ state, int n_inst, MetaImport imp)
 {
     __shared__ ScanBest s_best[FRENET_WG / WAVE];
+    __shared__ InstDesc s_desc;                                   // the descriptor being worked on, read once
     int inst = blockIdx.x;
     if (inst >= n_inst) return;
-    if (desc[inst].ego.has_prev_s == FOT_PREV_S_CHAINED) return;   // handled by the head of its chain
+    constexpr int DESC_WORDS = (int)(sizeof(InstDesc) / sizeof(unsigned long long));
+    static_assert(sizeof(InstDesc) % sizeof(unsigned long long) == 0, "InstDesc is copied in 8-byte words");
+    if (imp.h_desc) {
+        // First kernel of a plan call: the descriptors still sit in the caller-side pinned staging block.  Every
+        // workgroup moves its own instance's descriptor and wave-map slice into HBM for the kernels that follow
+        // (instead of a separate H2D copy in front of the launch sequence) and works from the staging copy itself.
+        desc = imp.h_desc;
+        const unsigned long long *src = (const unsigned long long *)&desc[inst];
+        if (threadIdx.x < DESC_WORDS) {
+            const unsigned long long v = src[threadIdx.x];
+            ((unsigned long long *)&imp.d_desc[inst])[threadIdx.x] = v;
+            ((unsigned long long *)&s_desc)[threadIdx.x] = v;
+        }
+        __syncthreads();
+        const int w0 = s_desc.wave0, nw = s_desc.n_waves;
+        for (int i = threadIdx.x; i < nw; i += FRENET_WG) {
+            imp.d_wave_inst[w0 + i] = imp.h_wave_inst[w0 + i];
+            imp.d_wave_base[w0 + i] = imp.h_wave_base[w0 + i];
+        }
+    } else {
+        if (threadIdx.x < DESC_WORDS)
+            ((unsigned long long *)&s_desc)[threadIdx.x] = ((const unsigned long long *)&desc[inst])[threadIdx.x];
+        __syncthreads();
+    }
+    if (s_desc.ego.has_prev_s == FOT_PREV_S_CHAINED) return;      // handled by the head of its chain
     const SplineView sp = stage_spline(sp_hbm, lds_knots);
     const DevParams &P = *Pp;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -161,8 +186,15 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
     const int n_glob = global_search_count(sp);
     double carry_prev_s = 0.0;                                 // new_prev_s of the previous member of the chain
     bool chained = false;
-    do {
-        const InstDesc &D = desc[inst];
+    const int n_members = 1 + s_desc.n_chained;
+    for (int m = 0; m < n_members; ++m, ++inst) {
+        if (m > 0) {                                           // next member of the chain: its descriptor
+            __syncthreads();
+            if (threadIdx.x < DESC_WORDS)
+                ((unsigned long long *)&s_desc)[threadIdx.x] = ((const unsigned long long *)&desc[inst])[threadIdx.x];
+            __syncthreads();
+        }
+        const InstDesc &D = s_desc;
         const double x = D.ego.x, y = D.ego.y;
         const bool has_prev = chained ? true : D.ego.has_prev_s != 0;
         const double prev_s = chained ? carry_prev_s : D.ego.prev_s;
@@ -207,8 +239,7 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
         }
         carry_prev_s = new_prev_s;
         chained = true;
-        ++inst;
-    } while (inst < n_inst && desc[inst].ego.has_prev_s == FOT_PREV_S_CHAINED);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1107,11 +1138,12 @@ k_safety(const DevParams *__restrict__ Pp, int n, const double *__restrict__ ego
 #define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
-                        hipStream_t st)
+                        MetaImport imp, hipStream_t st)
 {
     if (n_inst <= 0) return 0;
     const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
-    k_frenet_state<<<n_inst, FRENET_WG, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, n_inst);
+    k_frenet_state<<<n_inst, FRENET_WG, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, n_inst,
+                                                                                 imp);
     FOT_LAUNCH_CHECK();
     return 0;
 }

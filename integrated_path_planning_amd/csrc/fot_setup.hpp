@@ -268,6 +268,10 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
             L.any_obstacles = true;
         }
     }
+    for (int i = b.n_inst - 1, run = 0; i >= 0; --i) {              // chain lengths, seen from each head
+        L.desc[i].n_chained = run;
+        run = L.desc[i].ego.has_prev_s == FOT_PREV_S_CHAINED ? run + 1 : 0;
+    }
     L.n_waves = (int)L.wave_inst.size();
     if ((L.n_static > 0 && !b.static_xy) || (L.dyn_src_points > 0 && !b.dyn_xy)) {
         err = "obstacle offsets given without coordinates";

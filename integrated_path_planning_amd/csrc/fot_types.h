@@ -77,6 +77,8 @@ struct InstDesc {
     int32_t wave0;                       // first wave of this instance
     int32_t n_waves;                     // waves of this instance
     int32_t max_viol;                    // floor(eps*S)
+    int32_t n_chained;                   // instances right behind this one that continue its nearest-point cache
+    int32_t _pad;
 };
 
 // device-produced per-instance state
