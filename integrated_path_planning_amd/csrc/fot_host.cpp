@@ -65,15 +65,15 @@ struct Workspace {
     bool staging_pending = false;
     PinnedBuf staging;
     DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
-    DevBuf dState, dLonInfo;
+    DevBuf dState;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
-    DevBuf dProfBox, dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: profile boxes + culled entry lists
+    DevBuf dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: culled entry lists + per-wave chunk ranges
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
-        DevBuf *bufs[] = { &dMeta, &dState, &dLonInfo, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
-                           &dProfBox, &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
+        DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
+                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
         for (DevBuf *b : bufs) b->release();
         staging.release();
         if (staging_done) (void)hipEventDestroy(staging_done);
@@ -157,8 +157,7 @@ int upload_spline(fot_handle *h)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_lon_table", "k_cull", "k_evaluate",
-                                                        "k_select" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_select" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -224,14 +223,12 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     const DevParams &P = h->P;
     HIP_TRY(h, w.dMeta.ensure(meta_bytes));
     HIP_TRY(h, w.dState.ensure(sizeof(InstState) * (size_t)L.n_inst));
-    HIP_TRY(h, w.dLonInfo.ensure(sizeof(LonInfo) * (size_t)std::max<int64_t>(L.n_lon, 1)));
     const size_t slots = (size_t)std::max<int64_t>(L.n_slots, 1);
     HIP_TRY(h, w.dCost.ensure(sizeof(double) * slots));
     HIP_TRY(h, w.dVlast.ensure(sizeof(double) * slots));
     HIP_TRY(h, w.dTravel.ensure(sizeof(double) * slots));
     HIP_TRY(h, w.dStatus.ensure(slots));
     HIP_TRY(h, w.dKeep.ensure(slots));
-    HIP_TRY(h, w.dProfBox.ensure(sizeof(float) * 4 * (size_t)P.n_total * (size_t)std::max<int64_t>(L.n_lon, 1)));
     const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
     HIP_TRY(h, w.dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
     HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
@@ -266,24 +263,19 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, st));
         HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
-    {
-        ProfScope ps(h, 1, st);
-        LAUNCH_TRY(h, launch_lon_table(dP, sv, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
-                                       w.dProfBox.as<float>(), L.n_inst, L.max_lon, st));
-    }
     if (L.any_obstacles) {
-        ProfScope ps(h, 2, st);
-        LAUNCH_TRY(h, launch_cull(dP, d_desc, w.dState.as<InstState>(), L.n_inst, P.n_total, w.dProfBox.as<float>(),
+        ProfScope ps(h, 1, st);
+        LAUNCH_TRY(h, launch_cull(dP, d_desc, w.dState.as<InstState>(), L.n_inst, P.n_total, sv,
                                   d_static, d_dyn, b.obstacle_dtype, ea, st));
     }
     {
-        ProfScope ps(h, 3, st);
-        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(), P.n_total,
+        ProfScope ps(h, 2, st);
+        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total,
                                       d_wave_inst, d_wave_base, L.n_waves, ea, ca, st));
     }
     {
-        ProfScope ps(h, 4, st);
-        LAUNCH_TRY(h, launch_select(dP, d_desc, w.dState.as<InstState>(), w.dLonInfo.as<LonInfo>(),
+        ProfScope ps(h, 3, st);
+        LAUNCH_TRY(h, launch_select(dP, d_desc, w.dState.as<InstState>(),
                                     sv, ca, d_out, L.n_inst, st));
     }
     return FOT_OK;
@@ -767,7 +759,7 @@ int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double 
     HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * 2));
     HIP_TRY(h, hipMemsetAsync(h->dTmpA.p, 0, sizeof(double) * 15 * FOT_MAX_NT, h->stream));
     LAUNCH_TRY(h, launch_debug_path(h->dP.as<DevParams>(), (const InstDesc *)w->dMeta.p, w->dState.as<InstState>(),
-                                    w->dLonInfo.as<LonInfo>(), spline_view(h), local, index,
+                                    spline_view(h), local, index,
                                     h->dTmpA.as<double>(), h->dTmpD.as<int32_t>(), h->stream));
     int32_t meta[2] = { 0, 0 };
     HIP_TRY(h, hipMemcpyAsync(arrays, h->dTmpA.p, sizeof(double) * 15 * FOT_MAX_NT, hipMemcpyDeviceToHost, h->stream));

@@ -32,17 +32,14 @@ struct MetaImport {
 // every launcher returns 0 or the hipError_t of the launch
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         MetaImport imp, hipStream_t st);
-int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                     LonInfo *lon_info, float *prof_box, int n_inst, int max_lon, hipStream_t st);
 int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
-                const float *prof_box, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
+                SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
                 hipStream_t st);
-int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                    const LonInfo *lon_info, int n_total, const int32_t *wave_inst,
+int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total, const int32_t *wave_inst,
                     const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st);
-int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state,
                   SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
-int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state,
                       SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st);
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
 int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,

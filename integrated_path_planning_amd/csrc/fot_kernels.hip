@@ -2,9 +2,6 @@
 //
 // Pipeline of one fot_plan_batch (one launch each over the whole batch; every decision in float64):
 //   k_frenet_state : 1 wave / instance: nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
-//   k_lon_table    : 1 wave / longitudinal profile, lane = time sample: quartic + reference frame at s(t) -> profile
-//                    summary (jerk sum, final speed) and the float32 bounding box of the profile's lateral candidates at that sample (two end points of a
-//                    segment: the quintic is affine in its target offset)
 //   k_cull         : 1 wave / (instance, 8 consecutive time steps): merges the profile boxes, then sorts the obstacles
 //                    of those time rows that lie inside the grown boxes into per-step entry lists (strips, LDS atomics)
 //   k_evaluate     : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks, and -- while
@@ -243,59 +240,23 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
 }
 
 // ---------------------------------------------------------------------------
-// longitudinal profiles + reference frame table
+// longitudinal profiles
 // ---------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(WAVE)
-k_lon_table(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *__restrict__ desc,
-            const InstState *__restrict__ state, LonInfo *__restrict__ lon_info, float *__restrict__ prof_box)
+// float32 bounding box (instance-local frame) of the lateral candidates of profile `slot` at time step k; empty
+// when the profile has no sample k.  See profile_box (fot_math.hpp): two end points of a segment.
+__device__ __forceinline__ Box32 profile_box_at(const DevParams &P, const InstDesc &D, const InstState &S,
+                                                const SplineView &sp, int slot, int k)
 {
-    const DevParams &P = *Pp;
-    const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave of the grid, before any of them leaves
-    const int inst = blockIdx.y;
-    const InstDesc &D = desc[inst];
-    const InstState &S = state[inst];
-    if (!S.c2f_ok) return;
-    const int slot = blockIdx.x;
     const int n_grid_lon = P.n_ti * D.n_tv;
-    if (slot >= n_grid_lon + S.n_brake) return;
-
-    LonInfo L;
     const bool brake = slot >= n_grid_lon;
     const TimeInfo &lat_ti = brake ? P.brake[slot - n_grid_lon] : P.ti[slot / D.n_tv];
-    if (!brake) {
-        const int ti = slot / D.n_tv, itv = slot - ti * D.n_tv;
-        lon_coeffs(S.frenet0, tv_value(P, D, itv), P.ti[ti], L);
-        L.n_t = P.ti[ti].n_t;
-        L.n_eval = L.n_t;
-    } else {
-        lon_coeffs(S.frenet0, 0.0, lat_ti, L);
-        L.n_t = P.n_total;
-        L.n_eval = lat_ti.n_t;
-    }
-    const int k = threadIdx.x;
-    Box32 box = box_empty();
-    double jerk2 = 0.0, sd_k = 0.0;
-    if (k < L.n_t) {
-        LonSample ls;
-        double sddd;
-        make_lon_sample(sp, L, k, P.dt, ls, sddd);          // the rows themselves are rebuilt where they are used
-        jerk2 = sddd * sddd;
-        sd_k = ls.sd;
-        box = profile_box(P, S.frenet0, brake, lat_ti, ls, k, L.n_eval, D.ego.x, D.ego.y);
-    }
-    if (k < P.n_total) {
-        float4 w; w.x = box.x0; w.y = box.y0; w.z = box.x1; w.w = box.y1;
-        *(float4 *)(prof_box + ((int64_t)(D.lon_off + slot) * P.n_total + k) * 4) = w;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) jerk2 += __shfl_xor(jerk2, off, WAVE);
-    const double sd_last = __shfl(sd_k, L.n_t - 1, WAVE);
-    if (k == 0) {
-        L.Js = jerk2;
-        L.sd_last = sd_last;
-        lon_info[D.lon_off + slot] = L;
-    }
+    const LonInfo L = profile_info(P, D, S.frenet0, slot, false);
+    if (k >= L.n_t) return box_empty();
+    LonSample ls;
+    double sddd;
+    make_lon_sample(sp, L, k, P.dt, ls, sddd);
+    return profile_box(P, S.frenet0, brake, lat_ti, ls, k, L.n_eval, D.ego.x, D.ego.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -456,7 +417,7 @@ struct FusedSink {
 // profiles.  Layout [profile][k][field], 9 fields = 72 contiguous bytes per row (the arc length s is not in the row:
 // only the low-speed rule and the travelled distance read it, and they rebuild it from the profile's polynomial).
 constexpr int EVAL_WG = WAVES_PER_GROUP * WAVE;
-constexpr int EVAL_LDS_BYTES = 53000;                             // three workgroups per CU within 160 KB of LDS
+constexpr int EVAL_LDS_BYTES = 54400;                             // three workgroups per CU within 160 KB of LDS
 constexpr int EVAL_LDS_PROFILES_MAX = 16;
 extern __shared__ double s_lon[];
 
@@ -464,8 +425,10 @@ constexpr int ROW_FIELDS = 9;
 
 struct StagedTab {
     int lds_row0;                        // index of this lane's profile row 0 in s_lon, or -1: not staged
-    int g;                               // lanes outside the block's window rebuild the row of profile g on the spot
-    const LonInfo *lon_info;             //   (re-read per step: nothing of it is kept in registers across the loop)
+    int slot;                            // lanes outside the block's window rebuild the rows of their profile on the
+    const DevParams *Pp;                 //   spot, from the instance's state (nothing of it stays in registers
+    const InstDesc *Dp;                  //   across the loop)
+    const double *fr;
     SplineView sp;
     double dt;
     __device__ __forceinline__ void load(int k, LonSample &L) const
@@ -476,7 +439,7 @@ struct StagedTab {
             L.cos_r = r[4]; L.sin_r = r[5]; L.kr = r[6]; L.dkr = r[7]; L.inv_sd = r[8];
         } else {
             ComputeTab direct;
-            direct.sp = sp; direct.L = lon_info[g]; direct.dt = dt;
+            direct.sp = sp; direct.L = profile_info(*Pp, *Dp, fr, slot, false); direct.dt = dt;
             direct.load(k, L);
         }
         // the row is in registers from here on: what follows (the sink's scalar warm-up loads) must not sit
@@ -487,14 +450,14 @@ struct StagedTab {
     __device__ __forceinline__ double s_at(int k) const
     {
         ComputeTab direct;
-        direct.sp = sp; direct.L = lon_info[g]; direct.dt = dt;
+        direct.sp = sp; direct.L = profile_info(*Pp, *Dp, fr, slot, false); direct.dt = dt;
         return direct.s_at(k);
     }
 };
 
 __global__ void __launch_bounds__(EVAL_WG)
 k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
-           const InstState *__restrict__ state, const LonInfo *__restrict__ lon_info, int lds_profiles,
+           const InstState *__restrict__ state, int lds_profiles,
            int lds_knots, int ablate, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
            const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
            const uint8_t *__restrict__ ent_sid,
@@ -503,26 +466,29 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
 {
     const DevParams &P = *Pp;
     const int n_total = P.n_total;
-    // --- the rows of the profiles [g_lo, g_lo + n_stage) of the block's instance, built straight into LDS (no
-    //     table in HBM): g_lo is the profile of the block's first candidate; a block never spans two instances
+    // --- the rows of the profiles [slot_lo, slot_lo + n_stage) of the block's instance, built straight into LDS (no
+    //     table in HBM): slot_lo is the profile of the block's first candidate; a block never spans two instances
     const int wave_first = blockIdx.x * (EVAL_WG / WAVE);
-    int g_lo = 0, n_stage = 0;
+    int slot_lo = 0, n_stage = 0;
+    const int inst0 = wave_inst[wave_first];                      // wave_first < n_waves by construction of the grid
+    const InstDesc &D0 = desc[inst0];
+    const InstState &S0 = state[inst0];
     {
-        const int inst0 = wave_inst[wave_first];                  // wave_first < n_waves by construction of the grid
-        const InstDesc &D0 = desc[inst0];
-        const InstState &S0 = state[inst0];
         const int idx0 = wave_base[wave_first];
         if (S0.c2f_ok && idx0 < S0.n_cand) {
-            const int slot0 = decode_candidate(P, D0, S0.frenet0, idx0).lon_slot;
+            slot_lo = decode_candidate(P, D0, S0.frenet0, idx0).lon_slot;
             const int n_prof = P.n_ti * D0.n_tv + S0.n_brake;     // valid profiles of the instance
-            g_lo = D0.lon_off + slot0;
-            n_stage = n_prof - slot0 < lds_profiles ? n_prof - slot0 : lds_profiles;
+            n_stage = n_prof - slot_lo < lds_profiles ? n_prof - slot_lo : lds_profiles;
         }
     }
-    const SplineView sp_lds = stage_spline(sp, lds_knots, s_lon + lds_profiles * n_total * ROW_FIELDS);   // behind the rows
+    // LDS: rows [lds_profiles][n_total][ROW_FIELDS] | profile summaries [lds_profiles] | spline
+    LonInfo *s_info = (LonInfo *)(s_lon + lds_profiles * n_total * ROW_FIELDS);
+    const SplineView sp_lds = stage_spline(sp, lds_knots, (double *)(s_info + lds_profiles));
+    if ((int)threadIdx.x < n_stage) s_info[threadIdx.x] = profile_info(P, D0, S0.frenet0, slot_lo + threadIdx.x, true);
+    __syncthreads();
     for (int i = threadIdx.x; i < n_stage * n_total; i += EVAL_WG) {
         const int p = i / n_total, k = i - p * n_total;
-        const LonInfo Lp = lon_info[g_lo + p];
+        const LonInfo Lp = s_info[p];
         if (k < Lp.n_t) {
             LonSample ls;
             double sddd;
@@ -553,11 +519,11 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
         return;
     }
     const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
-    const int g = D.lon_off + cd.lon_slot;
-    const LonInfo L = lon_info[g];
+    const bool staged = (unsigned)(cd.lon_slot - slot_lo) < (unsigned)n_stage;
+    const LonInfo L = staged ? s_info[cd.lon_slot - slot_lo] : profile_info(P, D, S.frenet0, cd.lon_slot, true);
     StagedTab tab;
-    tab.lds_row0 = (unsigned)(g - g_lo) < (unsigned)n_stage ? (g - g_lo) * n_total * ROW_FIELDS : -1;
-    tab.g = g; tab.lon_info = lon_info; tab.sp = sp; tab.dt = P.dt;
+    tab.lds_row0 = staged ? (cd.lon_slot - slot_lo) * n_total * ROW_FIELDS : -1;
+    tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.sp = sp; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
 
@@ -604,12 +570,13 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
 // profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
 constexpr int CULL_KG = 8;
 constexpr int CULL_LIST = 512;          // kept obstacles per time step remembered between the two passes
+constexpr int CULL_PBOX = 128;          // profiles per instance whose boxes are kept in LDS (more: recomputed)
 constexpr uint32_t CULL_IDX_MASK = 0xFFFFFu;   // obstacle index (< 2^20, fot_setup.hpp) | bin << 20
 
 template <typename T>
 __global__ void __launch_bounds__(CULL_KG * WAVE)
 k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-       int n_inst, const float *__restrict__ prof_box, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
+       int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
        uint32_t *__restrict__ wave_rng, int ablate)
 {
@@ -620,7 +587,9 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __shared__ Box32 s_box[CULL_KG];                             // per-step constants
     __shared__ BinMap s_bm[CULL_KG];
     __shared__ float s_margin[CULL_KG];
+    __shared__ Box32 s_pbox[CULL_KG][CULL_PBOX];                 // boxes of the instance's profiles at the group's steps
     const DevParams &P = *Pp;
+    const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
     const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
     const int inst = blockIdx.x / groups, k0 = (blockIdx.x - inst * groups) * CULL_KG;
     if (inst >= n_inst) return;
@@ -632,7 +601,6 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const int nk = P.n_total - k0 < CULL_KG ? P.n_total - k0 : CULL_KG;
     const int n_grid_lon = P.n_ti * D.n_tv;
     const int n_prof = S.c2f_ok ? n_grid_lon + S.n_brake : 0;
-    const float *pbox = prof_box + (int64_t)D.lon_off * P.n_total * 4;           // + (slot * n_total + k) * 4
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
     const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     const float slack = box_footprint_slack(P);
@@ -642,8 +610,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         Box32 bw = box_empty();
         if (wv < nk)
             for (int w = lane; w < n_prof; w += WAVE) {
-                const float4 v = *(const float4 *)(pbox + ((int64_t)w * P.n_total + k0 + wv) * 4);
-                Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
+                const Box32 o = profile_box_at(P, D, S, sp, w, k0 + wv);
+                if (w < CULL_PBOX) s_pbox[wv][w] = o;               // read again below, per candidate wave
                 box_merge(bw, o);
             }
         bw.x0 = wave_min_f32(bw.x0); bw.y0 = wave_min_f32(bw.y0);
@@ -777,11 +745,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             int s0, s1;
             wave_profile_span(P, D, n_grid_lon, idx0, idx1, s0, s1);
             Box32 wb = box_empty();
-            for (int sl = s0; sl <= s1; ++sl) {
-                const float4 v = *(const float4 *)(pbox + ((int64_t)sl * P.n_total + k) * 4);
-                Box32 o; o.x0 = v.x; o.y0 = v.y; o.x1 = v.z; o.y1 = v.w;
-                box_merge(wb, o);
-            }
+            for (int sl = s0; sl <= s1; ++sl)
+                box_merge(wb, sl < CULL_PBOX ? s_pbox[kk][sl] : profile_box_at(P, D, S, sp, sl, k));
             const float wm = cull_margin(sq_max, wb) + slack;
             r = strip_range(bmk, wb, wm, [&](int bb) { return s_start[kk][bb]; });
         }
@@ -797,7 +762,7 @@ constexpr int SELECT_WG = 256;
 
 __global__ void __launch_bounds__(SELECT_WG)
 k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-         const LonInfo *__restrict__ lon_info, SplineView sp,
+         SplineView sp,
          const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
          const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
          const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
@@ -872,7 +837,7 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
     }
     const int keep = cand_keep[(int64_t)D.cand_off + best.idx];
     const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
-    const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
+    const LonInfo L = profile_info(P, D, S.frenet0, cd.lon_slot, false);
     ComputeTab tab;
     tab.sp = sp; tab.L = L; tab.dt = P.dt;
     double q[6];
@@ -898,7 +863,7 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
 
 __global__ void __launch_bounds__(WAVE)
 k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-             const LonInfo *__restrict__ lon_info, SplineView sp, int inst, int idx,
+             SplineView sp, int inst, int idx,
              double *__restrict__ out /* [15][FOT_MAX_NT] */, int32_t *__restrict__ meta /* n_t, valid */)
 {
     const DevParams &P = *Pp;
@@ -907,7 +872,7 @@ k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc
     const int lane = threadIdx.x;
     if (!S.c2f_ok || idx < 0 || idx >= S.n_cand) { if (lane == 0) { meta[0] = 0; meta[1] = 0; } return; }
     const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
-    const LonInfo L = lon_info[D.lon_off + cd.lon_slot];
+    const LonInfo L = profile_info(P, D, S.frenet0, cd.lon_slot, false);
     ComputeTab tab;
     tab.sp = sp; tab.L = L; tab.dt = P.dt;
     double q[6];
@@ -1148,47 +1113,37 @@ int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc,
     return 0;
 }
 
-int launch_lon_table(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                     LonInfo *lon_info, float *prof_box, int n_inst, int max_lon, hipStream_t st)
-{
-    if (n_inst <= 0 || max_lon <= 0) return 0;
-    dim3 grid((unsigned)max_lon, (unsigned)n_inst);
-    const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
-    k_lon_table<<<grid, WAVE, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, lon_info, prof_box);
-    FOT_LAUNCH_CHECK();
-    return 0;
-}
-
 int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
-                const float *prof_box, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
+                SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
                 hipStream_t st)
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
     const unsigned grid = (unsigned)((int64_t)n_inst * ((n_total + CULL_KG - 1) / CULL_KG));
     static const int ablate = getenv("FOT_CULL_ABLATE") ? atoi(getenv("FOT_CULL_ABLATE")) : 0;   // timing diagnostics
+    const int lds_knots = sp.n <= 64 ? sp.n : 0;                           // a short spline rides along in LDS
+    const size_t lds = sizeof(double) * 9 * (size_t)lds_knots;
     if (dtype == FOT_F32)
-        k_cull<float><<<grid, CULL_KG * WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const float *)static_xy,
+        k_cull<float><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const float *)static_xy,
                                              (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, ablate);
     else
-        k_cull<double><<<grid, CULL_KG * WAVE, 0, st>>>(P, desc, state, n_inst, prof_box, (const double *)static_xy,
+        k_cull<double><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const double *)static_xy,
                                               (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, ablate);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state,
-                    const LonInfo *lon_info, int n_total, const int32_t *wave_inst,
+int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total, const int32_t *wave_inst,
                     const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
     const int wpb = EVAL_WG / WAVE;
     const size_t per_prof = sizeof(double) * ROW_FIELDS * (size_t)n_total;
     const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
-    int lds_profiles = (int)((EVAL_LDS_BYTES - sizeof(double) * 9 * (size_t)lds_knots) / per_prof);
+    int lds_profiles = (int)((EVAL_LDS_BYTES - sizeof(double) * 9 * (size_t)lds_knots) / (per_prof + sizeof(LonInfo)));
     if (lds_profiles > EVAL_LDS_PROFILES_MAX) lds_profiles = EVAL_LDS_PROFILES_MAX;
-    const size_t lds = per_prof * (size_t)lds_profiles + sizeof(double) * 9 * (size_t)lds_knots;
+    const size_t lds = (per_prof + sizeof(LonInfo)) * (size_t)lds_profiles + sizeof(double) * 9 * (size_t)lds_knots;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
-    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, sp, desc, state, lon_info, lds_profiles, lds_knots,
+    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, sp, desc, state, lds_profiles, lds_knots,
                                                                 ablate, wave_inst,
                                                                 wave_base, n_waves, e.rng, e.e32, e.e64, e.sid,
                                                                 c.cost, c.v_last, c.travel, c.status, c.keep);
@@ -1196,20 +1151,20 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     return 0;
 }
 
-int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state,
                   SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st)
 {
     if (n_inst <= 0) return 0;
-    k_select<<<n_inst, SELECT_WG, 0, st>>>(P, desc, state, lon_info, sp, c.cost, c.v_last, c.travel, c.status,
+    k_select<<<n_inst, SELECT_WG, 0, st>>>(P, desc, state, sp, c.cost, c.v_last, c.travel, c.status,
                                      c.keep, out, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state, const LonInfo *lon_info,
+int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state,
                       SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st)
 {
-    k_debug_path<<<1, WAVE, 0, st>>>(P, desc, state, lon_info, sp, inst, idx, out, meta);
+    k_debug_path<<<1, WAVE, 0, st>>>(P, desc, state, sp, inst, idx, out, meta);
     FOT_LAUNCH_CHECK();
     return 0;
 }

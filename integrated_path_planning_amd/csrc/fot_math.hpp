@@ -278,6 +278,37 @@ FOT_HD void lon_sample(const LonInfo &L, int k, double dt, double &s, double &sd
     }
 }
 
+// One longitudinal profile of an instance by its slot (Ti x tv grid entry, then the brake ladder): coefficients and
+// sample counts; with_summary also the jerk sum over the samples and the final speed the cost reads (:703-734).
+// Cheap and closed-form, so every kernel that needs a profile derives it on the spot -- no table of them in HBM.
+FOT_HD LonInfo profile_info(const DevParams &P, const InstDesc &D, const double *fr, int slot, bool with_summary)
+{
+    LonInfo L;
+    const int n_grid_lon = P.n_ti * D.n_tv;
+    if (slot < n_grid_lon) {
+        const int ti = slot / D.n_tv, itv = slot - ti * D.n_tv;
+        lon_coeffs(fr, tv_value(P, D, itv), P.ti[ti], L);
+        L.n_t = P.ti[ti].n_t;
+        L.n_eval = L.n_t;
+    } else {
+        const TimeInfo &tb = P.brake[slot - n_grid_lon];
+        lon_coeffs(fr, 0.0, tb, L);
+        L.n_t = P.n_total;
+        L.n_eval = tb.n_t;
+    }
+    L.Js = 0.0; L.sd_last = 0.0;
+    if (with_summary) {
+        // sum over the polynomial samples k = 0..n-1 of jerk(t_k)^2 with jerk(t) = 6 a3 + 24 a4 t, t_k = k dt, in closed
+        // form (the jerk is zero on the brake padding): n c0^2 + 2 c0 c1 sum(k) + c1^2 sum(k^2), c1 = 24 a4 dt
+        const double n = (double)L.n_eval, c0 = 6.0 * L.a3, c1 = 24.0 * L.a4 * P.dt;
+        const double sum_k = n * (n - 1.0) * 0.5, sum_k2 = (n - 1.0) * n * (2.0 * n - 1.0) / 6.0;
+        L.Js = n * c0 * c0 + 2.0 * c0 * c1 * sum_k + c1 * c1 * sum_k2;
+        double s_, sdd, sddd;
+        lon_sample(L, L.n_t - 1, P.dt, s_, L.sd_last, sdd, sddd);
+    }
+    return L;
+}
+
 // ---------------------------------------------------------------------------
 // Frenet -> Cartesian of one sample
 // (reference: frenet_planner.py:792-799, coordinate_converter.py:128-158)
