@@ -3,6 +3,8 @@
 Every per-candidate status, length and cost must agree, as well as the selected path.  Seeds are fixed; a failure
 message names the seed so the case can be replayed.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -91,7 +93,11 @@ def random_request(rng, sp, kw):
     return req
 
 
-@pytest.mark.parametrize("seed", range(40))
+# FOT_FUZZ_SEEDS=N widens the sweep (default 40 seeds x 6 instances; a 1000-seed sweep was run once per build round)
+N_SEEDS = int(os.environ.get("FOT_FUZZ_SEEDS", "40"))
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_configuration(seed):
     rng = np.random.default_rng(1000 + seed)
     wx, wy = random_path(rng)
