@@ -208,16 +208,15 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     if (rc != FOT_OK) return fail(h, rc, err);
     if (L.n_inst == 0) return FOT_OK;
 
-    // --- staging: descriptors + wave maps in one pinned block, one H2D copy
+    // --- staging: the descriptors in a pinned block (k_frenet_state pulls them into HBM; the wave maps behind them in
+    //     dMeta are written on the device)
     const size_t desc_bytes = align256(sizeof(InstDesc) * (size_t)L.n_inst);
     const size_t map_bytes = align256(sizeof(int32_t) * (size_t)L.n_waves);
     const size_t meta_bytes = desc_bytes + 2 * map_bytes;
     if (w.staging_pending) { HIP_TRY(h, hipEventSynchronize(w.staging_done)); w.staging_pending = false; }
-    HIP_TRY(h, w.staging.ensure(meta_bytes));
+    HIP_TRY(h, w.staging.ensure(desc_bytes));
     char *stg = (char *)w.staging.p;
     std::memcpy(stg, L.desc.data(), sizeof(InstDesc) * (size_t)L.n_inst);
-    std::memcpy(stg + desc_bytes, L.wave_inst.data(), sizeof(int32_t) * (size_t)L.n_waves);
-    std::memcpy(stg + desc_bytes + map_bytes, L.wave_base.data(), sizeof(int32_t) * (size_t)L.n_waves);
 
     // --- workspace (grow-only; a growing hipFree/hipMalloc synchronises, steady state does not)
     const DevParams &P = h->P;
@@ -255,8 +254,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
         ProfScope ps(h, 0, st);
         MetaImport imp;
         imp.h_desc = (const InstDesc *)stg;
-        imp.h_wave_inst = (const int32_t *)(stg + desc_bytes);
-        imp.h_wave_base = (const int32_t *)(stg + desc_bytes + map_bytes);
         imp.d_desc = (InstDesc *)w.dMeta.p;
         imp.d_wave_inst = (int32_t *)((char *)w.dMeta.p + desc_bytes);
         imp.d_wave_base = (int32_t *)((char *)w.dMeta.p + desc_bytes + map_bytes);

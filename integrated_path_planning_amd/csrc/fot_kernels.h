@@ -24,7 +24,6 @@ struct EntryArrays {
 // descriptors still in pinned host memory, to be moved into HBM by k_frenet_state (h_desc == nullptr: already there)
 struct MetaImport {
     const InstDesc *h_desc = nullptr;
-    const int32_t *h_wave_inst = nullptr, *h_wave_base = nullptr;
     InstDesc *d_desc = nullptr;
     int32_t *d_wave_inst = nullptr, *d_wave_base = nullptr;
 };

@@ -155,7 +155,7 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
     static_assert(sizeof(InstDesc) % sizeof(unsigned long long) == 0, "InstDesc is copied in 8-byte words");
     if (imp.h_desc) {
         // First kernel of a plan call: the descriptors still sit in the caller-side pinned staging block.  Every
-        // workgroup moves its own instance's descriptor and wave-map slice into HBM for the kernels that follow
+        // workgroup moves its own instance's descriptor into HBM and writes its slice of the wave map for the kernels that follow
         // (instead of a separate H2D copy in front of the launch sequence) and works from the staging copy itself.
         desc = imp.h_desc;
         const unsigned long long *src = (const unsigned long long *)&desc[inst];
@@ -165,10 +165,10 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
             ((unsigned long long *)&s_desc)[threadIdx.x] = v;
         }
         __syncthreads();
-        const int w0 = s_desc.wave0, nw = s_desc.n_waves;
+        const int w0 = s_desc.wave0, nw = s_desc.n_waves;       // wave w0 + i of the batch = candidates 64 i .. of inst
         for (int i = threadIdx.x; i < nw; i += FRENET_WG) {
-            imp.d_wave_inst[w0 + i] = imp.h_wave_inst[w0 + i];
-            imp.d_wave_base[w0 + i] = imp.h_wave_base[w0 + i];
+            imp.d_wave_inst[w0 + i] = inst;
+            imp.d_wave_base[w0 + i] = i * WAVE;
         }
     } else {
         if (threadIdx.x < DESC_WORDS)
