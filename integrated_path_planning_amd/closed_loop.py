@@ -241,6 +241,8 @@ class BatchedClosedLoop:
             ep = Episode(peds=ReplayPedestrians(tracks, c.dt), observer=Observer(c.obs_len, c.dt, self.sgan_dt),
                          ego=ego, sm=sm, pstate=ps,
                          cycle=SpeculativePlanningCycle(ps, sm, c.ego_target_speed, max_replan_attempts=3))
+            if engine is None:
+                ep.cycle._path_kw = {"as_arrays": True}
             self.episodes.append(ep)
         self._warmup()
 
@@ -292,7 +294,7 @@ class BatchedClosedLoop:
                 stale = max(ep.peds.time - last, 0.0) if last is not None else 0.0
                 groups.setdefault(stale, []).append(i)
             for stale, idx in groups.items():
-                obs = [np.stack(list(eps[i].observer.history), axis=0) for i in idx]
+                obs = [np.stack(list(eps[i].observer.history)[-2:], axis=0) for i in idx]   # CV reads the last two samples
                 cat = np.concatenate(obs, axis=1)                    # [obs_len, sum P, 2]
                 out = self.resampler.predict_cv(cat, staleness=stale, float32_observations=True)
                 o = 0
@@ -303,7 +305,9 @@ class BatchedClosedLoop:
         for i, ep in enumerate(eps):
             cur = ep.peds.positions[:, None, :]
             d = preds[i] if preds[i] is not None else cur              # not ready: current positions only (:495-498)
-            if preds[i] is not None and not (d.shape[1] >= 1 and np.allclose(d[:, 0, :], cur[:, 0, :])):
+            # np.allclose(d[:, 0], cur[:, 0]) of the reference (rtol 1e-5, atol 1e-8; finite inputs), without its overhead
+            if preds[i] is not None and not (d.shape[1] >= 1 and bool(
+                    np.all(np.abs(d[:, 0, :] - cur[:, 0, :]) <= 1e-8 + 1e-5 * np.abs(cur[:, 0, :])))):
                 d = np.concatenate([cur, d], axis=1)                    # prepend the t=0 positions (:503-511)
             dyns[i] = d
         return preds, dyns, t_pred

@@ -51,6 +51,7 @@ class BatchResult:
         self.records = records
         self.n = n
         self._with_stop = list(with_stop)
+        self._paths = None
 
     def __len__(self):
         return self.n
@@ -68,14 +69,25 @@ class BatchResult:
             d["stop_distance_error"] = int(r.stats[7])
         return d
 
-    def path(self, i: int) -> Optional[FrenetPath]:
+    def _path_block(self) -> np.ndarray:
+        """[n, 15, FOT_MAX_NT] float64 view of the path arrays of all records (no copy)."""
+        if self._paths is None:
+            raw = np.frombuffer(self.records, dtype=np.uint8).reshape(-1, _abi.RESULT_BYTES)
+            off = getattr(_abi.Result, _abi.PATH_FIELDS[0]).offset
+            self._paths = raw[:, off:].view(np.float64).reshape(raw.shape[0], len(_abi.PATH_FIELDS), -1)
+        return self._paths
+
+    def path(self, i: int, as_arrays: bool = False) -> Optional[FrenetPath]:
+        """The selected path of instance i as the reference's FrenetPath (lists); as_arrays=True: NumPy rows, for
+        callers that take thousands of paths per second (closed_loop.py)."""
         r = self.records[i]
         if r.status != _abi.PLAN_OK:
             return None
         n = int(r.n_keep)
+        block = self._path_block()[i, :, :n]
         fp = FrenetPath()
-        for f in _abi.PATH_FIELDS:
-            setattr(fp, f, np.ctypeslib.as_array(getattr(r, f))[:n].tolist())
+        for j, f in enumerate(_abi.PATH_FIELDS):
+            setattr(fp, f, block[j].copy() if as_arrays else block[j].tolist())
         fp.cost = float(r.cost)
         return fp
 

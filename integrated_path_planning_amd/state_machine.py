@@ -152,6 +152,7 @@ class SpeculativePlanningCycle:
         self.sm = state_machine
         self.ego_target_speed = ego_target_speed
         self.max_replan_attempts = max_replan_attempts
+        self._path_kw = {}                        # BatchedClosedLoop asks for NumPy rows instead of lists
 
     def _ladder(self, metrics, ego_speed) -> List[StateMachineOutput]:
         """Configurations the retry loop would issue if every attempt failed (dry run on a copy)."""
@@ -194,7 +195,7 @@ class SpeculativePlanningCycle:
             if not np.isnan(rec.new_prev_s):
                 pl.converter._prev_s = float(rec.new_prev_s)
             pl.last_check_stats = res.stats(base + j)
-            path = res.path(base + j)
+            path = res.path(base + j, **self._path_kw)
             if path is not None:
                 pl._last_kappa = float(rec.new_last_kappa)
             return path
