@@ -246,7 +246,7 @@ def main():
                                            "three_calls_p50_ms": float(np.percentile(np.array(t_seq) * 1e3, 50))}
         p3.close()
         # row f4: whole closed-loop episodes in lock-step (fixture = pedestrian tracks + scenario of the reference run)
-        epi = os.path.join(ROOT, "tests", "golden", "closed_loop", "scenario01_cv_episode.npz")
+        epi = os.path.join(ROOT, "tests", "golden", "closed_loop", "reference_cv_episodes.npz")
         if os.path.exists(epi):
             from integrated_path_planning_amd.closed_loop import BatchedClosedLoop
             z = np.load(epi, allow_pickle=False)

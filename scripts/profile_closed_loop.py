@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import torch
 from integrated_path_planning_amd.closed_loop import BatchedClosedLoop
 import integrated_path_planning_amd.closed_loop as cl
-z = np.load('/root/repo/tests/golden/closed_loop/scenario01_cv_episode.npz', allow_pickle=False)
+z = np.load('/root/repo/tests/golden/closed_loop/reference_cv_episodes.npz', allow_pickle=False)
 cfg = json.loads(str(z['meta']))['variants']['base']['config']
 loop = BatchedClosedLoop(cfg, [z['base_ped_traj']] * 64)
 import cProfile, pstats

@@ -15,7 +15,7 @@ STATE_NAMES = {0: "NORMAL", 1: "CAUTION", 2: "EMERGENCY"}
 
 
 def load_episodes():
-    z = np.load(os.path.join(GOLDEN_DIR, "closed_loop", "scenario01_cv_episode.npz"), allow_pickle=False)
+    z = np.load(os.path.join(GOLDEN_DIR, "closed_loop", "reference_cv_episodes.npz"), allow_pickle=False)
     d = {k: z[k] for k in z.files}
     d["meta"] = json.loads(str(d["meta"]))
     return d

@@ -108,7 +108,7 @@ def main():
               "no path", int((plen == 0).sum()))
     meta["config"] = meta["variants"]["base"]["config"]          # scenario_01, kept for the callers that read it here
     out["meta"] = np.array(json.dumps(meta))
-    path = os.path.join(HERE, "closed_loop", "scenario01_cv_episode.npz")
+    path = os.path.join(HERE, "closed_loop", "reference_cv_episodes.npz")
     np.savez_compressed(path, **out)
     print(f"{os.path.getsize(path) / 1e6:.2f} MB")
 
