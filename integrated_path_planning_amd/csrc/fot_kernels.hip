@@ -476,9 +476,11 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     {
         const int idx0 = wave_base[wave_first];
         if (S0.c2f_ok && idx0 < S0.n_cand) {
+            // profiles of the block's first .. last candidate (slots grow with the candidate index)
+            const int idx1 = idx0 + EVAL_WG - 1 < S0.n_cand - 1 ? idx0 + EVAL_WG - 1 : S0.n_cand - 1;
             slot_lo = decode_candidate(P, D0, S0.frenet0, idx0).lon_slot;
-            const int n_prof = P.n_ti * D0.n_tv + S0.n_brake;     // valid profiles of the instance
-            n_stage = n_prof - slot_lo < lds_profiles ? n_prof - slot_lo : lds_profiles;
+            const int used = decode_candidate(P, D0, S0.frenet0, idx1).lon_slot - slot_lo + 1;
+            n_stage = used < lds_profiles ? used : lds_profiles;
         }
     }
     // LDS: rows [lds_profiles][n_total][ROW_FIELDS] | profile summaries [lds_profiles] | spline
