@@ -184,6 +184,14 @@ def main():
         cpu = {"value": n_c / dt_cpu, "unit": "candidates/s", "cores": 1, "kind": "port",
                "sample": f"first {n_cpu} instances of the same batch, oracle/fot_oracle.c single thread, "
                          f"{dt_cpu:.1f} s; host has {os.cpu_count()} logical cores"}
+        # the same port on the box's CPU share: one instance per task, threads (the C call releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = min(16, os.cpu_count() or 1)
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(n_thr) as ex:
+            n_mt = sum(ex.map(lambda rq: oracle_plan_for_request(orc, oparams, osp, rq).n_cand, reqs[:n_cpu]))
+        dt_mt = time.perf_counter() - t1
+        cpu["threads"] = {"value": n_mt / dt_mt, "cores": n_thr, "seconds": dt_mt}
 
     # ---- plan-step latency for one ego through the host-pointer API (H2D + kernels + D2H)
     latency = None
