@@ -103,3 +103,13 @@ def test_device_resident_handover_into_planner(engine):
     rq = PlanRequest(*ego, dist=got_t.astype(np.float64))
     assert_record_matches_oracle(rec, oracle_plan_for_request(orc, params, sp, rq), label="resample->plan")
     assert rs.best_sample(dist) == orc.best_sample(got_t.astype(np.float64))[0]
+
+
+def test_predict_cv_float32_observation_mode(engine):
+    rng = np.random.default_rng(12)
+    obs = rng.normal(0, 20, (8, 21, 2))
+    rs = PredictionResampler(engine, pred_len=12, sgan_dt=0.4, sim_dt=0.1, plan_horizon=5.0)
+    for f32 in (False, True):
+        got = rs.predict_cv(obs, staleness=0.2, float32_observations=f32)
+        want = orc.predict_cv(obs[-1], obs[-2], 0.2, float32_observations=f32)
+        np.testing.assert_allclose(got, want, rtol=1e-15, atol=1e-13)

@@ -41,3 +41,21 @@ def test_best_sample(cases):
     for m in cases["meta"]["select"]:
         best, dist = orc.best_sample(cases[f"s{m['case']}_samples"])
         assert best == m["best"], m
+
+
+def test_predict_cv_float32_observations_follow_numpy_semantics():
+    """The observer hands float32 tensors to predict_cv (observer.py:134): positions rounded to float32, the velocity
+    (p_curr - p_prev) / sgan_dt evaluated in float32, the extrapolation in float64 (trajectory_predictor.py:203-228)."""
+    rng = np.random.default_rng(11)
+    obs = rng.normal(0, 20, (8, 13, 2))
+    for stale in (0.0, 0.1, 0.30000000000000004):
+        got = orc.predict_cv(obs[-1], obs[-2], stale, float32_observations=True)
+        cur, prev = obs[-1].astype(np.float32), obs[-2].astype(np.float32)
+        vel = (cur - prev) / 0.4                                   # float32 array / Python float -> float32
+        assert vel.dtype == np.float32
+        t = np.arange(0.1, 5.0 + 1e-9, 0.1) + stale
+        want = cur[:, None, :] + vel[:, None, :] * t[None, :, None]   # float32 * float64 -> float64
+        assert want.dtype == np.float64
+        np.testing.assert_allclose(got, want, rtol=1e-15, atol=1e-13)
+    f64 = orc.predict_cv(obs[-1], obs[-2], 0.1)
+    assert np.abs(f64 - orc.predict_cv(obs[-1], obs[-2], 0.1, float32_observations=True)).max() > 1e-7
