@@ -82,3 +82,18 @@ def test_empty_and_degenerate_inputs():
             PlanRequest(5.0, 0.0, 0.0, 5.0, 0.0, dyn=np.full((3, 1, 2), 1e6)),          # everything far away, T = 1
             PlanRequest(500.0, 300.0, 0.0, 5.0, 0.0, static=np.array([[500.0, 300.0]]))]  # ego far off the path
     _check(bp, params, sp, reqs)
+
+
+def test_more_profiles_than_the_cull_box_cache():
+    """31 horizons x 9 terminal speeds = 279 longitudinal profiles: k_cull keeps the boxes of the first 128 in LDS and
+    derives the others again where it needs them; k_evaluate blocks span more profiles than fit their LDS window."""
+    kw = dict(dt=0.1, min_t=2.0, max_t=5.0, d_t_s=1.0, max_road_width=1.0, d_road_w=1.0, robot_radius=0.8,
+              obstacle_radius=0.2, max_speed=12.0)
+    rng = np.random.default_rng(4)
+    dyn = np.array([25.0, 0.0]) + rng.normal(0, 6.0, (25, 1, 2)) + np.cumsum(rng.normal(0, 0.1, (25, 51, 2)), axis=1)
+    static = np.column_stack([rng.uniform(5, 60, 40), rng.uniform(-3, 3, 40)])
+    bp = BatchPlanner(waypoints=(WX, WY), **kw)
+    reqs = [PlanRequest(2.0, 0.1, 0.0, 6.0, 0.0, target_speed=7.5, dyn=dyn, static=static),
+            PlanRequest(8.0, -0.2, 0.02, 4.0, 0.3, target_speed=7.5, dyn=dyn)]
+    res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
+    assert res.records[0].n_cand > 279 * 3
