@@ -92,7 +92,7 @@ SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_se
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
            "fot_debug_candidate_path", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
            "fot_predict_cv", "fot_safety_metrics_batch", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
-PROFILE_KERNELS = 6
+PROFILE_KERNELS = 4                      # FOT_PROFILE_KERNELS (include/fot.h)
 
 _lib = None
 

@@ -129,3 +129,12 @@ def test_reference_style_spline_object_is_accepted():
     bad = SimpleNamespace(s=[0.0, 1.0], sx=SimpleNamespace(a=[0, 1], b=[1, 2], c=[0, 0], d=[0]), sy=ref_like.sy)
     with pytest.raises(ValueError):
         spline_arrays(bad)
+
+
+def test_header_constants_match_the_python_mirror():
+    import re
+    from integrated_path_planning_amd import _abi
+    text = open(os.path.join(os.path.dirname(__file__), "..", "include", "fot.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define (FOT_[A-Z_]+) (\d+)\b", text)}
+    assert defs["FOT_PROFILE_KERNELS"] == _abi.PROFILE_KERNELS
+    assert defs["FOT_MAX_NT"] == _abi.MAX_NT
