@@ -391,12 +391,13 @@ struct FusedSink {
             }
             // a single violation is fatal (no chance constraint budget): a certain float32 hit settles the candidate
             if (sure) { hit = true; return; }
-            if (near_bits != 0) exact(k, c0, nb, near_bits, px, py);
+            if (near_bits != 0) exact(k, c0, nb, near_bits, px, py, fx, fy, thr, filter_threshold_sure(fc, fx, fy));
         }
     }
 
     // rare: exact float64 re-check of the chunks whose float32 distance came within the threshold
-    __device__ __forceinline__ void exact(int k, int c0, int nb, uint32_t near_bits, double px, double py)
+    __device__ __forceinline__ void exact(int k, int c0, int nb, uint32_t near_bits, double px, double py, float fx,
+                                          float fy, float thr, float thr_sure)
     {
         const DevParams &P = *Pp;
         const InstDesc &D = *Dp;
@@ -406,7 +407,8 @@ struct FusedSink {
             const int hb = 31 - __clz((int)near_bits);             // highest bit = earliest chunk
             near_bits &= ~(1u << hb);
             const int64_t e = base + (int64_t)(c0 + nb - 1 - hb) * ENT_CHUNK;
-            exact_chunk(e64 + e, sid + e, px, py, P.sq_r, sq_dyn, D.max_viol, hit_mask, viol, hit);
+            exact_chunk_f32first(chunks[e / ENT_CHUNK], e64 + e, sid + e, fx, fy, thr, thr_sure, px, py, P.sq_r, sq_dyn,
+                                 D.max_viol, hit_mask, viol, hit);
         }
     }
 

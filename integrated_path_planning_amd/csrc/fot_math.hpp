@@ -845,6 +845,33 @@ FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py,
     }
 }
 
+// The same decision with the float64 coordinates touched only where float32 cannot tell: all float32 coordinates
+// and sample ids of the chunk are fetched in one go (72 contiguous bytes), every entry is classified by its float32
+// squared distance -- above `thr`: miss; at or below `thr_sure` (filter_threshold_sure: within the SMALLER radius for
+// certain): hit of whatever kind; in between: the reference's float64 expression on that one entry.
+FOT_HD void exact_chunk_f32first(const f2x8 &c32, const d2 *e64, const uint8_t *sid, float fx, float fy, float thr,
+                                 float thr_sure, double px, double py, double sq_static, double sq_dyn, int max_viol,
+                                 uint64_t &hit_mask, int &viol, bool &collided)
+{
+    uint8_t s8[ENT_CHUNK];
+    for (int j = 0; j < ENT_CHUNK; ++j) s8[j] = sid[j];
+    for (int j = 0; j < ENT_CHUNK; ++j) {
+        const float dx = fx - c32.x[j], dy = fy - c32.y[j];
+        const float d32 = fmaf(dy, dy, dx * dx);
+        if (d32 > thr) continue;                                             // certainly outside either radius
+        const int s = s8[j];
+        const bool is_static = s == SID_STATIC;
+        if (!is_static && ((hit_mask >> s) & 1)) continue;                   // this sample already counts
+        const bool in = d32 <= thr_sure ? true : within(e64[j], px, py, is_static ? sq_static : sq_dyn);
+        if (!in) continue;
+        if (is_static) collided = true;                                      // static obstacles are hard constraints
+        else {
+            hit_mask |= (uint64_t)1 << s;
+            if (++viol > max_viol) collided = true;
+        }
+    }
+}
+
 // Collision state of one candidate, fed sample by sample from evaluate_candidate and tested against the culled
 // entry lists of its instance (same decision as collide_candidate).  cnt[k]: entries of time step k (multiple of 8);
 // the entry arrays hold ent_cap slots per k.  This is the portable form; k_evaluate's sink is the same logic with
@@ -880,7 +907,8 @@ struct EntryCollider {
             const float m = min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy);
             if (m > thr) continue;
             if (max_viol == 0 && m <= thr_sure) { hit = true; break; }      // certain hit: one violation is fatal
-            exact_chunk(e64 + base + c, sid + base + c, px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
+            exact_chunk_f32first(*(const f2x8 *)(e32 + base + c), e64 + base + c, sid + base + c, fx, fy, thr, thr_sure,
+                                 px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
         }
     }
     FOT_HD bool collided() const { return hit; }
