@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+N_SIMD = 1024                    # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9                 # MI355X peak engine clock
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_FP64_PEAK_TF = 78.6       # fp64 vector peak = half the 157.3 TF fp32 vector peak
 # algorithmic HBM bytes and nominal flops per candidate of config 3/4/5
@@ -161,6 +163,18 @@ def main():
             "note": "nominal brute-force flops of SURVEY 8(d) (every candidate sample x every obstacle point); the "
                     "broad phase skips ~96% of those pair tests, so this can exceed the peak"}
     valu["frac"] = valu["achieved"] / valu["peak"]
+    # what the kernel actually issues (rocprofv3 --pmc SQ_INSTS_VALU of the same command, profiles/): the time its vector
+    # instructions alone would take at one wave64 instruction per 4 cycles per SIMD, against the measured launch time
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))[dom]     # copy of the latest <tag>_pmc.json
+        n_valu = float(pmc["SQ_INSTS_VALU"])
+        issue_ms = n_valu * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
+        valu["issue_bound"] = {"source": "profiles/pmc.json", "valu_instructions_per_launch": n_valu,
+                               "cycles_per_instruction": 4, "simds": N_SIMD, "clock_ghz": CLOCK_HZ / 1e9,
+                               "bound_ms": issue_ms, "frac": issue_ms / dom_ms,
+                               "note": "valid for the default workload (256 instances per launch), which the profile ran"}
+    except Exception:
+        pass
     kernels = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items() if v["launches"]}
 
     # ---- parity spot check against the oracle (checker only, outside the timed region)

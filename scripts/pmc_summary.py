@@ -69,6 +69,7 @@ def main():
             pmc.setdefault(k, {}).update({c: v[0] / v[1] for c, v in cs.items() if v[1]})
     json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    json.dump(pmc, open(os.path.join(out, "pmc.json"), "w"), indent=1)          # what bench.py reads (with traffic.json)
     print(json.dumps(traffic, indent=1))
 
 
