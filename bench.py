@@ -67,10 +67,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # FOT_BENCH_REHEARSE=1: dry run of the N > 1 control flow on a box with ONE GPU -- every rank on cuda:0, records
+    # gathered through host memory with "gloo".  Not a measurement (the line says so), never used by the driver.
+    rehearse = os.environ.get("FOT_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     n_inst = args.instances_per_gpu
     seeds = range(rank * n_inst, (rank + 1) * n_inst)
@@ -83,17 +91,28 @@ def main():
     dyn_dev = torch.from_numpy(pb.dyn_xy).to(dev)
     static_dev = torch.from_numpy(pb.static_xy).to(dev) if pb.static_xy.size else None
     out_dev = torch.zeros(n_inst * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * n_inst * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev) if world > 1 else None
+    # N > 1: the selected-path records of every rank are all-gathered (RCCL over xGMI) in every step; the gather of step i
+    # runs on the collective's stream while step i+1 plans into the other buffer pair (distributed.PipelinedAllGather)
+    from integrated_path_planning_amd.distributed import PipelinedAllGather
+    pg = PipelinedAllGather(n_inst * _abi.RESULT_BYTES, world, torch.device("cpu") if rehearse else dev) if world > 1 else None
     bstruct = pb.with_device_obstacles(static_dev.data_ptr() if static_dev is not None else None, dyn_dev.data_ptr())
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out_dev)      # selected-path records of every rank, RCCL over xGMI
+        if pg is None:
+            bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
+            return
+        j, out, _ = pg.slot()                                   # free again: the gather that last read it is done
+        if rehearse:
+            bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
+            out.copy_(out_dev)                                  # (synchronous D2H: rehearsal only)
+        else:
+            bp.plan_packed_device(bstruct, out.data_ptr(), stream.cuda_stream)
+        pg.launch(j)
 
     def fence():
-        if world > 1:
+        if pg is not None:
+            pg.drain()                                          # every gather of the timed steps is inside the region
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -110,15 +129,19 @@ def main():
     prof = bp.profile_read(reset=True)
     bp.profile(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # candidates actually generated (from the result records)
+    gathered = None
+    if pg is not None:
+        gathered = pg.drain()
+        out_dev = pg.send[(pg.step - 1) % pg.depth]
     recs_host = out_dev.cpu().numpy()
     recs = (_abi.Result * n_inst).from_buffer_copy(recs_host.tobytes())
     cand_local = sum(int(r.n_cand) for r in recs)
-    cand_total = torch.tensor([cand_local], dtype=torch.int64, device=dev)
+    cand_total = torch.tensor([cand_local], dtype=torch.int64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(cand_total)
     cand_total = int(cand_total.item())
@@ -296,7 +319,7 @@ def main():
         "metric": "candidate trajectories/sec", "value": value, "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL of the N>1 control flow on one GPU: not a measurement)",
         "config": {"workload": "config4: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "
                                "20-sample x 30-pedestrian x 51-step fp32 prediction distribution, eps=0" % n_inst,
                    "instances_per_gpu": n_inst, "candidates_per_step": cand_total,

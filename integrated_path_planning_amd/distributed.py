@@ -62,6 +62,44 @@ def all_gather_records(local, n_total: int, world: int, rank: int, group=None):
     return torch.cat(parts)
 
 
+class PipelinedAllGather:
+    """Double-buffered asynchronous all-gather for back-to-back plan steps.
+
+    The gather of step i runs on the collective's own stream (RCCL over xGMI) while step i+1 already plans into the
+    other buffer pair; a buffer pair is handed out again only after the gather that used it has completed.  Every rank
+    contributes the same number of bytes (equal shards, as in the weak-scaling benchmark)."""
+
+    def __init__(self, n_bytes_local: int, world: int, device, depth: int = 2, group=None):
+        import torch
+        self.world, self.depth, self.group = world, depth, group
+        self.send = [torch.zeros(n_bytes_local, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.recv = [torch.zeros(world * n_bytes_local, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+        self.step = 0
+
+    def slot(self):
+        """(index, send buffer, receive buffer) for the next step."""
+        j = self.step % self.depth
+        if self.work[j] is not None:
+            self.work[j].wait()                  # device-side wait on the current stream for "nccl", host wait for "gloo"
+            self.work[j] = None
+        return j, self.send[j], self.recv[j]
+
+    def launch(self, j: int) -> None:
+        """Start gathering send[j] (written on the current stream) into recv[j]."""
+        import torch.distributed as dist
+        self.work[j] = dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group, async_op=True)
+        self.step += 1
+
+    def drain(self):
+        """Wait for every gather in flight; returns the receive buffer of the most recent step (None before any)."""
+        for j in range(self.depth):
+            if self.work[j] is not None:
+                self.work[j].wait()
+                self.work[j] = None
+        return self.recv[(self.step - 1) % self.depth] if self.step else None
+
+
 def records_from_bytes(buf: np.ndarray, n: int):
     """uint8 array -> ctypes array of ``fot_result``."""
     return (_abi.Result * n).from_buffer_copy(np.ascontiguousarray(buf[: n * _abi.RESULT_BYTES]).tobytes())

@@ -79,3 +79,45 @@ def test_all_gather_world2(n_total):
         p.join(120)
         assert p.exitcode == 0
     assert all(ret[r] for r in range(world))
+
+
+def _pipe_worker(rank, world, port, ret):
+    from integrated_path_planning_amd.distributed import PipelinedAllGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nb = 3 * _abi.RESULT_BYTES
+        pg = PipelinedAllGather(nb, world, torch.device("cpu"))
+        ok = True
+        seen = {}
+        for step in range(7):                                   # more steps than buffers: every pair is reused
+            j, send, recv = pg.slot()
+            if j in seen:                                       # the pair is free again: its previous gather is complete
+                s0 = seen[j]
+                for r in range(world):
+                    ok &= bool((recv[r * nb:(r + 1) * nb] == (s0 * 16 + r) % 251).all())
+            send.fill_((step * 16 + rank) % 251)
+            pg.launch(j)
+            seen[j] = step
+        last = pg.drain()
+        for r in range(world):
+            ok &= bool((last[r * nb:(r + 1) * nb] == (6 * 16 + r) % 251).all())
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_all_gather_world2():
+    """Double-buffered asynchronous gather (what bench.py runs at N > 1): buffers rotate, nothing is overwritten early."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(world))
