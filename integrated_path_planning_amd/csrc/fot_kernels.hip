@@ -1,15 +1,18 @@
 // fot_kernels.hip -- gfx950 kernels of the Frenet optimal-trajectory planner.
 //
 // Pipeline of one fot_plan_batch (one launch each over the whole batch; every decision in float64):
-//   k_frenet_state : 1 wave / instance: nearest point (wave-parallel scan + shuffle argmin) + Cartesian->Frenet
-//   k_cull         : 1 wave / (instance, 8 consecutive time steps): merges the profile boxes, then sorts the obstacles
-//                    of those time rows that lie inside the grown boxes into per-step entry lists (strips, LDS atomics)
-//   k_evaluate     : 1 lane / candidate: quintic, Frenet->Cartesian, cost, truncation, kinematic checks, and -- while
-//                    the candidate can still pass -- the collision test of each sample against the entry list of
-//                    its time step (wave-uniform chunk walk on scalar loads, float32 broad phase, exact float64
-//                    re-check of near chunks).  Candidate points never leave registers.
-//   k_select       : 1 wave / instance: stop-distance filter, rejection histogram, first-minimum argmin
-//                    (shuffle reduction, lowest index wins ties), selected path written out
+//   k_frenet_state : 4 waves / instance: pulls the instance's descriptor out of the pinned staging block, nearest point
+//                    (sample scan over the workgroup, three refinement rounds per evaluation) + Cartesian->Frenet
+//   k_cull         : 8 waves / (instance, 8 consecutive time steps): derives and merges the boxes of the instance's
+//                    longitudinal profiles, sorts the obstacles of those time rows that lie inside the grown boxes
+//                    into per-step entry lists (strips, LDS atomics), writes each candidate wave's chunk range
+//   k_evaluate     : 1 lane / candidate, 4 waves / workgroup: the workgroup builds the rows of its profiles in LDS;
+//                    quintic, Frenet->Cartesian, cost, truncation, kinematic checks, and -- while the candidate can
+//                    still pass -- the collision test of each sample against the entry list of its time step
+//                    (wave-uniform chunk walk on scalar loads, float32 bounds, float64 only between them).
+//                    Candidate points never leave registers.
+//   k_select       : 4 waves / instance: stop-distance filter, rejection histogram, first-minimum argmin (lowest index
+//                    wins ties), selected path rebuilt from its profile and written out
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
