@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances-per-gpu", type=int, default=256)
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="plan calls in flight: consecutive steps alternate between this many handles/streams, so the "
+                         "launch gaps and the draining tail of one step are filled by the next (1 = strictly serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="timing diagnostics only (FOT_EVAL_ABLATE / FOT_CULL_ABLATE builds give wrong results)")
@@ -97,18 +100,29 @@ def main():
     pg = PipelinedAllGather(n_inst * _abi.RESULT_BYTES, world, torch.device("cpu") if rehearse else dev) if world > 1 else None
     bstruct = pb.with_device_obstacles(static_dev.data_ptr() if static_dev is not None else None, dyn_dev.data_ptr())
     stream = torch.cuda.current_stream(dev)
+    # steps are independent plan calls: with --overlap 2 they alternate between two handles (each with its own
+    # workspace) on two streams, the way a server keeps two batches in flight
+    n_ov = max(1, min(args.overlap, 2))
+    planners = [bp] + [BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **kw)
+                       for _ in range(n_ov - 1)]
+    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_ov - 1)]
+    outs = [out_dev] + [torch.zeros_like(out_dev) for _ in range(n_ov - 1)]
+    counter = [0]
 
     def step():
-        if pg is None:
-            bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
-            return
-        j, out, _ = pg.slot()                                   # free again: the gather that last read it is done
-        if rehearse:
-            bp.plan_packed_device(bstruct, out_dev.data_ptr(), stream.cuda_stream)
-            out.copy_(out_dev)                                  # (synchronous D2H: rehearsal only)
-        else:
-            bp.plan_packed_device(bstruct, out.data_ptr(), stream.cuda_stream)
-        pg.launch(j)
+        b = counter[0] % n_ov
+        counter[0] += 1
+        with torch.cuda.stream(streams[b]):
+            if pg is None:
+                planners[b].plan_packed_device(bstruct, outs[b].data_ptr(), streams[b].cuda_stream)
+                return
+            j, out, _ = pg.slot()                               # free again: the gather that last read it is done
+            if rehearse:
+                planners[b].plan_packed_device(bstruct, outs[b].data_ptr(), streams[b].cuda_stream)
+                out.copy_(outs[b])                              # (synchronous D2H: rehearsal only)
+            else:
+                planners[b].plan_packed_device(bstruct, out.data_ptr(), streams[b].cuda_stream)
+            pg.launch(j)
 
     def fence():
         if pg is not None:
@@ -119,15 +133,20 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    bp.profile(True)
-    bp.profile_read(reset=True)
+    for p_ in planners:
+        p_.profile(True)
+        p_.profile_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = bp.profile_read(reset=True)
-    bp.profile(False)
+    prof = {}
+    for p_ in planners:                                         # per-kernel HIP-event totals over all handles
+        for k_, v_ in p_.profile_read(reset=True).items():
+            a_ = prof.setdefault(k_, {"launches": 0, "total_ms": 0.0})
+            a_["launches"] += v_["launches"]; a_["total_ms"] += v_["total_ms"]
+        p_.profile(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -322,7 +341,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL of the N>1 control flow on one GPU: not a measurement)",
         "config": {"workload": "config4: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "
                                "20-sample x 30-pedestrian x 51-step fp32 prediction distribution, eps=0" % n_inst,
-                   "instances_per_gpu": n_inst, "candidates_per_step": cand_total,
+                   "instances_per_gpu": n_inst, "plan_calls_in_flight": n_ov, "candidates_per_step": cand_total,
                    "parallelism": "instances sharded over %d GPU(s), RCCL all-gather of %d-byte path records"
                                   % (world, _abi.RESULT_BYTES)},
         "roofline": roofline, "roofline_valu": valu, "kernel_ms": kernels,
