@@ -97,12 +97,14 @@ def main():
     # N > 1: the selected-path records of every rank are all-gathered (RCCL over xGMI) in every step; the gather of step i
     # runs on the collective's stream while step i+1 plans into the other buffer pair (distributed.PipelinedAllGather)
     from integrated_path_planning_amd.distributed import PipelinedAllGather
-    pg = PipelinedAllGather(n_inst * _abi.RESULT_BYTES, world, torch.device("cpu") if rehearse else dev) if world > 1 else None
+    pg = PipelinedAllGather(n_inst * _abi.RESULT_BYTES, world, torch.device("cpu") if rehearse else dev,
+                            depth=max(2, min(args.overlap, 4))) if world > 1 else None     # slot j <-> stream j
     bstruct = pb.with_device_obstacles(static_dev.data_ptr() if static_dev is not None else None, dyn_dev.data_ptr())
     stream = torch.cuda.current_stream(dev)
-    # steps are independent plan calls: with --overlap 2 they alternate between two handles (each with its own
-    # workspace) on two streams, the way a server keeps two batches in flight
-    n_ov = max(1, min(args.overlap, 2))
+    # steps are independent plan calls: by default they alternate between two handles (each with its own
+    # workspace) on two streams, the way a server keeps batches in flight (--overlap 3 is faster still, but then two
+    # launches of the dominant kernel share the GPU and its per-launch time no longer says anything about the kernel)
+    n_ov = max(1, min(args.overlap, 4))
     planners = [bp] + [BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **kw)
                        for _ in range(n_ov - 1)]
     streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_ov - 1)]
