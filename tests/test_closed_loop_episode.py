@@ -69,3 +69,17 @@ def test_replay_velocities_and_clamp():
     p.step(10)
     assert p._idx == 4 and abs(p.time - 5.0) < 1e-12
     np.testing.assert_allclose(p.goals, tr[-1])
+
+
+def test_static_rectangles_expand_like_the_reference(episodes):
+    """integrated_simulator.py:805-832: boundary points every 0.5 m, duplicates removed (count recorded from the reference)."""
+    from integrated_path_planning_amd.closed_loop import expand_static_obstacles
+    v = episodes["meta"]["variants"]["walls"]
+    pts = expand_static_obstacles(v["config"]["static_obstacles"], step=0.5)
+    assert len(pts) == v["n_static_points"] > 0
+    assert np.array_equal(pts, np.unique(pts, axis=0))
+    xmin, xmax, ymin, ymax = v["config"]["static_obstacles"][0]
+    on_edge = (np.isclose(pts[:, 0], xmin) | np.isclose(pts[:, 0], xmax) | np.isclose(pts[:, 1], ymin) | np.isclose(pts[:, 1], ymax))
+    first = (pts[:, 1] >= ymin - 1e-9) & (pts[:, 1] <= ymax + 0.5)
+    assert on_edge[first & (pts[:, 0] <= xmax + 1e-9)].any()
+    assert expand_static_obstacles(None).shape == (0, 2) and expand_static_obstacles([]).shape == (0, 2)
