@@ -624,7 +624,7 @@ typedef struct {
 static int collision_geometry(const orc_params *p, int n, const double *x, const double *y,
                               const double *yaw, const double *t, double inflation, coll_geom *g)
 {
-    if (n == 0) return 0;
+    if (n <= 0) return 0;
     double ego_r;
     int m = 0;
     if (p->n_circles <= 0) {
