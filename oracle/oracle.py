@@ -171,7 +171,7 @@ class Spline:
         self.n = L.orc_spline_n(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # module globals are gone at interpreter exit
             lib().orc_spline_free(self._h)
             self._h = None
 

@@ -56,7 +56,7 @@ def random_planner_kwargs(rng):
     return kw
 
 
-def random_request(rng, sp, kw):
+def random_request(rng, sp, kw, dense=False):
     s_end = sp.coeffs()[0][-1]
     s = rng.uniform(0.0, s_end) if rng.random() < 0.9 else rng.uniform(s_end - 3, s_end)
     x, y, yaw, _, _ = [a[0] for a in sp.eval([s])]
@@ -73,17 +73,26 @@ def random_request(rng, sp, kw):
     if rng.random() < 0.2:
         req.max_stop_distance = float(rng.uniform(0.05, 12.0))
     n_t = int(round(kw["max_t"] / kw["dt"])) + 1
-    ahead = np.stack([a for a in sp.eval(np.clip(s + rng.uniform(0, 45, 64), 0, s_end))[:2]], axis=1)
+    ax, ay, ayaw = sp.eval(np.clip(s + rng.uniform(0, 45, 64), 0, s_end))[:3]
+    ahead = np.stack([ax, ay], axis=1)
+
+    def beside(idx):                                # points along both road sides, some reaching into the lattice
+        reach = kw["max_road_width"] + kw["robot_radius"] + kw["obstacle_radius"]
+        off = rng.choice([-1.0, 1.0], len(idx)) * rng.uniform(0.6, 2.0, len(idx)) * reach
+        return ahead[idx] + np.stack([-np.sin(ayaw[idx]) * off, np.cos(ayaw[idx]) * off], axis=1)
     mode = rng.integers(0, 4)
-    if rng.random() < 0.5:
-        pick = ahead[rng.integers(0, 64, rng.integers(1, 40))]
-        req.static = pick + rng.normal(0, 4.0, pick.shape)
+    if dense:                                       # crowded scenes: the broad phase's strips, lists and bins fill up
+        mode = int(rng.integers(1, 3))
+    if rng.random() < (0.8 if dense else 0.5):
+        pick = ahead[rng.integers(0, 64, rng.integers(100, 700) if dense else rng.integers(1, 40))]
+        req.static = beside(rng.integers(0, 64, len(pick))) + rng.normal(0, 0.3, pick.shape) if dense \
+            else pick + rng.normal(0, 4.0, pick.shape)
     if mode in (1, 2):
-        P = int(rng.integers(1, 25))
+        P = int(rng.integers(30, 90)) if dense else int(rng.integers(1, 25))
         T = int(rng.choice([1, n_t // 2, n_t, n_t + 3]))
-        S = 1 if mode == 1 else int(rng.integers(2, 24))
-        p0 = ahead[rng.integers(0, 64, P)] + rng.normal(0, 5.0, (P, 2))
-        vel = rng.normal(0, 1.2, (S, P, 1, 2))
+        S = 1 if mode == 1 else (int(rng.integers(20, 64)) if dense else int(rng.integers(2, 24)))
+        p0 = beside(rng.integers(0, 64, P)) if dense else ahead[rng.integers(0, 64, P)] + rng.normal(0, 5.0, (P, 2))
+        vel = rng.normal(0, 0.3 if dense else 1.2, (S, P, 1, 2))
         t = (np.arange(T) * kw["dt"])[None, None, :, None]
         traj = p0[None, :, None, :] + vel * t + np.cumsum(rng.normal(0, 0.05, (S, P, T, 2)), axis=2)
         if mode == 1:
@@ -94,21 +103,35 @@ def random_request(rng, sp, kw):
 
 
 # FOT_FUZZ_SEEDS=N widens the sweep (default 40 seeds x 6 instances; a 1000-seed sweep was run once per build round)
+# FOT_FUZZ_BASE=B moves the sweep to seeds B .. B+N-1
 N_SEEDS = int(os.environ.get("FOT_FUZZ_SEEDS", "40"))
+SEED_BASE = int(os.environ.get("FOT_FUZZ_BASE", "0"))
+N_DENSE = int(os.environ.get("FOT_FUZZ_DENSE_SEEDS", "8"))
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
+@pytest.mark.parametrize("seed", range(SEED_BASE, SEED_BASE + N_SEEDS))
 def test_random_configuration(seed):
+    run_seed(seed, n_inst=6, dense=False)
+
+
+@pytest.mark.parametrize("seed", range(SEED_BASE, SEED_BASE + N_DENSE))
+def test_random_crowded_configuration(seed):
+    run_seed(500000 + seed, n_inst=3, dense=True)
+
+
+def run_seed(seed, n_inst, dense):
     rng = np.random.default_rng(1000 + seed)
     wx, wy = random_path(rng)
     kw = random_planner_kwargs(rng)
+    if dense:                                       # let most candidates reach the collision check
+        kw.update(max_curvature=10.0, max_accel=max(kw["max_accel"], 5.0))
     okw = dict(kw)
     fp = okw.pop("footprint", None)
     if fp is not None:
         okw["footprint_offsets"], okw["footprint_radius"] = list(fp.offsets), fp.radius
     params, sp = orc.make_params(**okw), orc.Spline(wx, wy)
     bp = BatchPlanner(waypoints=(wx, wy), **kw)
-    reqs = [random_request(rng, sp, kw) for _ in range(6)]
+    reqs = [random_request(rng, sp, kw, dense) for _ in range(n_inst)]
     res = bp.plan_batch(reqs)
     for i, rq in enumerate(reqs):
         want = oracle_plan_for_request(orc, params, sp, rq, table=True)
