@@ -267,8 +267,13 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     }
     {
         ProfScope ps(h, 2, st);
+        // every instance with the same number of waves: k_evaluate may reorder its workgroups (longest first)
+        const InstDesc *hd = (const InstDesc *)stg;
+        int uniform = L.n_inst;
+        for (int i = 0; i < L.n_inst && uniform; ++i)
+            if (hd[i].n_waves != hd[0].n_waves || hd[i].wave0 != i * hd[0].n_waves) uniform = 0;
         LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total,
-                                      d_wave_inst, d_wave_base, L.n_waves, ea, ca, st));
+                                      d_wave_inst, d_wave_base, L.n_waves, uniform, ea, ca, st));
     }
     {
         ProfScope ps(h, 3, st);

@@ -35,7 +35,7 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
                 SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
                 hipStream_t st);
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total, const int32_t *wave_inst,
-                    const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st);
+                    const int32_t *wave_base, int n_waves, int uniform_n_inst, EntryArrays e, CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state,
                   SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state,

@@ -463,7 +463,7 @@ struct StagedTab {
 __global__ void __launch_bounds__(EVAL_WG)
 k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
            const InstState *__restrict__ state, int lds_profiles,
-           int lds_knots, int ablate, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
+           int lds_knots, int ablate, int perm_n_inst, int perm_nb, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
            const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
            const uint8_t *__restrict__ ent_sid,
            double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
@@ -473,7 +473,14 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     const int n_total = P.n_total;
     // --- the rows of the profiles [slot_lo, slot_lo + n_stage) of the block's instance, built straight into LDS (no
     //     table in HBM): slot_lo is the profile of the block's first candidate; a block never spans two instances
-    const int wave_first = blockIdx.x * (EVAL_WG / WAVE);
+    // uniform batches: workgroups in (position inside the instance, descending) x (instance) order -- the long
+    // horizons and the brake ladder first, the short horizons in the last round; an instance stays on one XCD
+    int blk = blockIdx.x;
+    if (perm_nb > 0) {
+        const int pos = blk / perm_n_inst, i = blk - pos * perm_n_inst;
+        blk = i * perm_nb + (perm_nb - 1 - pos);
+    }
+    const int wave_first = blk * (EVAL_WG / WAVE);
     int slot_lo = 0, n_stage = 0;
     const int inst0 = wave_inst[wave_first];                      // wave_first < n_waves by construction of the grid
     const InstDesc &D0 = desc[inst0];
@@ -1140,7 +1147,7 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
 }
 
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total, const int32_t *wave_inst,
-                    const int32_t *wave_base, int n_waves, EntryArrays e, CandArrays c, hipStream_t st)
+                    const int32_t *wave_base, int n_waves, int uniform_n_inst, EntryArrays e, CandArrays c, hipStream_t st)
 {
     if (n_waves <= 0) return 0;
     const int wpb = EVAL_WG / WAVE;
@@ -1150,8 +1157,11 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     if (lds_profiles > EVAL_LDS_PROFILES_MAX) lds_profiles = EVAL_LDS_PROFILES_MAX;
     const size_t lds = (per_prof + sizeof(LonInfo)) * (size_t)lds_profiles + sizeof(double) * 9 * (size_t)lds_knots;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
-    k_evaluate<<<(n_waves + wpb - 1) / wpb, EVAL_WG, lds, st>>>(P, sp, desc, state, lds_profiles, lds_knots,
-                                                                ablate, wave_inst,
+    static const int no_perm = getenv("FOT_EVAL_NOPERM") ? 1 : 0;
+    const int n_blocks = (n_waves + wpb - 1) / wpb;
+    const int perm_nb = uniform_n_inst > 1 && !no_perm && n_blocks % uniform_n_inst == 0 ? n_blocks / uniform_n_inst : 0;
+    k_evaluate<<<n_blocks, EVAL_WG, lds, st>>>(P, sp, desc, state, lds_profiles, lds_knots,
+                                                                ablate, uniform_n_inst, perm_nb, wave_inst,
                                                                 wave_base, n_waves, e.rng, e.e32, e.e64, e.sid,
                                                                 c.cost, c.v_last, c.travel, c.status, c.keep);
     FOT_LAUNCH_CHECK();
