@@ -460,6 +460,16 @@ struct StagedTab {
     }
 };
 
+#ifdef FOT_TIMELINE
+// diagnostic build (scripts/timeline.sh): per wave of the last k_evaluate launch -- workgroup start, wave start
+// (after the LDS prologue), wave end on the 100 MHz clock, and the chunks its strip ranges cover
+__device__ uint64_t g_timeline[4 * 16384];
+extern "C" int fot_timeline_read(uint64_t *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(uint64_t) * (size_t)n_words);
+}
+#endif
+
 __global__ void __launch_bounds__(EVAL_WG)
 k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
            const InstState *__restrict__ state, int lds_profiles,
@@ -475,6 +485,9 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     //     table in HBM): slot_lo is the profile of the block's first candidate; a block never spans two instances
     // uniform batches: workgroups in (position inside the instance, descending) x (instance) order -- the long
     // horizons and the brake ladder first, the short horizons in the last round; an instance stays on one XCD
+#ifdef FOT_TIMELINE
+    const uint64_t t_blk = __builtin_amdgcn_s_memrealtime();
+#endif
     int blk = blockIdx.x;
     if (perm_nb > 0) {
         const int pos = blk / perm_n_inst, i = blk - pos * perm_n_inst;
@@ -527,6 +540,12 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     // lane k holds the strip range of time step k (read back with v_readlane): loaded while every lane of the
     // wave is still active, padding lanes included
     const uint32_t my_rng = D.ent_cap != 0 && lane < n_total && !(ablate & 1) ? wave_rng[(int64_t)wave * n_total + lane] : 0u;
+#ifdef FOT_TIMELINE
+    const uint64_t t_wave = __builtin_amdgcn_s_memrealtime();
+    const int tl_wave = blockIdx.x * (EVAL_WG / WAVE) + (threadIdx.x / WAVE);          // in dispatch order
+    int tl_chunks = (int)(my_rng & 0xffffu) - (int)(my_rng >> 16);
+    for (int o = 32; o > 0; o >>= 1) tl_chunks += __shfl_xor(tl_chunks, o);
+#endif
     if (!live) {                                               // padding lane: never counted
         cand_status[slot] = 255;
         cand_keep[slot] = 0;
@@ -568,6 +587,13 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     cand_travel[slot] = r.travel;
     cand_status[slot] = (uint8_t)r.status;
     cand_keep[slot] = (uint8_t)r.keep;
+#ifdef FOT_TIMELINE
+    if (tl_wave < 16384 && lane == __ffsll((unsigned long long)__ballot(1)) - 1) {
+        g_timeline[tl_wave * 4 + 0] = t_blk; g_timeline[tl_wave * 4 + 1] = t_wave;
+        g_timeline[tl_wave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        g_timeline[tl_wave * 4 + 3] = (uint64_t)tl_chunks;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,89 @@
+"""Diagnostic: wave timeline of one k_evaluate launch on the bench workload (needs a -DFOT_TIMELINE build of libfot,
+see scripts/timeline.sh).  Prints slot utilisation, the concurrency curve and what list scheduling of the measured
+wave durations would give at workgroup and at wave granularity."""
+import ctypes as C
+import heapq
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import request_from_instance                                   # noqa: E402
+from integrated_path_planning_amd import _abi, synthetic as syn            # noqa: E402
+from integrated_path_planning_amd.batch import PackedBatch                 # noqa: E402
+from integrated_path_planning_amd.planner import BatchPlanner              # noqa: E402
+
+N_INST, WPB, SLOTS = 256, 4, 3072                       # 256 CUs x 4 SIMDs x 3 waves (VGPR-limited)
+
+
+def list_schedule(durations, slots):
+    ends = [0.0] * slots
+    heapq.heapify(ends)
+    last = 0.0
+    for d in durations:
+        e = heapq.heappop(ends) + d
+        last = max(last, e)
+        heapq.heappush(ends, e)
+    return last
+
+
+def main():
+    dev = torch.device("cuda:0")
+    reqs = [request_from_instance(syn.config3_instance(s)) for s in range(N_INST)]
+    pb = PackedBatch(reqs, obstacle_dtype=np.float32)
+    bp = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=0, **syn.CONFIG3_PLANNER)
+    dyn = torch.from_numpy(pb.dyn_xy).to(dev)
+    out = torch.zeros(N_INST * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    bs = pb.with_device_obstacles(None, dyn.data_ptr())
+    st = torch.cuda.current_stream(dev)
+    for _ in range(5):
+        bp.plan_packed_device(bs, out.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    L = _abi.lib()
+    if not hasattr(L, "fot_timeline_read"):
+        raise SystemExit("libfot was built without -DFOT_TIMELINE (scripts/timeline.sh)")
+    raw = np.zeros(4 * 16384, dtype=np.uint64)
+    L.fot_timeline_read.argtypes = [C.c_void_p, C.c_int]
+    assert L.fot_timeline_read(raw.ctypes.data, raw.size) == 0
+    t = raw.reshape(-1, 4).astype(np.int64)
+    n_waves = int(np.nonzero(t[:, 2])[0].max()) + 1
+    n_waves = (n_waves + WPB - 1) // WPB * WPB
+    t = t[:n_waves]
+    ok = t[:, 2] > 0
+    t0 = t[ok, 0].min()
+    tb, tw, te = [(t[:, i] - t0) / 100.0 for i in range(3)]                 # us
+    dur = np.where(ok, te - tw, 0.0)
+    prologue = float(np.median((tw - tb)[ok]))
+    span = float(te[ok].max())
+    print(f"waves {int(ok.sum())} (+{int((~ok).sum())} all-padding), kernel span {span:.1f} us, prologue {prologue:.1f} us")
+    print(f"wave duration: median {np.median(dur[ok]):.1f} p95 {np.percentile(dur[ok], 95):.1f} max {dur[ok].max():.1f} us")
+    work = float((te - tb)[ok].sum()) / SLOTS
+    print(f"sum of wave residency / {SLOTS} slots = {work:.1f} us -> slot utilisation {work / span:.2f}")
+    d4 = dur.reshape(-1, WPB)
+    full = ok.reshape(-1, WPB).all(1)
+    print(f"inside a workgroup: slowest wave {d4[full].max(1).mean():.1f} us, mean wave {d4[full].mean(1).mean():.1f} us")
+    ev = np.concatenate([np.stack([tb[ok], np.ones(ok.sum())], 1), np.stack([te[ok], -np.ones(ok.sum())], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    conc = np.cumsum(ev[:, 1])
+    marks = np.arange(0.0, span, 20.0)
+    print("resident waves at t [us]: " + "  ".join(f"{int(m)}:{int(conc[min(np.searchsorted(ev[:, 0], m), len(conc) - 1)])}" for m in marks))
+    wg = d4.max(1) + prologue
+    item = (dur + prologue)[ok]
+    print(f"list scheduling, workgroups in dispatch order: {list_schedule(wg, SLOTS // WPB):.1f} us; longest first: "
+          f"{list_schedule(np.sort(wg)[::-1], SLOTS // WPB):.1f} us")
+    print(f"list scheduling, single waves in dispatch order: {list_schedule(item, SLOTS):.1f} us; longest first: "
+          f"{list_schedule(np.sort(item)[::-1], SLOTS):.1f} us")
+    ch = t[:, 3][ok].astype(float)
+    A = np.stack([np.ones_like(ch), ch], 1)
+    coef = np.linalg.lstsq(A, dur[ok], rcond=None)[0]
+    r2 = 1 - ((dur[ok] - A @ coef) ** 2).sum() / ((dur[ok] - dur[ok].mean()) ** 2).sum()
+    print(f"duration ~ {coef[0]:.1f} + {coef[1]:.3f} x chunks in the wave's strip ranges (R^2 {r2:.2f})")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.save(os.path.join(ROOT, "gpurun_out", "timeline.npy"), t)
+
+
+if __name__ == "__main__":
+    main()
