@@ -41,8 +41,8 @@ F_ALG = 147.2e3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--instances-per-gpu", type=int, default=256)
     ap.add_argument("--overlap", type=int, default=2,
                     help="plan calls in flight: consecutive steps alternate between this many handles/streams, so the "
