@@ -452,11 +452,19 @@ struct StagedTab {
         asm volatile("" : "+v"(L.sd), "+v"(L.sdd), "+v"(L.rx), "+v"(L.ry), "+v"(L.cos_r), "+v"(L.sin_r),
                           "+v"(L.kr), "+v"(L.dkr), "+v"(L.inv_sd));
     }
+    // arc length s(t_k): asked for by the low-speed rules only (a few percent of the samples, but every eighth time
+    // step of a wave has such a lane) -- staged lanes re-read their profile's coefficients from the block's summaries
+    const LonInfo *info;                 // in LDS, nullptr: not staged
     __device__ __forceinline__ double s_at(int k) const
     {
-        ComputeTab direct;
-        direct.sp = sp; direct.L = profile_info(*Pp, *Dp, fr, slot, false); direct.dt = dt;
-        return direct.s_at(k);
+        double s_, u0, u1, u2;
+        if (info) {
+            lon_sample(*info, k, dt, s_, u0, u1, u2);
+        } else {
+            const LonInfo Ld = profile_info(*Pp, *Dp, fr, slot, false);
+            lon_sample(Ld, k, dt, s_, u0, u1, u2);
+        }
+        return s_;
     }
 };
 
@@ -556,6 +564,7 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     const LonInfo L = staged ? s_info[cd.lon_slot - slot_lo] : profile_info(P, D, S.frenet0, cd.lon_slot, true);
     StagedTab tab;
     tab.lds_row0 = staged ? (cd.lon_slot - slot_lo) * n_total * ROW_FIELDS : -1;
+    tab.info = staged ? s_info + (cd.lon_slot - slot_lo) : nullptr;
     tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.sp = sp; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
