@@ -454,8 +454,12 @@ FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSampl
             check_flag(c, dd > fmax(1.5 * d_s, 0.02), CK_CURV);                               // lateral slip
             const double sn = p.sin_t * c.prev.cos_t - p.cos_t * c.prev.sin_t;                // sin/cos of the yaw step
             const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
-            const double dyaw = fabs(atan2(sn, cs));
-            check_flag(c, dyaw > fmax(C.lim_curv * sqrt(step2), 0.1), CK_CURV);               // yaw-step cap
+            // yaw-step cap: the cap is at least 0.1 rad and |atan2(sn, cs)| <= |sn| / cs for cs > 0, so a step with
+            // |sn| <= 0.09 cs can never exceed it -- the arc tangent (and the square root) only for the others
+            if (!(cs > 0.0 && fabs(sn) <= 0.09 * cs)) {
+                const double dyaw = fabs(atan2(sn, cs));
+                check_flag(c, dyaw > fmax(C.lim_curv * sqrt(step2), 0.1), CK_CURV);
+            }
         }
         check_flag(c, p.v * p.v * fabs(p.kappa) > C.lim_lat, CK_LAT);                         // :975
         check_flag(c, has_d && fabs(p.d) > C.road_lim, CK_ROAD);                 // :982
