@@ -640,7 +640,10 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const DevParams &P = *Pp;
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
     const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
-    const int inst = blockIdx.x / groups, k0 = (blockIdx.x - inst * groups) * CULL_KG;
+    // workgroups go round-robin over the 8 XCDs: all groups of instance i run back to back on XCD i mod 8, so the
+    // 64-byte runs that neighbouring groups cut out of the same cache lines of the prediction tensor meet in one L2
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int inst = xcd + 8 * (seq / groups), k0 = (seq % groups) * CULL_KG;
     if (inst >= n_inst) return;
     const InstDesc &D = desc[inst];
     if (D.ent_cap == 0) return;
@@ -1167,7 +1170,7 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
                 hipStream_t st)
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
-    const unsigned grid = (unsigned)((int64_t)n_inst * ((n_total + CULL_KG - 1) / CULL_KG));
+    const unsigned grid = (unsigned)((int64_t)((n_inst + 7) / 8 * 8) * ((n_total + CULL_KG - 1) / CULL_KG));
     static const int ablate = getenv("FOT_CULL_ABLATE") ? atoi(getenv("FOT_CULL_ABLATE")) : 0;   // timing diagnostics
     const int lds_knots = sp.n <= 64 ? sp.n : 0;                           // a short spline rides along in LDS
     const size_t lds = sizeof(double) * 9 * (size_t)lds_knots;
