@@ -284,6 +284,14 @@ __device__ __forceinline__ void sload_chunk(f16 &dst, const f2x8 *src)
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(src), "n"(OFF) : "memory");
 }
 
+// the same, issued before anything that reads `ahead` afterwards: the compiler otherwise sinks the load below the
+// distance arithmetic of the chunk in use (which does not depend on it) and the wait then follows it at once
+template <int OFF>
+__device__ __forceinline__ void sload_chunk_ahead(f16 &dst, const f2x8 *src, float &ahead)
+{
+    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(dst), "+v"(ahead) : "s"(src), "n"(OFF) : "memory");
+}
+
 // waits for every outstanding scalar load; `c` is tied in so that its uses stay behind the wait
 __device__ __forceinline__ void swait_chunk(f16 &c)
 {
@@ -362,7 +370,7 @@ struct FusedSink {
     {
         if (n_chunks == 0) return;                                // wave-uniform
         if (!alive || hit) return;                                // lanes whose collision outcome is already settled
-        const float fx = (float)(px - oxd), fy = (float)(py - oyd);
+        float fx = (float)(px - oxd), fy = (float)(py - oyd);
         const float thr = filter_threshold(fc, fx, fy);
         const float thr_sure = any_fatal ? filter_threshold_sure(fc, fx, fy) : -1.0f;
         bool sure = false;                                        // some obstacle is certainly within its radius
@@ -380,12 +388,12 @@ struct FusedSink {
             sload_chunk<0>(ca, cp);
             swait_chunk(ca);
             for (int c = 0; c < nb; c += 2) {
-                sload_chunk<64>(cb, cp);
+                sload_chunk_ahead<64>(cb, cp, fx);
                 const float ma = min_sqdist32_f16(ca, fx, fy);
                 near_bits = (near_bits << 1) | (uint32_t)(ma <= thr);
                 sure |= ma <= thr_sure;
                 swait_chunk(cb);
-                sload_chunk<128>(ca, cp);
+                sload_chunk_ahead<128>(ca, cp, fx);
                 const float mb = min_sqdist32_f16(cb, fx, fy);
                 near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
                 sure |= mb <= thr_sure;
