@@ -576,6 +576,9 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.sp = sp; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+    // q[0..2] are the instance's lateral state (wave-uniform): as scalar values they end up in spilled SGPRs and come
+    // back through v_readlane in every time step -- three vector registers are cheaper
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
 
     FusedSink sink;
     sink.Pp = Pp; sink.Dp = &D;
