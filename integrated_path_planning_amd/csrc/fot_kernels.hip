@@ -442,7 +442,7 @@ struct StagedTab {
     const DevParams *Pp;                 //   spot, from the instance's state (nothing of it stays in registers
     const InstDesc *Dp;                  //   across the loop)
     const double *fr;
-    SplineView sp;
+    const SplineView *spp;               // the kernel's own argument block: nine pointers that only the fall-back reads
     double dt;
     __device__ __forceinline__ void load(int k, LonSample &L) const
     {
@@ -452,7 +452,7 @@ struct StagedTab {
             L.cos_r = r[4]; L.sin_r = r[5]; L.kr = r[6]; L.dkr = r[7]; L.inv_sd = r[8];
         } else {
             ComputeTab direct;
-            direct.sp = sp; direct.L = profile_info(*Pp, *Dp, fr, slot, false); direct.dt = dt;
+            direct.sp = *spp; direct.L = profile_info(*Pp, *Dp, fr, slot, false); direct.dt = dt;
             direct.load(k, L);
         }
         // the row is in registers from here on: what follows (the sink's scalar warm-up loads) must not sit
@@ -573,7 +573,10 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     StagedTab tab;
     tab.lds_row0 = staged ? (cd.lon_slot - slot_lo) * n_total * ROW_FIELDS : -1;
     tab.info = staged ? s_info + (cd.lon_slot - slot_lo) : nullptr;
-    tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.sp = sp; tab.dt = P.dt;
+    tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.dt = P.dt;
+    // SplineView is the second kernel argument (offset 8): read back from the argument segment where it is needed
+    // instead of holding its 18 scalar registers across the loop
+    tab.spp = (const SplineView *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const DevParams *));
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
     // q[0..2] are the instance's lateral state (wave-uniform): as scalar values they end up in spilled SGPRs and come
