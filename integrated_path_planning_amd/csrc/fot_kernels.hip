@@ -324,13 +324,26 @@ __device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float 
 // come within the conservative threshold are re-checked in float64, so the decision is the reference's.
 // Scalar registers are the scarce resource of k_evaluate (two 16-register chunk buffers): the sink keeps only
 // what the per-chunk loop needs, the exact re-check fetches its constants where it runs.
+// Layout of k_evaluate's argument segment (its parameter list, in order).  What only rare branches or the epilogue
+// read -- the spline view, the float64 / sample-id entry arrays, the output arrays -- is fetched from the segment at
+// the point of use instead of occupying scalar registers across the time-step loop.
+struct EvalKernArgs {
+    const DevParams *Pp; SplineView sp; const InstDesc *desc; const InstState *state;
+    int lds_profiles, lds_knots, ablate, perm_n_inst, perm_nb;
+    const int32_t *wave_inst, *wave_base; int n_waves;
+    const uint32_t *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
+    double *cand_cost, *cand_vlast, *cand_travel; uint8_t *cand_status, *cand_keep;
+};
+__device__ __forceinline__ const EvalKernArgs &eval_kernargs()
+{
+    return *(const EvalKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
 struct FusedSink {
     const DevParams *Pp;
     const InstDesc *Dp;
     uint32_t my_rng;                     // lane k: strip range of time step k of this wave (0: nothing to test)
     const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
-    const d2 *e64;
-    const uint8_t *sid;
     int chunks_per_k;                    // ent_cap / 8
     double oxd, oyd;
     FilterConst fc;
@@ -413,6 +426,9 @@ struct FusedSink {
         const DevParams &P = *Pp;
         const InstDesc &D = *Dp;
         const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+        const EvalKernArgs &KA = eval_kernargs();
+        const d2 *e64 = KA.ent64 + D.ent_off;
+        const uint8_t *sid = KA.ent_sid + D.ent_off;
         const int64_t base = ((int64_t)k * chunks_per_k + c_lo) * ENT_CHUNK;
         while (near_bits != 0 && !hit) {
             const int hb = 31 - __clz((int)near_bits);             // highest bit = earliest chunk
@@ -574,9 +590,7 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     tab.lds_row0 = staged ? (cd.lon_slot - slot_lo) * n_total * ROW_FIELDS : -1;
     tab.info = staged ? s_info + (cd.lon_slot - slot_lo) : nullptr;
     tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.dt = P.dt;
-    // SplineView is the second kernel argument (offset 8): read back from the argument segment where it is needed
-    // instead of holding its 18 scalar registers across the loop
-    tab.spp = (const SplineView *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const DevParams *));
+    tab.spp = &eval_kernargs().sp;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
     // q[0..2] are the instance's lateral state (wave-uniform): as scalar values they end up in spilled SGPRs and come
@@ -587,8 +601,6 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     sink.Pp = Pp; sink.Dp = &D;
     sink.my_rng = my_rng;
     sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
-    sink.e64 = ent64 + D.ent_off;
-    sink.sid = ent_sid + D.ent_off;
     sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
     sink.oxd = D.ego.x; sink.oyd = D.ego.y;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
@@ -605,11 +617,12 @@ k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__re
     asm volatile("" : "+s"(lc.n_circ_fp));
     CandResult r;
     evaluate_candidate(P, D, lc, L, tab, q, n_total, sink, r);
-    cand_cost[slot] = r.cost;
-    cand_vlast[slot] = r.v_last;
-    cand_travel[slot] = r.travel;
-    cand_status[slot] = (uint8_t)r.status;
-    cand_keep[slot] = (uint8_t)r.keep;
+    const EvalKernArgs &KA = eval_kernargs();
+    KA.cand_cost[slot] = r.cost;
+    KA.cand_vlast[slot] = r.v_last;
+    KA.cand_travel[slot] = r.travel;
+    KA.cand_status[slot] = (uint8_t)r.status;
+    KA.cand_keep[slot] = (uint8_t)r.keep;
 #ifdef FOT_TIMELINE
     if (tl_wave < 16384 && lane == __ffsll((unsigned long long)__ballot(1)) - 1) {
         g_timeline[tl_wave * 4 + 0] = t_blk; g_timeline[tl_wave * 4 + 1] = t_wave;
