@@ -324,7 +324,7 @@ __device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float 
 // come within the conservative threshold are re-checked in float64, so the decision is the reference's.
 // Scalar registers are the scarce resource of k_evaluate (two 16-register chunk buffers): the sink keeps only
 // what the per-chunk loop needs, the exact re-check fetches its constants where it runs.
-// Layout of k_evaluate's argument segment (its parameter list, in order).  What only rare branches or the epilogue
+// k_evaluate's only parameter, i.e. the layout of its argument segment.  What only rare branches or the epilogue
 // read -- the spline view, the float64 / sample-id entry arrays, the output arrays -- is fetched from the segment at
 // the point of use instead of occupying scalar registers across the time-step loop.
 struct EvalKernArgs {
@@ -502,15 +502,20 @@ extern "C" int fot_timeline_read(uint64_t *out, int n_words)
 }
 #endif
 
-__global__ void __launch_bounds__(EVAL_WG)
-k_evaluate(const DevParams *__restrict__ Pp, SplineView sp, const InstDesc *__restrict__ desc,
-           const InstState *__restrict__ state, int lds_profiles,
-           int lds_knots, int ablate, int perm_n_inst, int perm_nb, const int32_t *__restrict__ wave_inst, const int32_t *__restrict__ wave_base, int n_waves,
-           const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const d2 *__restrict__ ent64,
-           const uint8_t *__restrict__ ent_sid,
-           double *__restrict__ cand_cost, double *__restrict__ cand_vlast, double *__restrict__ cand_travel,
-           uint8_t *__restrict__ cand_status, uint8_t *__restrict__ cand_keep)
+__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_evaluate(const EvalKernArgs a)
 {
+    // (the struct is the whole argument segment, so eval_kernargs() addresses exactly these fields)
+    const DevParams *__restrict__ Pp = a.Pp;
+    const SplineView sp = a.sp;
+    const InstDesc *__restrict__ desc = a.desc;
+    const InstState *__restrict__ state = a.state;
+    const int lds_profiles = a.lds_profiles, lds_knots = a.lds_knots, ablate = a.ablate;
+    const int perm_n_inst = a.perm_n_inst, perm_nb = a.perm_nb, n_waves = a.n_waves;
+    const int32_t *__restrict__ wave_inst = a.wave_inst, *__restrict__ wave_base = a.wave_base;
+    const uint32_t *__restrict__ wave_rng = a.wave_rng;
+    const f2 *__restrict__ ent32 = a.ent32;
+    uint8_t *__restrict__ cand_status = a.cand_status, *__restrict__ cand_keep = a.cand_keep;
     const DevParams &P = *Pp;
     const int n_total = P.n_total;
     // --- the rows of the profiles [slot_lo, slot_lo + n_stage) of the block's instance, built straight into LDS (no
@@ -1225,10 +1230,14 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     static const int no_perm = getenv("FOT_EVAL_NOPERM") ? 1 : 0;
     const int n_blocks = (n_waves + wpb - 1) / wpb;
     const int perm_nb = uniform_n_inst > 1 && !no_perm && n_blocks % uniform_n_inst == 0 ? n_blocks / uniform_n_inst : 0;
-    k_evaluate<<<n_blocks, EVAL_WG, lds, st>>>(P, sp, desc, state, lds_profiles, lds_knots,
-                                                                ablate, uniform_n_inst, perm_nb, wave_inst,
-                                                                wave_base, n_waves, e.rng, e.e32, e.e64, e.sid,
-                                                                c.cost, c.v_last, c.travel, c.status, c.keep);
+    EvalKernArgs a;
+    a.Pp = P; a.sp = sp; a.desc = desc; a.state = state;
+    a.lds_profiles = lds_profiles; a.lds_knots = lds_knots; a.ablate = ablate;
+    a.perm_n_inst = uniform_n_inst; a.perm_nb = perm_nb;
+    a.wave_inst = wave_inst; a.wave_base = wave_base; a.n_waves = n_waves;
+    a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
+    a.cand_cost = c.cost; a.cand_vlast = c.v_last; a.cand_travel = c.travel; a.cand_status = c.status; a.cand_keep = c.keep;
+    k_evaluate<<<n_blocks, EVAL_WG, lds, st>>>(a);
     FOT_LAUNCH_CHECK();
     return 0;
 }
