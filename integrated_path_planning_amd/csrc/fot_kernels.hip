@@ -692,7 +692,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     // wave wv: box of time step k0 + wv over all longitudinal profiles of the instance
     {
         Box32 bw = box_empty();
-        if (wv < nk)
+        if (wv < nk && !(ablate & 8))
             for (int w = lane; w < n_prof; w += WAVE) {
                 const Box32 o = profile_box_at(P, D, S, sp, w, k0 + wv);
                 if (w < CULL_PBOX) s_pbox[wv][w] = o;               // read again below, per candidate wave
