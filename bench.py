@@ -6,20 +6,42 @@
 A "step" is one pass of the hot path (obstacle preparation -> Frenet state ->
 lattice -> Frenet->Cartesian + checks -> collision -> argmin -> selected paths)
 over one batch of synthetic instances whose obstacle tensors are already
-resident in HBM.  Workload per GPU = BASELINE.json config 4: 256 independent ego
-instances, each a 2240-candidate lattice (5 s horizon, dt = 0.1 s) checked
-against a 20-sample x 30-pedestrian x 51-step prediction distribution (fp32).
-For N > 1 every rank plans its own 256 instances (weak scaling) and the selected
-path records are all-gathered with RCCL inside the step.
+resident in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the extra
-objects "roofline" (dominant kernel, measured with HIP events on its stream
-inside the timed region) and "cpu_baseline" (the CPU oracle on this host).
+Workload
+  N = 1 : BASELINE.json config 4 -- 256 independent ego instances per batch,
+          each a 2240-candidate lattice (5 s horizon, dt = 0.1 s) checked
+          against a 20-sample x 30-pedestrian x 51-step prediction distribution
+          (fp32), eps = 0.
+  N > 1 : BASELINE.json config 5 -- 512 instances per GPU (4096 over 8 GPUs,
+          contiguous shards), selected-path records all-gathered with RCCL
+          inside the step (weak scaling).  `--instances-per-gpu` overrides.
+  The timed loop rotates `--batches` (default 8) DISTINCT batches, i.e. more
+  than 256 MiB of obstacle tensors, so that no step finds its inputs in the
+  Infinity Cache.
+
+`--gpus N` without WORLD_SIZE in the environment starts the N ranks itself
+(child `torch.distributed.run`, before this process touches the GPU); under
+`torch.distributed.run` it is a plain rank.
+
+Two timed legs of exactly K steps each (barrier + synchronize on both sides):
+the SERIAL leg (one plan call in flight) yields `serial`, `kernel_ms` and the
+`roofline` of the dominant kernel -- a launch has the GPU to itself there, so
+kernel_ms[dominant] <= serial.ms_per_step -- and the HEADLINE leg (`--overlap`
+plan calls in flight, default 2: how a server keeps batches in flight) yields
+`value` / `ms_per_step`.  `--overlap 1` runs the serial leg only.
+
+Prints ONE JSON line on rank 0 with the extra objects "roofline" (dominant
+kernel, HIP events on its stream inside the timed serial leg), "roofline_issue"
+(VALU issue bound from the committed PMC profile) and "cpu_baseline" (the CPU
+oracle on this host).
 """
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,15 +49,43 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                 # MI355X peak engine clock
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, MI355X_MICROARCH.md "HBM3E peak BW"
-VALU_FP64_PEAK_TF = 78.6       # fp64 vector peak = half the 157.3 TF fp32 vector peak
-# algorithmic HBM bytes and nominal flops per candidate of config 3/4/5
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, MI355X_MICROARCH.md "8 TB/s peak (spec)"
+# algorithmic HBM bytes per candidate of config 3/4/5
 B_ALG = 119.0
-F_ALG = 147.2e3
+KERNEL_SOURCES = ("fot_kernels.hip", "fot_math.hpp", "fot_types.h", "fot_setup.hpp")
+
+
+def kernel_source_hash():
+    """Identifies the kernel sources a committed PMC profile was taken on (scripts/pmc_summary.py stores the same)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "integrated_path_planning_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def usable_cores():
+    """Cores this process may actually keep busy: the affinity mask, capped by the cgroup CPU quota (a container that
+    sees 256 logical cores but is throttled to a 16-core share gains nothing from 256 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def parse_args():
@@ -43,33 +93,119 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--instances-per-gpu", type=int, default=256)
+    ap.add_argument("--instances-per-gpu", type=int, default=0,
+                    help="0 = 256 at --gpus 1 (config 4), 512 at --gpus > 1 (config 5's shard)")
+    ap.add_argument("--batches", type=int, default=8, help="distinct batches rotated through the timed loop")
     ap.add_argument("--overlap", type=int, default=2,
-                    help="plan calls in flight: consecutive steps alternate between this many handles/streams, so the "
-                         "launch gaps and the draining tail of one step are filled by the next (1 = strictly serial)")
+                    help="plan calls in flight in the headline leg: consecutive steps alternate between this many "
+                         "handles/streams (1 = strictly serial, one leg only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="timing diagnostics only (FOT_EVAL_ABLATE / FOT_CULL_ABLATE builds give wrong results)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="timing diagnostics only (FOT_EVAL_ABLATE / FOT_CULL_ABLATE builds give wrong results)")
     ap.add_argument("--cpu-instances", type=int, default=256,
-                    help="instances of the same workload timed on the CPU oracle (~53 ms each)")
+                    help="instances of the same workload timed on the single-thread CPU oracle (~53 ms each)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks as CHILD processes (this process has not
+    touched the GPU and never will) and pass their output and exit code through."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Leg:
+    """One timed configuration of the step loop: `n_ov` handles on `n_ov` streams, batches rotated."""
+
+    def __init__(self, n_ov, make_planner, dev, batches, out_bytes, pg, rehearse):
+        import torch
+        self.torch, self.dev, self.n_ov, self.pg, self.rehearse = torch, dev, n_ov, pg, rehearse
+        self.planners = [make_planner() for _ in range(n_ov)]
+        cur = torch.cuda.current_stream(dev)
+        self.streams = [cur] + [torch.cuda.Stream(device=dev) for _ in range(n_ov - 1)]
+        self.outs = [torch.zeros(out_bytes, dtype=torch.uint8, device=dev) for _ in range(n_ov)]
+        self.batches = batches
+        self.count = 0
+
+    def step(self):
+        torch = self.torch
+        i = self.count
+        self.count += 1
+        b = i % self.n_ov
+        bstruct = self.batches[i % len(self.batches)]
+        with torch.cuda.stream(self.streams[b]):
+            if self.pg is None:
+                self.planners[b].plan_packed_device(bstruct, self.outs[b].data_ptr(), self.streams[b].cuda_stream)
+                return
+            j, out, _ = self.pg.slot()                          # free again: the gather that last read it is done
+            if self.rehearse:
+                self.planners[b].plan_packed_device(bstruct, self.outs[b].data_ptr(), self.streams[b].cuda_stream)
+                out.copy_(self.outs[b])                         # (synchronous D2H: rehearsal only)
+            else:
+                self.planners[b].plan_packed_device(bstruct, out.data_ptr(), self.streams[b].cuda_stream)
+            self.pg.launch(j)
+
+    def fence(self):
+        import torch.distributed as dist
+        if self.pg is not None:
+            self.pg.drain()                                     # every gather of the timed steps is inside the region
+            dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def run(self, warmup, steps, profile):
+        """W untimed + exactly K timed steps; returns (seconds, per-kernel HIP-event totals)."""
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        if profile:
+            for p_ in self.planners:
+                p_.profile(True)
+                p_.profile_read(reset=True)
+        first = self.count
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        prof = {}
+        if profile:
+            for p_ in self.planners:
+                for k_, v_ in p_.profile_read(reset=True).items():
+                    a_ = prof.setdefault(k_, {"launches": 0, "total_ms": 0.0})
+                    a_["launches"] += v_["launches"]; a_["total_ms"] += v_["total_ms"]
+                p_.profile(False)
+        return elapsed, prof, first
+
+    def close(self):
+        for p_ in self.planners:
+            p_.close()
 
 
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(self_launch(args))                             # nothing above has touched the GPU
+
     import torch
     import torch.distributed as dist
     from integrated_path_planning_amd import _abi, synthetic as syn
-    from integrated_path_planning_amd.batch import PackedBatch
+    from integrated_path_planning_amd.batch import PackedBatch, PlanRequest, request_from_instance
+    from integrated_path_planning_amd.distributed import PipelinedAllGather
     from integrated_path_planning_amd.planner import BatchPlanner
-    from helpers import request_from_instance
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     # FOT_BENCH_REHEARSE=1: dry run of the N > 1 control flow on a box with ONE GPU -- every rank on cuda:0, records
     # gathered through host memory with "gloo".  Not a measurement (the line says so), never used by the driver.
     rehearse = os.environ.get("FOT_BENCH_REHEARSE") == "1" and world > 1
@@ -81,175 +217,186 @@ def main():
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
 
-    n_inst = args.instances_per_gpu
-    seeds = range(rank * n_inst, (rank + 1) * n_inst)
+    n_inst = args.instances_per_gpu or (256 if world == 1 else 512)
+    n_rot = max(1, args.batches)
     kw = syn.CONFIG3_PLANNER
-    reqs = [request_from_instance(syn.config3_instance(s)) for s in seeds]
-    pb = PackedBatch(reqs, obstacle_dtype=np.float32)
-    bp = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **kw)
+    wp = (syn.STRAIGHT_WX, syn.STRAIGHT_WY)
+    # batch b of the rotation = seeds [b * world * n_inst, (b+1) * world * n_inst), contiguous shards over the ranks:
+    # batch 0 is config 4 (seeds 0..255) at N = 1 and config 5 (seeds 0..4095, 512 per rank) at N = 8
+    reqs_rot, packed, dyn_dev, bstructs = [], [], [], []
+    for b in range(n_rot):
+        s0 = b * world * n_inst + rank * n_inst
+        reqs = [request_from_instance(syn.config3_instance(s)) for s in range(s0, s0 + n_inst)]
+        pb = PackedBatch(reqs, obstacle_dtype=np.float32)
+        d = torch.from_numpy(pb.dyn_xy).to(dev)                 # obstacle tensors resident in HBM
+        reqs_rot.append(reqs); packed.append(pb); dyn_dev.append(d)
+        bstructs.append(pb.with_device_obstacles(None, d.data_ptr()))
+    obstacle_mb = sum(p.dyn_xy.nbytes for p in packed) / 1e6
+    out_bytes = n_inst * _abi.RESULT_BYTES
 
-    # obstacle tensors + result records resident in HBM (torch = device memory + streams only)
-    dyn_dev = torch.from_numpy(pb.dyn_xy).to(dev)
-    static_dev = torch.from_numpy(pb.static_xy).to(dev) if pb.static_xy.size else None
-    out_dev = torch.zeros(n_inst * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
-    # N > 1: the selected-path records of every rank are all-gathered (RCCL over xGMI) in every step; the gather of step i
-    # runs on the collective's stream while step i+1 plans into the other buffer pair (distributed.PipelinedAllGather)
-    from integrated_path_planning_amd.distributed import PipelinedAllGather
-    pg = PipelinedAllGather(n_inst * _abi.RESULT_BYTES, world, torch.device("cpu") if rehearse else dev,
-                            depth=max(2, min(args.overlap, 4))) if world > 1 else None     # slot j <-> stream j
-    bstruct = pb.with_device_obstacles(static_dev.data_ptr() if static_dev is not None else None, dyn_dev.data_ptr())
-    stream = torch.cuda.current_stream(dev)
-    # steps are independent plan calls: by default they alternate between two handles (each with its own
-    # workspace) on two streams, the way a server keeps batches in flight (--overlap 3 is faster still, but then two
-    # launches of the dominant kernel share the GPU and its per-launch time no longer says anything about the kernel)
+    def make_planner():
+        return BatchPlanner(waypoints=wp, device=local_rank, **kw)
+
+    def make_pg(depth):
+        # N > 1: the selected-path records of every rank are all-gathered (RCCL over xGMI) in every step; the gather of
+        # step i runs on the collective's stream while step i+1 plans into the other buffer pair
+        return PipelinedAllGather(out_bytes, world, torch.device("cpu") if rehearse else dev,
+                                  depth=depth) if world > 1 else None
+
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- serial leg: one plan call in flight; per-kernel HIP events -> kernel_ms, roofline
     n_ov = max(1, min(args.overlap, 4))
-    planners = [bp] + [BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **kw)
-                       for _ in range(n_ov - 1)]
-    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_ov - 1)]
-    outs = [out_dev] + [torch.zeros_like(out_dev) for _ in range(n_ov - 1)]
-    counter = [0]
+    pg1 = make_pg(2)
+    leg1 = Leg(1, make_planner, dev, bstructs, out_bytes, pg1, rehearse)
+    el1, prof, first1 = leg1.run(args.warmup, args.steps, profile=True)
+    el1 = reduce_max(el1)
+    # ---- headline leg
+    if n_ov > 1:
+        pg = make_pg(max(2, n_ov))
+        leg = Leg(n_ov, make_planner, dev, bstructs, out_bytes, pg, rehearse)
+        elapsed, _, first = leg.run(args.warmup, args.steps, profile=False)
+        elapsed = reduce_max(elapsed)
+    else:
+        pg, leg, elapsed, first = pg1, leg1, el1, first1
 
-    def step():
-        b = counter[0] % n_ov
-        counter[0] += 1
-        with torch.cuda.stream(streams[b]):
-            if pg is None:
-                planners[b].plan_packed_device(bstruct, outs[b].data_ptr(), streams[b].cuda_stream)
-                return
-            j, out, _ = pg.slot()                               # free again: the gather that last read it is done
-            if rehearse:
-                planners[b].plan_packed_device(bstruct, outs[b].data_ptr(), streams[b].cuda_stream)
-                out.copy_(outs[b])                              # (synchronous D2H: rehearsal only)
-            else:
-                planners[b].plan_packed_device(bstruct, out.data_ptr(), streams[b].cuda_stream)
-            pg.launch(j)
-
-    def fence():
-        if pg is not None:
-            pg.drain()                                          # every gather of the timed steps is inside the region
-            dist.barrier()
+    # ---- candidates actually generated: one untimed pass per rotation batch, counted from its result records
+    bp = leg1.planners[0]
+    stream = torch.cuda.current_stream(dev)
+    chk = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+    cand_batch, recs0 = [], None
+    for b in range(n_rot):
+        bp.plan_packed_device(bstructs[b], chk.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize(dev)
+        rh = chk.cpu().numpy()
+        recs = (_abi.Result * n_inst).from_buffer_copy(rh.tobytes())
+        cand_batch.append(sum(int(r.n_cand) for r in recs))
+        if b == 0:
+            recs0, recs0_host = recs, rh.copy()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    for p_ in planners:
-        p_.profile(True)
-        p_.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = {}
-    for p_ in planners:                                         # per-kernel HIP-event totals over all handles
-        for k_, v_ in p_.profile_read(reset=True).items():
-            a_ = prof.setdefault(k_, {"launches": 0, "total_ms": 0.0})
-            a_["launches"] += v_["launches"]; a_["total_ms"] += v_["total_ms"]
-        p_.profile(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def cand_of_leg(first_step):
+        tot = torch.tensor([sum(cand_batch[(first_step + i) % n_rot] for i in range(args.steps))], dtype=torch.int64,
+                           device="cpu" if rehearse else dev)
+        if world > 1:
+            dist.all_reduce(tot)
+        return int(tot.item())
 
-    # candidates actually generated (from the result records)
-    gathered = None
-    if pg is not None:
-        gathered = pg.drain()
-        out_dev = pg.send[(pg.step - 1) % pg.depth]
-    recs_host = out_dev.cpu().numpy()
-    recs = (_abi.Result * n_inst).from_buffer_copy(recs_host.tobytes())
-    cand_local = sum(int(r.n_cand) for r in recs)
-    cand_total = torch.tensor([cand_local], dtype=torch.int64, device="cpu" if rehearse else dev)
-    if world > 1:
-        dist.all_reduce(cand_total)
-    cand_total = int(cand_total.item())
-    value = cand_total * args.steps / elapsed
+    cand_total = cand_of_leg(first)
+    cand_serial = cand_of_leg(first1)
+    value = cand_total / elapsed
 
     gathered_ok = None
     if world > 1:
-        # every rank's slice of the gathered tensor must hold that rank's records
-        g = gathered.cpu().numpy()
+        # one more gathered step on batch 0: every rank's slice of the gathered tensor must hold that rank's records
+        j, out, recv = pg.slot()
+        if rehearse:
+            bp.plan_packed_device(bstructs[0], chk.data_ptr(), stream.cuda_stream)
+            out.copy_(chk)
+        else:
+            bp.plan_packed_device(bstructs[0], out.data_ptr(), stream.cuda_stream)
+        pg.launch(j)
+        g = pg.drain().cpu().numpy()
+        torch.cuda.synchronize(dev)
         rb = _abi.RESULT_BYTES
         mine = g[rank * n_inst * rb:(rank + 1) * n_inst * rb]
         allrec = (_abi.Result * (world * n_inst)).from_buffer_copy(g.tobytes())
-        gathered_ok = bool(np.array_equal(mine, recs_host) and all(r.n_cand > 0 for r in allrec))
+        gathered_ok = bool(np.array_equal(mine, recs0_host) and all(r.n_cand > 0 for r in allrec))
+        ok_t = torch.tensor([1 if gathered_ok else 0], dtype=torch.int64, device="cpu" if rehearse else dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        gathered_ok = bool(ok_t.item())
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (HIP events on its stream, inside the timed region)
+    # ---- roofline of the dominant kernel (HIP events on its stream, inside the timed serial leg)
     dom = max(prof, key=lambda k: prof[k]["total_ms"])
     dom_ms = prof[dom]["total_ms"] / max(prof[dom]["launches"], 1)
-    # candidates of one launch: a step splits the batch over the handle's lanes (one launch of each kernel per lane)
     launches_per_step = max(prof[dom]["launches"] / max(args.steps, 1), 1.0)
-    cand_launch = cand_local / launches_per_step
+    cand_launch = cand_batch[0] / launches_per_step
     alg_bytes = B_ALG * cand_launch
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as the
-    # gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); null when no profile is committed for it
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    src_hash = kernel_source_hash()
+
+    def committed(name):
+        """(per-kernel dict of a committed rocprofv3 --pmc summary, taken on these very kernel sources?)"""
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_gfx950_corrected")
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
-            traffic = None
+            return None, False
+        return d, d.get("_meta", {}).get("source_hash") == src_hash
+
+    traffic_d, traffic_fresh = committed("traffic.json")
+    traffic = (traffic_d or {}).get(dom, {}).get("hbm_bytes_gfx950_corrected") if traffic_fresh else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
                 "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                "candidates_per_launch": cand_launch, "launches_per_step": launches_per_step}
+                "candidates_per_launch": cand_launch, "launches_per_step": launches_per_step,
+                "measured_in": "serial leg (one plan call in flight)",
+                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources)"
+                                   if traffic is not None else
+                                   "null: profiles/traffic.json was taken on other kernel sources (hash mismatch)"
+                                   if traffic_d else "null: no committed profile"),
+                "note": "the path is not HBM-bound (SURVEY 8(d)); the binding resource is VALU issue, see roofline_issue"}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    valu = {"kernel": dom, "bound": "valu_fp64", "achieved": F_ALG * cand_launch / (dom_ms * 1e-3) / 1e12,
-            "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s",
-            "note": "nominal brute-force flops of SURVEY 8(d) (every candidate sample x every obstacle point); the "
-                    "broad phase skips ~96% of those pair tests, so this can exceed the peak"}
-    valu["frac"] = valu["achieved"] / valu["peak"]
-    # what the kernel actually issues (rocprofv3 --pmc SQ_INSTS_VALU of the same command, profiles/): the time its vector
-    # instructions alone would take at one wave64 instruction per 4 cycles per SIMD, against the measured launch time
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))[dom]     # copy of the latest <tag>_pmc.json
-        n_valu = float(pmc["SQ_INSTS_VALU"])
+    if traffic is not None:
+        roofline["achieved_from_traffic"] = traffic / (dom_ms * 1e-3) / 1e9
+    # what the kernel actually issues (rocprofv3 --pmc SQ_INSTS_VALU, profiles/): the time its vector instructions
+    # alone would take at one wave64 instruction per 4 cycles per SIMD, against the measured launch time
+    issue = None
+    pmc_d, pmc_fresh = committed("pmc.json")
+    if pmc_d and dom in pmc_d and "SQ_INSTS_VALU" in pmc_d[dom]:
+        n_valu = float(pmc_d[dom]["SQ_INSTS_VALU"])
         issue_ms = n_valu * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
-        valu["issue_bound"] = {"source": "profiles/pmc.json", "valu_instructions_per_launch": n_valu,
-                               "cycles_per_instruction": 4, "simds": N_SIMD, "clock_ghz": CLOCK_HZ / 1e9,
-                               "bound_ms": issue_ms, "frac": issue_ms / dom_ms,
-                               "note": "valid for the default workload (256 instances per launch), which the profile ran"}
-    except Exception:
-        pass
+        issue = {"kernel": dom, "bound": "valu_issue", "unit": "ms", "achieved": issue_ms, "peak": dom_ms,
+                 "frac": issue_ms / dom_ms, "valu_instructions_per_launch": n_valu, "cycles_per_instruction": 4,
+                 "simds": N_SIMD, "clock_ghz": CLOCK_HZ / 1e9,
+                 "source": "profiles/pmc.json" + (" (%s)" % pmc_d.get("_meta", {}).get("tag", "?")),
+                 "source_matches_build": pmc_fresh,
+                 "note": "executed VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over the measured launch "
+                         "time of the serial leg; valid for %d instances per launch" %
+                         int(pmc_d.get("_meta", {}).get("instances_per_launch", 256))}
     kernels = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items() if v["launches"]}
 
     # ---- parity spot check against the oracle (checker only, outside the timed region)
     from oracle import oracle as orc
-    from helpers import assert_record_matches_oracle, oracle_plan_for_request
+    from oracle.check import assert_record_matches_oracle, oracle_plan_for_request
     oparams = orc.make_params(**kw)
     osp = orc.Spline(syn.STRAIGHT_WX, syn.STRAIGHT_WY)
     n_check = 0 if args.no_parity else min(4, n_inst)
     for i in range(n_check):
-        assert_record_matches_oracle(recs[i], oracle_plan_for_request(orc, oparams, osp, reqs[i]), label=f"inst {i}")
+        assert_record_matches_oracle(recs0[i], oracle_plan_for_request(orc, oparams, osp, reqs_rot[0][i]),
+                                     label=f"inst {i}")
 
-    # ---- CPU baseline: the oracle (a C port of the reference algorithm), single thread, bounded sample
+    # ---- CPU baseline: the oracle (a C port of the reference algorithm), bounded samples of the same workload
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         n_cpu = min(args.cpu_instances, n_inst)
         t1 = time.perf_counter()
         n_c = 0
         for i in range(n_cpu):
-            n_c += oracle_plan_for_request(orc, oparams, osp, reqs[i]).n_cand
+            n_c += oracle_plan_for_request(orc, oparams, osp, reqs_rot[0][i]).n_cand
         dt_cpu = time.perf_counter() - t1
+        n_logical = os.cpu_count() or 1
+        n_avail = usable_cores()
         cpu = {"value": n_c / dt_cpu, "unit": "candidates/s", "cores": 1, "kind": "port",
-               "sample": f"first {n_cpu} instances of the same batch, oracle/fot_oracle.c single thread, "
-                         f"{dt_cpu:.1f} s; host has {os.cpu_count()} logical cores"}
-        # the same port on the box's CPU share: one instance per task, threads (the C call releases the GIL)
+               "sample": f"first {n_cpu} instances of batch 0, oracle/fot_oracle.c single thread, {dt_cpu:.1f} s; "
+                         f"host: nproc {n_logical}, {n_avail} usable by this process (affinity and cgroup quota)"}
+        # the same port on every core this process may use: one instance per task (the C call releases the GIL)
         from concurrent.futures import ThreadPoolExecutor
-        n_thr = min(16, os.cpu_count() or 1)
+        pool_reqs = [r for rq in reqs_rot for r in rq][:max(n_cpu, min(2048, 8 * n_avail))]
         t1 = time.perf_counter()
-        with ThreadPoolExecutor(n_thr) as ex:
-            n_mt = sum(ex.map(lambda rq: oracle_plan_for_request(orc, oparams, osp, rq).n_cand, reqs[:n_cpu]))
+        with ThreadPoolExecutor(n_avail) as ex:
+            n_mt = sum(ex.map(lambda rq: oracle_plan_for_request(orc, oparams, osp, rq).n_cand, pool_reqs))
         dt_mt = time.perf_counter() - t1
-        cpu["threads"] = {"value": n_mt / dt_mt, "cores": n_thr, "seconds": dt_mt}
+        cpu["threads"] = {"value": n_mt / dt_mt, "cores": n_avail, "nproc": n_logical, "seconds": dt_mt,
+                          "sample": f"{len(pool_reqs)} instances of the rotation batches"}
 
     # ---- plan-step latency for one ego through the host-pointer API (H2D + kernels + D2H)
     latency = None
@@ -258,14 +405,14 @@ def main():
         latency = {}
         for name, pk, mk in (("config2", syn.CONFIG2_PLANNER, syn.config2_instance),
                              ("config3", syn.CONFIG3_PLANNER, syn.config3_instance)):
-            p1 = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **pk)
-            packed = [PackedBatch([request_from_instance(mk(s))], np.float32) for s in range(8)]
-            for b in packed:
+            p1 = BatchPlanner(waypoints=wp, device=local_rank, **pk)
+            pk8 = [PackedBatch([request_from_instance(mk(s))], np.float32) for s in range(8)]
+            for b in pk8:
                 p1.plan_packed(b)
             ts = []
-            for it in range(400):
+            for it in range(1200):
                 t1 = time.perf_counter()
-                p1.plan_packed(packed[it % 8])
+                p1.plan_packed(pk8[it % 8])
                 ts.append(time.perf_counter() - t1)
             ts = np.array(ts) * 1e3
             latency[name] = {"p50_ms": float(np.percentile(ts, 50)), "p95_ms": float(np.percentile(ts, 95)),
@@ -293,11 +440,10 @@ def main():
             orc.process_prediction(raw[s_].astype(np.float64), p0, 0.2)
         latency["f1_resample_20x30"] = {"p50_ms": float(np.percentile(np.array(ts) * 1e3, 50)),
                                         "cpu_port_ms": (time.perf_counter() - t1) * 1e3}
-        p3 = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=local_rank, **syn.CONFIG3_PLANNER)
+        p3 = BatchPlanner(waypoints=wp, device=local_rank, **syn.CONFIG3_PLANNER)
         inst3 = syn.config3_instance(1)                       # a NO_PATH instance: the reference would retry twice
         lvl = [dict(), dict(target_speed=0.8 * syn.TARGET_SPEED, overrides=dict(max_accel=3.0, max_speed=11.0)),
                dict(target_speed=0.0, overrides=dict(max_accel=6.0, max_lat_accel=6.0), max_stop_distance=8.0)]
-        from integrated_path_planning_amd.batch import PlanRequest
         reqs3 = [PlanRequest(*inst3.ego, dist=inst3.dist, chain_prev_s=bool(j), **kw_) for j, kw_ in enumerate(lvl)]
         one_launch = PackedBatch(reqs3, np.float32)
         seq = [PackedBatch([PlanRequest(*inst3.ego, dist=inst3.dist, **kw_)], np.float32) for kw_ in lvl]
@@ -331,22 +477,46 @@ def main():
         ts = []
         for _ in range(5):
             t1 = time.perf_counter()
-            bp.plan_packed(pb)
+            bp.plan_packed(packed[0])
             ts.append(time.perf_counter() - t1)
-        host_api = {"candidates_per_s": cand_local / float(np.median(ts)),
+        host_api = {"candidates_per_s": cand_batch[0] / float(np.median(ts)),
                     "note": "fot_plan_batch with pageable host buffers: H2D of the obstacle tensors and D2H of the records included"}
+        # config 5's shard size on this one GPU: the like-for-like base of the N > 1 lines (512 instances per GPU)
+        if n_inst != 512:
+            reqs5 = [request_from_instance(syn.config3_instance(s)) for s in range(1536, 2048)]   # rank 3's shard
+            pb5 = PackedBatch(reqs5, obstacle_dtype=np.float32)
+            d5 = torch.from_numpy(pb5.dyn_xy).to(dev)
+            leg5 = Leg(n_ov, make_planner, dev, [pb5.with_device_obstacles(None, d5.data_ptr())],
+                       512 * _abi.RESULT_BYTES, None, False)
+            k5 = max(20, args.steps // 2)
+            el5, _, _ = leg5.run(max(3, args.warmup // 4), k5, profile=False)
+            rh5 = leg5.outs[0].cpu().numpy()
+            c5 = sum(int(r.n_cand) for r in (_abi.Result * 512).from_buffer_copy(rh5.tobytes()))
+            host_api["config5_shard_on_one_gpu"] = {
+                "instances": 512, "seeds": "1536..2047", "steps": k5, "ms_per_step": el5 / k5 * 1e3,
+                "candidates_per_s": c5 * k5 / el5, "plan_calls_in_flight": n_ov,
+                "note": "one fixed batch (123 MB of obstacle tensors, below the Infinity Cache size)"}
+            leg5.close()
 
+    cfg_name = "config4" if (world == 1 and n_inst == 256) else "config5" if n_inst == 512 else "config4-like"
     line = {
         "metric": "candidate trajectories/sec", "value": value, "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL of the N>1 control flow on one GPU: not a measurement)",
-        "config": {"workload": "config4: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "
-                               "20-sample x 30-pedestrian x 51-step fp32 prediction distribution, eps=0" % n_inst,
-                   "instances_per_gpu": n_inst, "plan_calls_in_flight": n_ov, "candidates_per_step": cand_total,
+        "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if not rehearse else "synthetic (REHEARSAL of the N>1 control flow on one GPU: not a measurement)",
+        "config": {"workload": "%s: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "
+                               "20-sample x 30-pedestrian x 51-step fp32 prediction distribution, eps=0; "
+                               "%d distinct batches rotated (%.0f MB of obstacle tensors per GPU)"
+                               % (cfg_name, n_inst, n_rot, obstacle_mb),
+                   "instances_per_gpu": n_inst, "instances_total": n_inst * world, "rotation_batches": n_rot,
+                   "plan_calls_in_flight": n_ov, "candidates_per_step": cand_total // args.steps,
                    "parallelism": "instances sharded over %d GPU(s), RCCL all-gather of %d-byte path records"
                                   % (world, _abi.RESULT_BYTES)},
-        "roofline": roofline, "roofline_valu": valu, "kernel_ms": kernels,
+        "serial": {"ms_per_step": el1 / args.steps * 1e3, "value": cand_serial / el1, "plan_calls_in_flight": 1,
+                   "steps": args.steps, "kernel_ms": kernels},
+        "roofline": roofline, "roofline_issue": issue, "kernel_ms": kernels,
+        "kernel_source_hash": src_hash,
         "cpu_baseline": cpu, "latency": latency, "host_api": host_api,
         "parity": {"instances_checked_against_oracle": n_check, "ok": n_check > 0, "all_gather_ok": gathered_ok},
     }

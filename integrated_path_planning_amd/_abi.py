@@ -103,6 +103,44 @@ class FotError(RuntimeError):
         self.code = code
 
 
+HIP_SONAME = "libamdhip64.so.7"          # what libfot.so carries as DT_NEEDED
+hip_runtime_path = None                  # which HIP runtime lib() bound libfot to (diagnostics / tests)
+
+
+def _bind_hip_runtime():
+    """ONE HIP runtime per process, whatever the import order.
+
+    PyTorch-ROCm ships its own HIP + HSA runtime in ``torch/lib`` and asks for it by FILE name (``libamdhip64.so``,
+    found through its RPATH); libfot asks for the SONAME ``libamdhip64.so.7``.  If libfot came first the loader would
+    pick the system copy for it and later a second, different copy for torch -- two HSA runtimes in one process, and
+    the second one finds no GPU.  So before libfot is opened: (1) a runtime that is already in the process is reused
+    (the loader matches libfot's DT_NEEDED against its SONAME); (2) otherwise, when this interpreter has a torch
+    installation, torch's copy is opened first -- ``import torch`` later resolves to the very same file; (3) otherwise
+    the loader's normal search (the system ROCm) applies.  torch itself is NOT imported here."""
+    global hip_runtime_path
+    noload = getattr(os, "RTLD_NOLOAD", 4)
+    for name in (HIP_SONAME, "libamdhip64.so"):
+        try:
+            C.CDLL(name, mode=noload | os.RTLD_NOW)
+            hip_runtime_path = f"(already loaded: {name})"
+            return
+        except OSError:
+            pass
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        tdir = list(spec.submodule_search_locations)[0] if spec and spec.submodule_search_locations else None
+    except Exception:
+        tdir = None
+    if tdir:
+        cand = os.path.join(tdir, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=os.RTLD_GLOBAL | os.RTLD_NOW)
+            hip_runtime_path = cand
+            return
+    hip_runtime_path = "(loader default)"
+
+
 def lib():
     """Load libfot.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
     global _lib
@@ -112,6 +150,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
             "(hipcc, gfx950). There is no CPU fallback.")
+    _bind_hip_runtime()
     L = C.CDLL(LIB_PATH)
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int32)

@@ -133,3 +133,11 @@ class PackedBatch:
         """Same batch with the obstacle coordinates already resident in HBM."""
         return self._make_struct(static_dev_ptr if self.static_xy.size else None,
                                  dyn_dev_ptr if self.dyn_xy.size else None)
+
+
+def request_from_instance(inst, **kw) -> PlanRequest:
+    """plan() arguments of a ``synthetic.Instance`` (the distribution wins over the single sample, as in the
+    reference: frenet_planner.py:1043-1047)."""
+    e = inst.ego
+    return PlanRequest(x=e[0], y=e[1], yaw=e[2], v=e[3], a=e[4], target_speed=inst.target_speed,
+                       static=inst.static, dyn=None if inst.dist is not None else inst.dyn, dist=inst.dist, **kw)

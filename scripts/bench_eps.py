@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import torch
-from helpers import request_from_instance
+from integrated_path_planning_amd.batch import request_from_instance
 from integrated_path_planning_amd import _abi, synthetic as syn
 from integrated_path_planning_amd.batch import PackedBatch
 from integrated_path_planning_amd.planner import BatchPlanner

@@ -8,11 +8,23 @@ of a wide streaming read on gfx950 -> doubled, WRITE_SIZE exact; MI355X_MICROARC
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("fot_kernels.hip", "fot_math.hpp", "fot_types.h", "fot_setup.hpp")      # == bench.py
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "integrated_path_planning_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -67,6 +79,12 @@ def main():
                     a[0] += float(row["Counter_Value"]); a[1] += 1
         for k, cs in acc.items():
             pmc.setdefault(k, {}).update({c: v[0] / v[1] for c, v in cs.items() if v[1]})
+    # which build and workload the counters belong to: bench.py only trusts them for the same kernel sources
+    meta = {"tag": tag, "source_hash": kernel_source_hash(),
+            "instances_per_launch": int(os.environ.get("FOT_PROFILE_INSTANCES", "256")),
+            "bench_args": os.environ.get("FOT_PROFILE_ARGS", "")}
+    pmc["_meta"] = meta
+    traffic["_meta"] = meta
     json.dump(pmc, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     json.dump(pmc, open(os.path.join(out, "pmc.json"), "w"), indent=1)          # what bench.py reads (with traffic.json)

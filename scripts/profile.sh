@@ -1,12 +1,18 @@
 #!/bin/bash
-# Kernel trace + HBM counters of the default bench workload, on the GPU box.  Three separate rocprofv3 runs
-# (kernel trace; FETCH_SIZE; WRITE_SIZE -- the two TCC counters do not fit one pass), the program itself after `--`.
-# Outputs under gpurun_out/prof_<tag>/; scripts/pmc_summary.py condenses them into profiles/.
+# Kernel trace + HBM / SQ counters of the bench workload, on the GPU box.  Separate rocprofv3 runs (kernel trace;
+# FETCH_SIZE; WRITE_SIZE -- the two TCC counters do not fit one pass; two SQ passes), the program itself after `--`.
+#   scripts/profile.sh <tag> [bench args...]      default: the SOLO profile (--overlap 1: one plan call in flight, so
+#                                                 every per-launch figure is a launch that has the GPU to itself)
+# Outputs under gpurun_out/prof_<tag>/; scripts/pmc_summary.py condenses them into gpurun_out/prof_<tag>/summary/
+# (copy what is to be judged into profiles/).
 set -e
 TAG=${1:-run}
+shift || true
+EXTRA="${*:---overlap 1}"
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-ARGS="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency --no-parity"
+ARGS="bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-latency --no-parity $EXTRA"
+export FOT_PROFILE_ARGS="$ARGS"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 $ARGS > "$OUT/trace.log" 2>&1

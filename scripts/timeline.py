@@ -11,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import request_from_instance                                   # noqa: E402
+from integrated_path_planning_amd.batch import request_from_instance                                   # noqa: E402
 from integrated_path_planning_amd import _abi, synthetic as syn            # noqa: E402
 from integrated_path_planning_amd.batch import PackedBatch                 # noqa: E402
 from integrated_path_planning_amd.planner import BatchPlanner              # noqa: E402

@@ -6,15 +6,6 @@ import sys
 import numpy as np
 import pytest
 
-# PyTorch-ROCm bundles its own HIP runtime (libamdhip64.so in torch/lib); libfot links the system one.  Whichever is
-# loaded first serves both only when torch comes first (the loader then resolves libfot's libamdhip64.so.7 to the copy
-# already in the process).  A few GPU tests use torch for device buffers, so load it before anything can load libfot,
-# whatever subset of the tests is run.
-try:
-    import torch  # noqa: F401
-except Exception:                                       # the planner itself does not need it
-    torch = None
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -2,16 +2,9 @@
 import numpy as np
 
 from integrated_path_planning_amd import _abi
-from integrated_path_planning_amd.batch import PlanRequest
-
-# north_star tolerance: selected path and cost within 1e-5 of the reference (fp32-level).
-# The kernels compute in float64, so the tests hold them to a much tighter bound.
-NORTH_STAR_TOL = 1e-5
-TIGHT = 1e-8
-
-
-def wrap_angle(a):
-    return (np.asarray(a) + np.pi) % (2 * np.pi) - np.pi
+from integrated_path_planning_amd.batch import PlanRequest, request_from_instance  # noqa: F401
+from oracle.check import (NORTH_STAR_TOL, TIGHT, assert_record_matches_oracle,  # noqa: F401
+                          oracle_plan_for_request, wrap_angle)
 
 
 def request_from_golden(g) -> PlanRequest:
@@ -22,38 +15,3 @@ def request_from_golden(g) -> PlanRequest:
                        max_stop_distance=m["max_stop"], static=g.static, dyn=g.dyn, dist=g.dist)
 
 
-def request_from_instance(inst, **kw) -> PlanRequest:
-    e = inst.ego
-    return PlanRequest(x=e[0], y=e[1], yaw=e[2], v=e[3], a=e[4], target_speed=inst.target_speed,
-                       static=inst.static, dyn=None if inst.dist is not None else inst.dyn, dist=inst.dist, **kw)
-
-
-def oracle_plan_for_request(orc, params, spline, req: PlanRequest, table=False):
-    ego = orc.make_ego(req.x, req.y, req.yaw, req.v, req.a, last_kappa=req.last_kappa, prev_s=req.prev_s)
-    return orc.plan(params, spline, ego, req.target_speed, req.overrides, req.max_stop_distance,
-                    static=req.static, dyn=req.dyn, dist=req.dist, table=table)
-
-
-def assert_record_matches_oracle(rec, want, tol=TIGHT, label=""):
-    """fot_result record vs oracle PlanOutput."""
-    assert rec.status == want.status, f"{label} status {rec.status} != {want.status}"
-    assert rec.best_index == want.best_index, f"{label} best_index {rec.best_index} != {want.best_index}"
-    assert rec.n_cand == want.n_cand, label
-    if want.stats is not None:
-        for k in range(8):
-            assert rec.stats[k] == want.stats.get(_abi.STATUS_NAMES[k], 0), f"{label} stats[{_abi.STATUS_NAMES[k]}]"
-    np.testing.assert_allclose(np.array(rec.frenet0[:]), want.frenet0, rtol=tol, atol=tol, err_msg=label)
-    np.testing.assert_allclose(rec.new_prev_s, want.new_prev_s, atol=tol, err_msg=label)
-    if want.status != 0:
-        return
-    np.testing.assert_allclose(rec.cost, want.cost, rtol=tol, err_msg=label)
-    n = rec.n_keep
-    for f in _abi.PATH_FIELDS:
-        got = np.array(getattr(rec, f)[:n])
-        exp = want.path[f]
-        assert len(exp) == n, f"{label} len({f})"
-        if f == "yaw":
-            np.testing.assert_allclose(wrap_angle(got - exp), 0.0, atol=tol, err_msg=f"{label} {f}")
-        else:
-            np.testing.assert_allclose(got, exp, rtol=tol, atol=tol, err_msg=f"{label} {f}")
-    np.testing.assert_allclose(rec.new_last_kappa, want.new_last_kappa, rtol=tol, atol=tol, err_msg=label)
