@@ -16,9 +16,13 @@
  *     modifies inputs (reference: integrated_simulator.py:698 passes copies).
  *   - one handle = one GPU + one stream + its own workspace.  Handles share no
  *     state, so one handle per host thread / per rank is safe; a single handle
- *     is not thread-safe (the reference planner is not either: it carries
+ *     is not thread-safe, and its calls execute in the order they were made even
+ *     when they are enqueued on different caller streams: every enqueue first waits
+ *     (on the device) for the handle's previous one, because they share the workspace
+ *     and the scratch buffers.  To keep several batches in flight use one handle per
+ *     batch in flight.  (The reference planner is not thread-safe either: it carries
  *     _last_kappa and converter._prev_s, frenet_planner.py:218, coordinate_converter.py:283;
- *     here that state is explicit in fot_ego / fot_result).
+ *     here that state is explicit in fot_ego / fot_result.)
  *   - all arithmetic that decides a candidate's status is float64, like the reference.
  */
 #ifndef FOT_H
@@ -131,7 +135,10 @@ typedef struct fot_batch {
     const void *static_xy;               /* host | device */
     const int32_t *static_off;           /* [n_inst+1] host, or NULL (no static obstacles) */
     /* dynamic_obstacles [P,T,2] / dynamic_obstacles_distribution [S,P,T,2] per instance, concatenated;
-     * instance i starts at point dyn_off[i]; dyn_dims[i] = {mode, S, P, T} (S = 1 for FOT_DYN_SINGLE) */
+     * instance i starts at point dyn_off[i]; dyn_dims[i] = {mode, S, P, T} (S = 1 for FOT_DYN_SINGLE).
+     * Non-finite coordinates never hit.  The reference drops a pedestrian whose track holds a NaN at EVERY time
+     * step (np.min / np.max in its box pre-filter, frenet_planner.py:1211-1219): pass such a track as all-NaN to
+     * reproduce that (the Python packer does, batch.py). */
     const void *dyn_xy;                  /* host | device */
     const int64_t *dyn_off;              /* [n_inst] host, or NULL (no dynamic obstacles) */
     const int32_t *dyn_dims;             /* [n_inst][4] host */

@@ -363,7 +363,7 @@ class BatchedClosedLoop:
         t0 = time.perf_counter()
         reqs: List[PlanRequest] = []
         plans = []
-        static = self.static_obstacle_points                          # the same array object for every request: packed once
+        static = self.static_obstacle_points                          # (fot_batch.static_off is a prefix array: one copy per request)
         for ep, dyn, m in zip(eps, dyns, metrics):
             ep.last_clearance = m.get("clearance_ahead", m.get("clearance", float("inf")))
             ladder, r, budget = ep.cycle.prepare(ep.ego, static, dyn, m)

@@ -89,6 +89,12 @@ struct fot_handle {
     int device = 0;
     hipStream_t stream = nullptr;            // the handle's own stream (host-pointer entry points, helpers)
     hipEvent_t fork = nullptr;               // caller's stream -> lanes
+    // One handle = ONE workspace and one set of scratch buffers, so its enqueues are ordered whatever streams the
+    // caller passes: an enqueue on a stream other than the previous one first waits (device side) for the event
+    // recorded behind the previous enqueue.  Work of different handles still overlaps freely.
+    hipEvent_t order_done = nullptr;
+    hipStream_t order_stream = nullptr;
+    bool order_valid = false;
     fot_params params;
     DevParams P;
     DevBuf dP;
@@ -126,6 +132,21 @@ int hip_fail(fot_handle *h, hipError_t e, const char *what)
 
 #define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail((h), e_, #expr); } while (0)
 #define LAUNCH_TRY(h, expr) do { int r_ = (expr); if (r_ != 0) return hip_fail((h), (hipError_t)r_, #expr); } while (0)
+
+// see fot_handle::order_done
+int order_begin(fot_handle *h, hipStream_t st)
+{
+    if (h->order_valid && st != h->order_stream) HIP_TRY(h, hipStreamWaitEvent(st, h->order_done, 0));
+    return FOT_OK;
+}
+
+int order_end(fot_handle *h, hipStream_t st)
+{
+    HIP_TRY(h, hipEventRecord(h->order_done, st));
+    h->order_stream = st;
+    h->order_valid = true;
+    return FOT_OK;
+}
 
 SplineView spline_view(const fot_handle *h)
 {
@@ -311,6 +332,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     if (!b.ego || !b.target_speed) return fail(h, FOT_ERR_INVALID, "ego / target_speed missing");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->prof_on && h->prof_kernel.size() > 16384) { int r = prof_drain(h); if (r != FOT_OK) return r; }
+    { int r = order_begin(h, user); if (r != FOT_OK) return r; }
 
     if (b.n_inst < FOT_SPLIT_MIN_INSTANCES * h->lanes_cfg / 2 || h->lanes_cfg <= 1) {
         h->ws[0].first_inst = 0;
@@ -318,7 +340,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
         if (rc != FOT_OK) return rc;
         h->lanes_used = 1;
         h->last_valid = true;
-        return FOT_OK;
+        return order_end(h, user);
     }
     HIP_TRY(h, hipEventRecord(h->fork, user));
     int i0 = 0;
@@ -340,7 +362,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     }
     h->lanes_used = lanes;
     h->last_valid = true;
-    return FOT_OK;
+    return order_end(h, user);
 }
 
 // lane and local index of global instance `inst` of the most recent plan call
@@ -393,6 +415,7 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipEventCreateWithFlags(&h->fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&h->order_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     for (int l = 0; l < FOT_LANES; ++l) {
         Workspace &w = h->ws[l];
         // lane streams only when the handle splits batches; lane 0 of a single-lane handle runs on the caller's stream
@@ -413,12 +436,14 @@ void fot_destroy(fot_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->order_valid) (void)hipEventSynchronize(h->order_done);   // work enqueued on a caller's stream
     for (Workspace &w : h->ws) if (w.stream) (void)hipStreamSynchronize(w.stream);
     DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
+    if (h->order_done) (void)hipEventDestroy(h->order_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -475,6 +500,7 @@ int fot_spline_eval(fot_handle *h, int32_t n, const double *s, double *x, double
     if (n <= 0) return FOT_OK;
     if (!s) return fail(h, FOT_ERR_INVALID, "s is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
+    { int r = order_begin(h, h->stream); if (r != FOT_OK) return r; }
     HIP_TRY(h, h->dTmpA.ensure(sizeof(double) * (size_t)n));
     HIP_TRY(h, h->dTmpB.ensure(sizeof(double) * 5 * (size_t)n));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
@@ -526,7 +552,7 @@ int resample_common(fot_handle *h, const fot_resample_params *rp, int cv, int32_
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // small per-pedestrian inputs: anchor | current  (and obs_prev for cv) through the handle's scratch
     const size_t row = sizeof(double) * 2 * (size_t)P;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    { int r = order_begin(h, st); if (r != FOT_OK) return r; }  // the scratch below is shared by every entry point
     HIP_TRY(h, h->dTmpA.ensure(3 * row + 64));
     char *scr = (char *)h->dTmpA.p;
     const double *d_anchor = nullptr, *d_current = nullptr;
@@ -555,6 +581,7 @@ int resample_common(fot_handle *h, const fot_resample_params *rp, int cv, int32_
         HIP_TRY(h, hipMemcpyAsync(sample_dist, h->dTmpD.p, sizeof(double) * (size_t)S, hipMemcpyDeviceToHost, st));
     }
     if (!on_device) HIP_TRY(h, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    { int r = order_end(h, st); if (r != FOT_OK) return r; }
     if (!on_device || sample_dist) HIP_TRY(h, hipStreamSynchronize(st));
     return FOT_OK;
 }
@@ -602,7 +629,7 @@ int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const 
     if (n_ped > 0 && (!ped_pos || !ped_vel)) return fail(h, FOT_ERR_INVALID, "NULL pedestrian array");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    HIP_TRY(h, hipStreamSynchronize(st));
+    { int r = order_begin(h, st); if (r != FOT_OK) return r; }
     const size_t ego_b = sizeof(double) * 4 * (size_t)n, off_b = align256(sizeof(int32_t) * ((size_t)n + 1));
     const size_t ped_b = sizeof(double) * 2 * std::max<size_t>(n_ped, 1);
     HIP_TRY(h, h->dTmpA.ensure(align256(ego_b) + off_b));
@@ -699,6 +726,7 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
         run = desc[i].ego.has_prev_s == FOT_PREV_S_CHAINED ? run + 1 : 0;
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    { int r = order_begin(h, h->stream); if (r != FOT_OK) return r; }
     HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc) * (size_t)n));
     HIP_TRY(h, h->dTmpB.ensure(sizeof(InstState) * (size_t)n));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, desc.data(), sizeof(InstDesc) * (size_t)n, hipMemcpyHostToDevice, h->stream));
@@ -814,7 +842,7 @@ int check_ext(fot_handle *h, int mode, int32_t n_paths, const int32_t *len, cons
 
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    HIP_TRY(h, hipStreamSynchronize(st));
+    { int r = order_begin(h, st); if (r != FOT_OK) return r; }
     const size_t st_bytes = sizeof(double) * 2 * (size_t)L.n_static, dy_bytes = sizeof(double) * 2 * (size_t)L.dyn_src_points;
     HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
     HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));

@@ -689,6 +689,9 @@ static int hits_dynamic(const coll_geom *g, const double *dyn, int P, int T, dou
             if (tr[2 * k] > mxx) mxx = tr[2 * k];
             if (tr[2 * k + 1] < mny) mny = tr[2 * k + 1];
             if (tr[2 * k + 1] > mxy) mxy = tr[2 * k + 1];
+            /* np.min / np.max propagate a NaN sample (:1211-1212): the track then fails the mask below */
+            if (isnan(tr[2 * k])) mnx = mxx = NAN;
+            if (isnan(tr[2 * k + 1])) mny = mxy = NAN;
         }
         if (!(mxx >= g->minx && mnx <= g->maxx && mxy >= g->miny && mny <= g->maxy)) continue;
         for (int i = 0; i < g->n; ++i) {

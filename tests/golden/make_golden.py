@@ -176,6 +176,19 @@ def build_cases():
     inst = syn.config3_instance(11)
     add("short_T", "straight", syn.CONFIG3_PLANNER, inst.ego, dyn=inst.dist[0, :, :20].astype(np.float64))
     add("cur_pos_only", "straight", syn.CONFIG3_PLANNER, inst.ego, dyn=inst.dist[0, :, :1].astype(np.float64))
+    # NaN samples: np.min / np.max over a pedestrian's track propagate the NaN, so _hits_dynamic drops that pedestrian
+    # at EVERY time step (frenet_planner.py:1211-1219); a NaN static point never matches the box mask (:1186-1191)
+    inst = syn.config3_instance(2)
+    d = inst.dist.astype(np.float64).copy()
+    d[:, [0, 3, 5, 7, 11, 13, 17, 19, 23, 29], 50, 1] = np.nan     # these pedestrians vanish from every sample
+    d[2, 1, 0, 1] = np.nan                                        # ... and pedestrian 1 from sample 2 only
+    add("nan_ped_dist", "straight", syn.CONFIG3_PLANNER, inst.ego, dist=d)
+    dd = inst.dist[4].astype(np.float64).copy()
+    dd[::2, 50, 1] = np.nan                                       # every other pedestrian: last sample NaN
+    st = syn.config2_instance(2).static + np.array([inst.ego[0] - syn.config2_instance(2).ego[0], 0.0])
+    st = np.concatenate([st, [[np.nan, 0.0], [inst.ego[0] + 12.0, np.nan]]])
+    add("nan_ped_single", "straight", dict(syn.CONFIG3_PLANNER, collision_margin_inflation=1.2), inst.ego, dyn=dd,
+        static=st)
     return cases
 
 

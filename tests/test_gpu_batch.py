@@ -322,3 +322,37 @@ def test_config5_shard_sample_vs_oracle(config5_shard):
     for i in range(0, 512, 16):
         want = oracle_plan_for_request(orc, params, sp, _rounded(reqs[i], np.float32))
         assert_record_matches_oracle(res.records[i], want, label=f"seed {1536 + i}")
+
+
+def test_one_handle_alternating_streams_is_ordered():
+    """One handle owns ONE workspace: plan calls enqueued on different caller streams must not overlap on it.  Ten
+    plan calls alternate between two streams without any host synchronisation, each followed by a device-resident
+    prediction resample on the other stream (shared scratch); every result equals that of a serial run."""
+    import torch
+    from integrated_path_planning_amd.prediction import PredictionResampler
+    kw = syn.CONFIG3_PLANNER
+    dev = torch.device("cuda", 0)
+    bp = BatchPlanner(waypoints=WP, **kw)
+    batches = [PackedBatch([request_from_instance(syn.config3_instance(40 * b + s)) for s in range(40)], np.float32)
+               for b in range(4)]
+    want = [bytes(bp.plan_packed(pb).records) for pb in batches]
+    dyn = [torch.from_numpy(pb.dyn_xy).to(dev) for pb in batches]
+    structs = [pb.with_device_obstacles(None, d.data_ptr()) for pb, d in zip(batches, dyn)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [torch.zeros(40 * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(10)]
+    rs = PredictionResampler(bp)
+    rng = np.random.default_rng(5)
+    raw = torch.from_numpy(rng.normal(0, 5, (20, 12, 30, 2)).astype(np.float32)).to(dev)
+    p0 = rng.normal(0, 5, (30, 2))
+    obs = [torch.zeros((20, 30, rs.n_dense + 1, 2), dtype=torch.float32, device=dev) for _ in range(10)]
+    torch.cuda.synchronize(dev)
+    for i in range(10):
+        st = streams[i % 2]
+        bp.plan_packed_device(structs[i % 4], outs[i].data_ptr(), st.cuda_stream)
+        rs.resample_device(raw.data_ptr(), np.float32, 20, 30, p0, p0, 0.2, obs[i].data_ptr(), np.float32,
+                           streams[(i + 1) % 2].cuda_stream)
+    torch.cuda.synchronize(dev)
+    for i in range(10):
+        got = outs[i].cpu().numpy().tobytes()
+        assert got == want[i % 4][: len(got)], f"plan call {i} differs from the serial run"
+        assert torch.equal(obs[i], obs[0]), f"resample {i} was disturbed"
