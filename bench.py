@@ -128,8 +128,9 @@ class Leg:
         import torch
         self.torch, self.dev, self.n_ov, self.pg, self.rehearse = torch, dev, n_ov, pg, rehearse
         self.planners = [make_planner() for _ in range(n_ov)]
-        cur = torch.cuda.current_stream(dev)
-        self.streams = [cur] + [torch.cuda.Stream(device=dev) for _ in range(n_ov - 1)]
+        # explicit streams only: a NULL stream handed to fot_plan_batch_device means "the handle's own stream", which
+        # neither torch's default stream nor the collective that follows would wait for
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_ov)]
         self.outs = [torch.zeros(out_bytes, dtype=torch.uint8, device=dev) for _ in range(n_ov)]
         self.batches = batches
         self.count = 0
@@ -269,7 +270,8 @@ def main():
 
     # ---- candidates actually generated: one untimed pass per rotation batch, counted from its result records
     bp = leg1.planners[0]
-    stream = torch.cuda.current_stream(dev)
+    stream = leg1.streams[0]
+    torch.cuda.set_stream(stream)                               # everything below (copies, collectives) follows it
     chk = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
     cand_batch, recs0 = [], None
     for b in range(n_rot):

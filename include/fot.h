@@ -193,6 +193,16 @@ int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
  * arrays[15][FOT_MAX_NT] in fot_result field order, *n_t = generated samples. */
 int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double *arrays, int32_t *n_t);
 
+/* Epsilon-band report for instance `inst` of the most recent plan call: per candidate and per group of decisions the
+ * smallest relative distance |value - threshold| / |threshold| of every comparison made on it (speed :964, accel :966,
+ * curvature incl. the 0.5 m/s gate and the low-speed rules :968/:995-1033, lateral acceleration :975, road :982,
+ * collision radius :1198/:1233 against the obstacles the broad phase kept, stop filter :307-324, structural:
+ * singularity :826, EPS_S_DOT :792, step length :955).  margins[cap][FOT_MARGIN_GROUPS]; +inf = no such decision.
+ * A status that differs from the reference's with all margins far above float64 rounding is a logic error; a margin
+ * at rounding level marks a decision that a re-association may flip.  Returns the number of candidates. */
+#define FOT_MARGIN_GROUPS 8
+int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins);
+
 /* FrenetPlanner._path_is_collision_free (frenet_planner.py:1035-1233) for n_paths externally
  * supplied paths against ONE obstacle set.  x, y, yaw, t: [n_paths][FOT_MAX_NT] host, len[n_paths];
  * static_xy [n_static][2] double host; dyn [S][P][T][2] double host with mode as in dyn_dims.

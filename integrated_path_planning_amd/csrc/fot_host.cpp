@@ -800,6 +800,32 @@ int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double 
     return FOT_OK;
 }
 
+int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->last_valid) return fail(h, FOT_ERR_INVALID, "no completed plan call on this handle");
+    int local = 0;
+    Workspace *w = lane_of(h, inst, &local);
+    if (!w) return fail(h, FOT_ERR_INVALID, "instance index out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());                          // diagnostic entry: whatever stream the plan ran on
+    InstState S;
+    HIP_TRY(h, hipMemcpy(&S, w->dState.as<InstState>() + local, sizeof(InstState), hipMemcpyDeviceToHost));
+    const int n = S.n_cand;
+    const int m = n < cap ? n : cap;
+    if (m <= 0 || !margins) return n;
+    const size_t bytes = sizeof(double) * FOT_MARGIN_GROUPS * (size_t)m;
+    HIP_TRY(h, h->dTmpB.ensure(bytes));
+    EntryArrays ea;
+    ea.cnt = w->dEntCnt.as<int32_t>(); ea.e32 = w->dEnt32.as<f2>(); ea.e64 = w->dEnt64.as<d2>();
+    ea.sid = w->dEntSid.as<uint8_t>(); ea.rng = w->dWaveRng.as<uint32_t>();
+    LAUNCH_TRY(h, launch_debug_margins(h->dP.as<DevParams>(), (const InstDesc *)w->dMeta.p, w->dState.as<InstState>(),
+                                       spline_view(h), local, ea, m, h->dTmpB.as<double>(), h->stream));
+    HIP_TRY(h, hipMemcpyAsync(margins, h->dTmpB.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return n;
+}
+
 }  // extern "C"
 
 namespace {

@@ -496,9 +496,14 @@ struct StagedTab {
 // diagnostic build (scripts/timeline.sh): per wave of the last k_evaluate launch -- workgroup start, wave start
 // (after the LDS prologue), wave end on the 100 MHz clock, and the chunks its strip ranges cover
 __device__ uint64_t g_timeline[4 * 16384];
+__device__ uint64_t g_shader_clock[2 * 16384];     // s_memtime at wave start / end: shader cycles (in-kernel clock)
 extern "C" int fot_timeline_read(uint64_t *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(uint64_t) * (size_t)n_words);
+}
+extern "C" int fot_timeline_read_clock(uint64_t *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shader_clock), sizeof(uint64_t) * (size_t)n_words);
 }
 #endif
 
@@ -579,6 +584,7 @@ k_evaluate(const EvalKernArgs a)
     const uint32_t my_rng = D.ent_cap != 0 && lane < n_total && !(ablate & 1) ? wave_rng[(int64_t)wave * n_total + lane] : 0u;
 #ifdef FOT_TIMELINE
     const uint64_t t_wave = __builtin_amdgcn_s_memrealtime();
+    const uint64_t c_wave = __builtin_amdgcn_s_memtime();
     const int tl_wave = blockIdx.x * (EVAL_WG / WAVE) + (threadIdx.x / WAVE);          // in dispatch order
     int tl_chunks = (int)(my_rng & 0xffffu) - (int)(my_rng >> 16);
     for (int o = 32; o > 0; o >>= 1) tl_chunks += __shfl_xor(tl_chunks, o);
@@ -633,6 +639,7 @@ k_evaluate(const EvalKernArgs a)
         g_timeline[tl_wave * 4 + 0] = t_blk; g_timeline[tl_wave * 4 + 1] = t_wave;
         g_timeline[tl_wave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
         g_timeline[tl_wave * 4 + 3] = (uint64_t)tl_chunks;
+        g_shader_clock[tl_wave * 2 + 0] = c_wave; g_shader_clock[tl_wave * 2 + 1] = __builtin_amdgcn_s_memtime();
     }
 #endif
 }
@@ -970,6 +977,34 @@ k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc
 }
 
 // ---------------------------------------------------------------------------
+// epsilon-band report of one instance of the last plan call (fot_debug_margins): one thread per candidate
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(WAVE)
+k_debug_margins(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+                SplineView sp, int inst, const int32_t *__restrict__ ent_cnt, const d2 *__restrict__ ent64,
+                const uint8_t *__restrict__ ent_sid, int cap, double *__restrict__ out /* [cap][MARGIN_CATS] */)
+{
+    const DevParams &P = *Pp;
+    const InstDesc &D = desc[inst];
+    const InstState &S = state[inst];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!S.c2f_ok || idx >= S.n_cand || idx >= cap) return;
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+    const LonInfo L = profile_info(P, D, S.frenet0, cd.lon_slot, false);
+    ComputeTab tab;
+    tab.sp = sp; tab.L = L; tab.dt = P.dt;
+    double q[6];
+    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+    MarginEntries ent;
+    ent.cnt = D.ent_cap != 0 ? ent_cnt + (int64_t)inst * P.n_total : nullptr;
+    ent.e64 = ent64 + D.ent_off; ent.sid = ent_sid + D.ent_off; ent.ent_cap = D.ent_cap;
+    double m[MARGIN_CATS];
+    candidate_margins(P, D, L, tab, q, ent, m);
+    for (int c = 0; c < MARGIN_CATS; ++c) out[(int64_t)idx * MARGIN_CATS + c] = m[c];
+}
+
+// ---------------------------------------------------------------------------
 // spline evaluation (fot_spline_eval)
 // ---------------------------------------------------------------------------
 
@@ -1256,6 +1291,15 @@ int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState 
                       SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st)
 {
     k_debug_path<<<1, WAVE, 0, st>>>(P, desc, state, sp, inst, idx, out, meta);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_debug_margins(const DevParams *P, const InstDesc *desc, const InstState *state, SplineView sp, int inst,
+                         EntryArrays e, int cap, double *out, hipStream_t st)
+{
+    if (cap <= 0) return 0;
+    k_debug_margins<<<(cap + WAVE - 1) / WAVE, WAVE, 0, st>>>(P, desc, state, sp, inst, e.cnt, e.e64, e.sid, cap, out);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -44,6 +44,8 @@ FOT_HD double fast_rsqrt(double a)
 #endif
 }
 
+FOT_HD double sum_sq_unfused(double a, double b);
+
 // ---------------------------------------------------------------------------
 // cubic spline (reference: src/planning/cubic_spline.py:47-166, 215-288)
 // ---------------------------------------------------------------------------
@@ -441,7 +443,7 @@ FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSampl
     check_flag(c, !(isfinite(p.v) && isfinite(p.a) && isfinite(p.kappa)), CK_NONFINITE);     // :944-946
     if (k > 0) {
         const double sx = p.x - c.prev.x, sy = p.y - c.prev.y;                                // :953-956
-        const double step2 = sx * sx + sy * sy;
+        const double step2 = sum_sq_unfused(sx, sy);
         check_flag(c, isnan(step2), CK_NANSTEP);
         if (step2 > c.max_step2) c.max_step2 = step2;
         check_flag(c, p.v > C.lim_speed, CK_SPEED);                                           // :964
@@ -608,10 +610,20 @@ struct ObstacleView {
     FOT_HD d2 dyn_at(int s, int p, int row, int P, int T) const { return at(dyn, ((int64_t)s * P + p) * T + row); }
 };
 
+// a*a + b*b with every operation rounded on its own -- NumPy's np.sum(diff ** 2, axis=2) squares, then adds
+// (frenet_planner.py:1196-1197, 1231-1232); the device compiler would otherwise contract the sum into an FMA
+FOT_HD double sum_sq_unfused(double a, double b)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const double aa = a * a, bb = b * b;
+    return aa + bb;
+}
+
 FOT_HD bool within(const d2 &o, double px, double py, double sq)       // (:1196-1198, :1231-1233)
 {
-    const double dx = px - o.x, dy = py - o.y;
-    return dx * dx + dy * dy <= sq;
+    return sum_sq_unfused(px - o.x, py - o.y) <= sq;
 }
 
 // Exact per-candidate check, straight from the definition.  Source::get(k, circle, x, y) returns the
@@ -975,6 +987,96 @@ FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const Tab &lon_ta
     o[5] = d; o[6] = d_d; o[7] = d_dd; o[8] = d_ddd;
     o[9] = c.x; o[10] = c.y; o[11] = atan2(c.sin_t, c.cos_t);
     o[12] = c.v; o[13] = c.a; o[14] = c.kappa;
+}
+
+// ---------------------------------------------------------------------------
+// epsilon-band report (fot_debug_margins): how close each candidate came to any threshold
+// ---------------------------------------------------------------------------
+
+// Per candidate, per group of decisions, the smallest RELATIVE distance |value - threshold| / |threshold| over every
+// comparison evaluate_candidate / the collision test / the stop filter makes on it.  A status that differs from the
+// reference's while all its margins are >> float64 rounding would be a logic error; a tiny margin says the decision is
+// within rounding of the threshold and may legitimately flip under a re-association.  Diagnostic only (one thread per
+// candidate, rows recomputed on the spot); the entry lists of the last plan call supply the obstacles (everything
+// outside them is more than the cull margin away from every point of the candidate).
+enum { MG_SPEED = 0, MG_ACCEL, MG_CURV, MG_LAT, MG_ROAD, MG_COLLISION, MG_STOP, MG_STRUCT, MARGIN_CATS };
+static_assert(MARGIN_CATS == FOT_MARGIN_GROUPS, "include/fot.h");
+
+FOT_HD void margin_note(double *m, int cat, double value, double threshold)
+{
+    const double r = fabs(value - threshold) / fabs(threshold);
+    if (r < m[cat]) m[cat] = r;                      // NaN never lowers a margin
+}
+
+struct MarginEntries {
+    const int32_t *cnt;                  // [n_total] entries of each time step of this instance (nullptr: none)
+    const d2 *e64; const uint8_t *sid;   // of this instance
+    int ent_cap;
+};
+
+template <class Tab>
+FOT_HD void candidate_margins(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
+                              const double *q, const MarginEntries &ent, double *m /*[MARGIN_CATS]*/)
+{
+    for (int c = 0; c < MARGIN_CATS; ++c) m[c] = INFINITY;
+    const LoopConst C = loop_const(P, D);
+    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+    const int n_circ = P.has_footprint ? P.n_circ : 1;
+    PathSample prev;
+    prev.x = prev.y = prev.kappa = prev.v = prev.a = prev.d = 0.0; prev.cos_t = 1.0; prev.sin_t = 0.0;
+    double v_last = 0.0;
+    int k_last = -1;
+    for (int k = 0; k < L.n_t; ++k) {
+        LonSample ls;
+        lon_tab.load(k, ls);
+        double d, d_d, d_dd, d_ddd;
+        lat_sample(q, k, L.n_eval, C.dt, d, d_d, d_dd, d_ddd);
+        CartSample c;
+        frenet_to_cart(ls, d, d_d, d_dd, c);
+        margin_note(m, MG_STRUCT, c.omkd, 0.05);                                    // SINGULARITY_EPS
+        margin_note(m, MG_STRUCT, fabs(ls.sd), 1e-3);                               // EPS_S_DOT
+        if (isnan(c.x)) break;                                                       // truncation: no threshold involved
+        if (k > 0) {
+            const double sx = c.x - prev.x, sy = c.y - prev.y;
+            const double step2 = sum_sq_unfused(sx, sy);
+            margin_note(m, MG_STRUCT, sqrt(step2), D.step_limit);
+            margin_note(m, MG_SPEED, c.v, C.lim_speed);
+            margin_note(m, MG_ACCEL, fabs(c.a), C.lim_accel);
+            margin_note(m, MG_CURV, c.v, 0.5);                                       // LOW_SPEED_CURVATURE_GATE
+            if (c.v > 0.5) {
+                margin_note(m, MG_CURV, fabs(c.kappa), C.lim_curv);
+            } else {
+                const double d_s = fabs(lon_tab.s_at(k) - lon_tab.s_at(k - 1));
+                margin_note(m, MG_CURV, fabs(d - prev.d), fmax(1.5 * d_s, 0.02));
+                const double sn = c.sin_t * prev.cos_t - c.cos_t * prev.sin_t;
+                const double cs = c.cos_t * prev.cos_t + c.sin_t * prev.sin_t;
+                margin_note(m, MG_CURV, fabs(atan2(sn, cs)), fmax(C.lim_curv * sqrt(step2), 0.1));
+            }
+            margin_note(m, MG_LAT, c.v * c.v * fabs(c.kappa), C.lim_lat);
+            margin_note(m, MG_ROAD, fabs(d), C.road_lim);
+        }
+        if (ent.cnt) {
+            const int n = ent.cnt[k];
+            const int64_t base = (int64_t)k * ent.ent_cap;
+            for (int ci = 0; ci < n_circ; ++ci) {
+                const double off = P.has_footprint ? P.circ_off[ci] : 0.0;
+                const double px = c.x + off * c.cos_t, py = c.y + off * c.sin_t;
+                for (int j = 0; j < n; ++j) {
+                    const d2 o = ent.e64[base + j];
+                    if (!(fabs(o.x) < 1e300)) continue;                                // list padding
+                    margin_note(m, MG_COLLISION, sum_sq_unfused(px - o.x, py - o.y),
+                                ent.sid[base + j] == 255 ? P.sq_r : sq_dyn);
+                }
+            }
+        }
+        prev.x = c.x; prev.y = c.y; prev.cos_t = c.cos_t; prev.sin_t = c.sin_t; prev.kappa = c.kappa;
+        prev.v = c.v; prev.a = c.a; prev.d = d;
+        v_last = c.v; k_last = k;
+    }
+    if (!isnan(D.max_stop) && k_last >= 0) {
+        margin_note(m, MG_STOP, fabs(v_last), 0.15);                                  // STOP_SPEED_EPS
+        margin_note(m, MG_STOP, lon_tab.s_at(k_last) - lon_tab.s_at(0), D.max_stop + 1e-6);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -120,6 +120,7 @@ class ShardedPlanner:
         self.device = torch.device("cuda", device_index)
         self.planner = BatchPlanner(waypoints=waypoints, device=device_index, **planner_kwargs)
         self._keep = None
+        self._stream = None
 
     def plan(self, requests: Sequence, obstacle_dtype=np.float32):
         """``requests``: the GLOBAL list of PlanRequest (every rank passes the same list).
@@ -133,13 +134,20 @@ class ShardedPlanner:
         dyn = torch.from_numpy(pb.dyn_xy).to(self.device) if pb.dyn_xy.size else None
         st = torch.from_numpy(pb.static_xy).to(self.device) if pb.static_xy.size else None
         out = torch.zeros(max(hi - lo, 1) * _abi.RESULT_BYTES, dtype=torch.uint8, device=self.device)
-        stream = torch.cuda.current_stream(self.device)
-        if hi > lo:
-            self.planner.plan_packed_device(
-                pb.with_device_obstacles(st.data_ptr() if st is not None else None,
-                                         dyn.data_ptr() if dyn is not None else None),
-                out.data_ptr(), stream.cuda_stream)
-        self._keep = (pb, dyn, st)                       # inputs must outlive the enqueued work
-        full = all_gather_records(out[: (hi - lo) * _abi.RESULT_BYTES], n_total, self.world, self.rank, self.group)
+        # an explicit stream: the NULL (default) stream would mean "the handle's own stream" to libfot, which the
+        # collective below does not wait for
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))     # the uploads above
+        with torch.cuda.stream(self._stream):
+            if hi > lo:
+                self.planner.plan_packed_device(
+                    pb.with_device_obstacles(st.data_ptr() if st is not None else None,
+                                             dyn.data_ptr() if dyn is not None else None),
+                    out.data_ptr(), self._stream.cuda_stream)
+            self._keep = (pb, dyn, st)                   # inputs must outlive the enqueued work
+            full = all_gather_records(out[: (hi - lo) * _abi.RESULT_BYTES], n_total, self.world, self.rank,
+                                      self.group)
+            self._stream.synchronize()
         host = full.cpu().numpy()
         return records_from_bytes(host, n_total), full

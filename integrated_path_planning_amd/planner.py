@@ -159,7 +159,9 @@ class BatchPlanner:
         return self.plan_packed(PackedBatch(requests, obstacle_dtype))
 
     def plan_packed_device(self, batch_struct: _abi.Batch, out_dev_ptr: int, stream: Optional[int] = None):
-        """Obstacles and results resident in HBM; enqueues on ``stream`` and returns immediately."""
+        """Obstacles and results resident in HBM; enqueues on ``stream`` (a hipStream_t handle) and returns immediately.
+        ``None`` / 0 = the handle's own stream, which no other stream waits for (torch's default stream has handle 0:
+        pass an explicit ``torch.cuda.Stream`` and follow up on that stream, or call ``synchronize()``)."""
         _abi.check(self._h, self._lib.fot_plan_batch_device(self._h, C.byref(batch_struct), C.c_void_p(out_dev_ptr),
                                                             C.c_void_p(stream) if stream else None))
 
@@ -192,6 +194,15 @@ class BatchPlanner:
             _abi.check(self._h, n)
         n = min(n, cap)
         return cost[:n], status[:n], keep[:n], nt[:n]
+
+    def margins(self, inst: int = 0, cap: int = 1 << 16) -> np.ndarray:
+        """[n_cand, 8] smallest relative distance to a threshold per candidate and decision group
+        (``_abi.MARGIN_NAMES``) of an instance of the last plan call; +inf where no such decision was made."""
+        out = np.full((cap, _abi.MARGIN_GROUPS), np.inf)
+        n = self._lib.fot_debug_margins(self._h, inst, cap, _as_dp(out))
+        if n < 0:
+            _abi.check(self._h, n)
+        return out[: min(n, cap)]
 
     def candidate_path(self, index: int, inst: int = 0) -> FrenetPath:
         """Candidate ``index`` of the last plan call as generated + converted, before truncation."""

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 from integrated_path_planning_amd.batch import request_from_instance                                   # noqa: E402
 from integrated_path_planning_amd import _abi, synthetic as syn            # noqa: E402
 from integrated_path_planning_amd.batch import PackedBatch                 # noqa: E402
@@ -49,6 +49,15 @@ def main():
     L.fot_timeline_read.argtypes = [C.c_void_p, C.c_int]
     assert L.fot_timeline_read(raw.ctypes.data, raw.size) == 0
     t = raw.reshape(-1, 4).astype(np.int64)
+    if hasattr(L, "fot_timeline_read_clock"):                              # in-kernel shader clock of the wave loops
+        ck = np.zeros(2 * 16384, dtype=np.uint64)
+        L.fot_timeline_read_clock.argtypes = [C.c_void_p, C.c_int]
+        if L.fot_timeline_read_clock(ck.ctypes.data, ck.size) == 0:
+            ck = ck.reshape(-1, 2).astype(np.int64)
+            okc = (t[:, 2] > t[:, 1]) & (ck[:, 1] > ck[:, 0])
+            ghz = (ck[okc, 1] - ck[okc, 0]) / ((t[okc, 2] - t[okc, 1]) * 10.0)          # cycles per ns (100 MHz ticks)
+            print(f"in-kernel shader clock over the wave loops: median {np.median(ghz):.3f} GHz "
+                  f"(p5 {np.percentile(ghz, 5):.3f}, p95 {np.percentile(ghz, 95):.3f})")
     n_waves = int(np.nonzero(t[:, 2])[0].max()) + 1
     n_waves = (n_waves + WPB - 1) // WPB * WPB
     t = t[:n_waves]

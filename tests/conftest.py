@@ -26,6 +26,14 @@ def pytest_sessionstart(session):
         subprocess.run(["make", "-C", os.path.join(ROOT, "integrated_path_planning_amd", "csrc")], check=True)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        import eps_band
+        eps_band.dump(ROOT)
+    except Exception:
+        pass
+
+
 def golden_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 

@@ -1,0 +1,67 @@
+"""Epsilon-band bookkeeping of the GPU parity tests.
+
+Status tables are asserted EQUAL to the reference's / the oracle's.  On top of that every table check records, per
+group of decisions, how close the nearest candidate came to a threshold (fot_debug_margins): the smallest relative
+margin seen over all goldens and fuzz seeds is written to gpurun_out/eps_band_report.json at the end of the session and
+printed.  A status that differs while every margin of that candidate is > EPS_BAND is a logic error and fails; a
+difference inside the band would be a legitimate float64 re-association flip (none has been observed)."""
+import json
+import os
+
+import numpy as np
+
+from integrated_path_planning_amd import _abi
+
+EPS_BAND = 1e-9
+_min = {name: [np.inf, ""] for name in _abi.MARGIN_NAMES}
+_stats = {"instances": 0, "candidates": 0, "status_differences": 0, "differences_inside_band": 0}
+
+
+def check_status_table(bp, inst, got, want, label):
+    """`got` / `want`: per-candidate status arrays of instance `inst` of bp's last plan call."""
+    got = np.asarray(got)
+    want = np.asarray(want).astype(got.dtype)
+    m = bp.margins(inst)
+    assert m.shape[0] == len(got), label
+    _stats["instances"] += 1
+    _stats["candidates"] += len(got)
+    for g, name in enumerate(_abi.MARGIN_NAMES):
+        col = m[:, g]
+        if len(col) and np.nanmin(col) < _min[name][0]:
+            _min[name] = [float(np.nanmin(col)), f"{label} cand {int(np.nanargmin(col))}"]
+    diff = np.flatnonzero(got != want)
+    if len(diff):
+        _stats["status_differences"] += len(diff)
+        worst = m[diff].min(axis=1)
+        inside = worst <= EPS_BAND
+        _stats["differences_inside_band"] += int(inside.sum())
+        bad = diff[~inside]
+        assert len(bad) == 0, (f"{label}: {len(bad)} candidate(s) differ in status although no decision is within "
+                               f"{EPS_BAND:g} of a threshold, e.g. cand {bad[0]}: got {got[bad[0]]} want {want[bad[0]]} "
+                               f"margins {dict(zip(_abi.MARGIN_NAMES, m[bad[0]]))}")
+    np.testing.assert_array_equal(got, want, err_msg=label)      # equality is still the bar
+
+
+def report():
+    if not _stats["instances"]:
+        return None
+    return {"eps_band": EPS_BAND, **_stats,
+            "min_relative_margin": {k: {"margin": v[0], "where": v[1]} for k, v in _min.items()}}
+
+
+def dump(root):
+    r = report()
+    if r is None:
+        return
+    out = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "eps_band_report.json"), "w") as f:
+            json.dump(r, f, indent=1)
+    except OSError:
+        pass
+    print("\neps-band report (smallest relative distance to a threshold, per decision group):")
+    for k, v in r["min_relative_margin"].items():
+        print(f"  {k:12s} {v['margin']:.3e}   {v['where']}")
+    print(f"  instances {r['instances']}, candidates {r['candidates']}, status differences {r['status_differences']}"
+          f" (inside the {EPS_BAND:g} band: {r['differences_inside_band']})")
