@@ -64,7 +64,7 @@ struct Workspace {
     hipEvent_t done = nullptr;               // this lane's part of the current call has been enqueued up to here
     bool staging_pending = false;
     PinnedBuf staging;
-    DevBuf dMeta;                            // InstDesc[] | wave_inst[] | wave_base[]
+    DevBuf dMeta;                            // InstDesc[]
     DevBuf dState;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
     DevBuf dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: culled entry lists + per-wave chunk ranges
@@ -100,6 +100,8 @@ struct fot_handle {
     DevBuf dP;
     HostSpline spline;
     DevBuf dSpline;
+    TileShapes shapes;                       // tile table (host copy) ...
+    DevBuf dShapes;                          // ... and in HBM: cand0[] | n[]
     bool has_path = false;
     Workspace ws[FOT_LANES];
     int lanes_cfg = 1;                       // sub-batches a large batch is split into
@@ -225,15 +227,14 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
 {
     BatchLayout &L = w.last;
     std::string err;
-    int rc = build_batch_layout(h->params, h->P, b, L, err);
+    int rc = build_batch_layout(h->params, h->P, h->shapes, b, L, err);
     if (rc != FOT_OK) return fail(h, rc, err);
     if (L.n_inst == 0) return FOT_OK;
 
     // --- staging: the descriptors in a pinned block (k_frenet_state pulls them into HBM; the wave maps behind them in
     //     dMeta are written on the device)
     const size_t desc_bytes = align256(sizeof(InstDesc) * (size_t)L.n_inst);
-    const size_t map_bytes = align256(sizeof(int32_t) * (size_t)L.n_waves);
-    const size_t meta_bytes = desc_bytes + 2 * map_bytes;
+    const size_t meta_bytes = desc_bytes;
     if (w.staging_pending) { HIP_TRY(h, hipEventSynchronize(w.staging_done)); w.staging_pending = false; }
     HIP_TRY(h, w.staging.ensure(desc_bytes));
     char *stg = (char *)w.staging.p;
@@ -254,14 +255,16 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
     HIP_TRY(h, w.dEnt64.ensure(sizeof(d2) * n_ent));
     HIP_TRY(h, w.dEntSid.ensure(n_ent));
-    HIP_TRY(h, w.dWaveRng.ensure(sizeof(uint32_t) * (size_t)P.n_total * (size_t)std::max(L.n_waves, 1)));
+    HIP_TRY(h, w.dWaveRng.ensure(sizeof(uint32_t) * (size_t)P.n_total * (size_t)std::max(L.n_tiles, 1)));
 
     // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
     w.staging_pending = true;
 
     const InstDesc *d_desc = (const InstDesc *)w.dMeta.p;
-    const int32_t *d_wave_inst = (const int32_t *)((char *)w.dMeta.p + desc_bytes);
-    const int32_t *d_wave_base = (const int32_t *)((char *)w.dMeta.p + desc_bytes + map_bytes);
+    TileTable tt;
+    tt.cand0 = h->dShapes.as<int32_t>();
+    tt.n = h->dShapes.as<int32_t>() + h->shapes.cand0.size();
+    tt.n_tiles = L.n_tiles; tt.max_tiles = L.max_tiles; tt.row_budget = L.row_budget;
     const DevParams *dP = h->dP.as<DevParams>();
     const SplineView sv = spline_view(h);
     CandArrays ca;
@@ -276,25 +279,17 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
         MetaImport imp;
         imp.h_desc = (const InstDesc *)stg;
         imp.d_desc = (InstDesc *)w.dMeta.p;
-        imp.d_wave_inst = (int32_t *)((char *)w.dMeta.p + desc_bytes);
-        imp.d_wave_base = (int32_t *)((char *)w.dMeta.p + desc_bytes + map_bytes);
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, st));
         HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
     if (L.any_obstacles) {
         ProfScope ps(h, 1, st);
         LAUNCH_TRY(h, launch_cull(dP, d_desc, w.dState.as<InstState>(), L.n_inst, P.n_total, sv,
-                                  d_static, d_dyn, b.obstacle_dtype, ea, st));
+                                  d_static, d_dyn, b.obstacle_dtype, ea, tt, st));
     }
     {
         ProfScope ps(h, 2, st);
-        // every instance with the same number of waves: k_evaluate may reorder its workgroups (longest first)
-        const InstDesc *hd = (const InstDesc *)stg;
-        int uniform = L.n_inst;
-        for (int i = 0; i < L.n_inst && uniform; ++i)
-            if (hd[i].n_waves != hd[0].n_waves || hd[i].wave0 != i * hd[0].n_waves) uniform = 0;
-        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total,
-                                      d_wave_inst, d_wave_base, L.n_waves, uniform, ea, ca, st));
+        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, L.n_inst, tt, ea, ca, st));
     }
     {
         ProfScope ps(h, 3, st);
@@ -427,6 +422,17 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     }
     if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemcpy(h->dP.p, &h->P, sizeof(DevParams), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    build_tile_shapes(h->P, h->shapes);
+    {
+        const size_t nt = h->shapes.cand0.size();
+        if ((e = h->dShapes.ensure(sizeof(int32_t) * 2 * std::max<size_t>(nt, 1))) != hipSuccess) return bail(e, "hipMalloc");
+        if (nt) {
+            if ((e = hipMemcpy(h->dShapes.p, h->shapes.cand0.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
+                return bail(e, "hipMemcpy");
+            if ((e = hipMemcpy(h->dShapes.as<int32_t>() + nt, h->shapes.n.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
+                return bail(e, "hipMemcpy");
+        }
+    }
     *out = h;
     return FOT_OK;
 }
@@ -438,7 +444,7 @@ void fot_destroy(fot_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->order_valid) (void)hipEventSynchronize(h->order_done);   // work enqueued on a caller's stream
     for (Workspace &w : h->ws) if (w.stream) (void)hipStreamSynchronize(w.stream);
-    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
+    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dShapes, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
@@ -695,7 +701,7 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
     // extents of the caller's obstacle arrays
     BatchLayout probe;
     std::string err;
-    int rc = build_batch_layout(h->params, h->P, *batch, probe, err);
+    int rc = build_batch_layout(h->params, h->P, h->shapes, *batch, probe, err);
     if (rc != FOT_OK) return fail(h, rc, err);
     const size_t elem = batch->obstacle_dtype == FOT_F32 ? sizeof(float) : sizeof(double);
     HIP_TRY(h, hipSetDevice(h->device));
@@ -852,7 +858,7 @@ int check_ext(fot_handle *h, int mode, int32_t n_paths, const int32_t *len, cons
     b.static_xy = static_xy; b.static_off = soff; b.dyn_xy = dyn; b.dyn_off = doff; b.dyn_dims = dims;
     BatchLayout L;
     std::string err;
-    int rc = build_batch_layout(h->params, P, b, L, err);
+    int rc = build_batch_layout(h->params, P, h->shapes, b, L, err);
     if (rc != FOT_OK) return fail(h, rc, err);
     h->last_valid = false;
 

@@ -18,24 +18,30 @@ struct EntryArrays {
     f2 *e32;           // instance-local float32 coordinates
     d2 *e64;           // exact coordinates
     uint8_t *sid;      // prediction sample of the entry, SID_STATIC for static obstacles
-    uint32_t *rng;     // [n_waves][n_total] chunk range of each candidate wave: c_lo << 16 | c_hi
+    uint32_t *rng;     // [n_tiles][n_total] chunk range of each tile: c_lo << 16 | c_hi
 };
 
 // descriptors still in pinned host memory, to be moved into HBM by k_frenet_state (h_desc == nullptr: already there)
 struct MetaImport {
     const InstDesc *h_desc = nullptr;
     InstDesc *d_desc = nullptr;
-    int32_t *d_wave_inst = nullptr, *d_wave_base = nullptr;
+};
+
+// The handle's tile table in HBM (built once per handle, one run per terminal-speed grid size = lattice shape):
+// tile t of an instance = candidates [cand0[shape_off + t], + n[shape_off + t]).  n_tiles / max_tiles: of the batch.
+struct TileTable {
+    const int32_t *cand0 = nullptr, *n = nullptr;
+    int n_tiles = 0, max_tiles = 0, row_budget = 0;
 };
 
 // every launcher returns 0 or the hipError_t of the launch
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         MetaImport imp, hipStream_t st);
 int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
-                SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
+                SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, TileTable tiles,
                 hipStream_t st);
-int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total, const int32_t *wave_inst,
-                    const int32_t *wave_base, int n_waves, int uniform_n_inst, EntryArrays e, CandArrays c, hipStream_t st);
+int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,
+                    int n_inst, TileTable tiles, EntryArrays e, CandArrays c, hipStream_t st);
 int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state,
                   SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state,

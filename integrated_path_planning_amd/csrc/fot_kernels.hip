@@ -6,11 +6,12 @@
 //   k_cull         : 8 waves / (instance, 8 consecutive time steps): derives and merges the boxes of the instance's
 //                    longitudinal profiles, sorts the obstacles of those time rows that lie inside the grown boxes
 //                    into per-step entry lists (strips, LDS atomics), writes each candidate wave's chunk range
-//   k_evaluate     : 1 lane / candidate, 4 waves / workgroup: the workgroup builds the rows of its profiles in LDS;
-//                    quintic, Frenet->Cartesian, cost, truncation, kinematic checks, and -- while the candidate can
-//                    still pass -- the collision test of each sample against the entry list of its time step
-//                    (wave-uniform chunk walk on scalar loads, float32 bounds, float64 only between them).
-//                    Candidate points never leave registers.
+//   k_evaluate     : 1 wave / TILE (up to 64 consecutive candidates of one instance, at most three full-length
+//                    profiles), 1 lane / candidate, tiles dealt out longest first: the wave builds the rows of its
+//                    tile's profiles in its own slice of LDS, then: quintic, Frenet->Cartesian, cost,
+//                    truncation, kinematic checks, and -- while the candidate can still pass -- the collision test of
+//                    each sample against the entry list of its time step (wave-uniform chunk walk on scalar loads,
+//                    float32 bounds, float64 only between them).  Candidate points never leave registers.
 //   k_select       : 4 waves / instance: stop-distance filter, rejection histogram, first-minimum argmin (lowest index
 //                    wins ties), selected path rebuilt from its profile and written out
 #include <hip/hip_runtime.h>
@@ -47,6 +48,12 @@ __device__ __forceinline__ float dpp_f32(float v)
     }
 FOT_WAVE_REDUCE_F32(wave_min_f32, fminf)
 FOT_WAVE_REDUCE_F32(wave_max_f32, fmaxf)
+
+// id (0..7) of the XCD this wave runs on: HW_REG_XCC_ID, bits [3:0]  (speed only: which L2 holds an instance's lists)
+__device__ __forceinline__ int xcc_id()
+{
+    return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u);
+}
 
 // ---------------------------------------------------------------------------
 // ego -> Frenet state
@@ -158,7 +165,7 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
     static_assert(sizeof(InstDesc) % sizeof(unsigned long long) == 0, "InstDesc is copied in 8-byte words");
     if (imp.h_desc) {
         // First kernel of a plan call: the descriptors still sit in the caller-side pinned staging block.  Every
-        // workgroup moves its own instance's descriptor into HBM and writes its slice of the wave map for the kernels that follow
+        // workgroup moves its own instance's descriptor into HBM for the kernels that follow
         // (instead of a separate H2D copy in front of the launch sequence) and works from the staging copy itself.
         desc = imp.h_desc;
         const unsigned long long *src = (const unsigned long long *)&desc[inst];
@@ -168,11 +175,6 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
             ((unsigned long long *)&s_desc)[threadIdx.x] = v;
         }
         __syncthreads();
-        const int w0 = s_desc.wave0, nw = s_desc.n_waves;       // wave w0 + i of the batch = candidates 64 i .. of inst
-        for (int i = threadIdx.x; i < nw; i += FRENET_WG) {
-            imp.d_wave_inst[w0 + i] = inst;
-            imp.d_wave_base[w0 + i] = i * WAVE;
-        }
     } else {
         if (threadIdx.x < DESC_WORDS)
             ((unsigned long long *)&s_desc)[threadIdx.x] = ((const unsigned long long *)&desc[inst])[threadIdx.x];
@@ -329,14 +331,17 @@ __device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float 
 // the point of use instead of occupying scalar registers across the time-step loop.
 struct EvalKernArgs {
     const DevParams *Pp; SplineView sp; const InstDesc *desc; const InstState *state;
-    int lds_profiles, lds_knots, ablate, perm_n_inst, perm_nb;
-    const int32_t *wave_inst, *wave_base; int n_waves;
+    int row_budget, lds_knots, ablate, n_inst, max_tiles;
+    const int32_t *tile_cand0, *tile_n;
     const uint32_t *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
     double *cand_cost, *cand_vlast, *cand_travel; uint8_t *cand_status, *cand_keep;
 };
+// k_evaluate's argument segment: EVAL_LEAD_PTRS read-only pointers (passed on their own so that they carry
+// `__restrict__`: only no-alias inputs are certain to keep their loads on the scalar unit), then this struct
+constexpr int EVAL_LEAD_PTRS = 7;
 __device__ __forceinline__ const EvalKernArgs &eval_kernargs()
 {
-    return *(const EvalKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const EvalKernArgs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + EVAL_LEAD_PTRS * sizeof(void *));
 }
 
 struct FusedSink {
@@ -442,61 +447,68 @@ struct FusedSink {
     __device__ __forceinline__ bool collided() const { return hit; }
 };
 
-// Longitudinal rows of the block's candidates in LDS: the 64 candidates of a wave share two or three longitudinal
-// profiles.  Layout [profile][k][field], 9 fields = 72 contiguous bytes per row (the arc length s is not in the row:
-// only the low-speed rule and the travelled distance read it, and they rebuild it from the profile's polynomial).
+// Longitudinal rows of a tile's profiles in the wave's own slice of LDS: the 64 candidates of a tile share two or
+// three longitudinal profiles (seven short ones in the brake-ladder tile).  Per profile a run of rows [k][field],
+// 9 fields = 72 contiguous bytes per row (the arc length s is not in the row: only the low-speed rule and the
+// travelled distance read it, and they rebuild it from the profile's polynomial); a profile's run holds
+// profile_rows() rows and lanes clamp their row index to it (the last row of a brake-ladder profile is its hold).
 constexpr int EVAL_WG = WAVES_PER_GROUP * WAVE;
-constexpr int EVAL_LDS_BYTES = 54400;                             // three workgroups per CU within 160 KB of LDS
-constexpr int EVAL_LDS_PROFILES_MAX = 16;
 extern __shared__ double s_lon[];
 
 constexpr int ROW_FIELDS = 9;
+constexpr int LONINFO_DOUBLES = (int)(sizeof(LonInfo) / sizeof(double));
+static_assert(sizeof(LonInfo) % sizeof(double) == 0, "LonInfo sits in the double-typed LDS array");
+// doubles of LDS per wave: rows | profile summaries | row offsets of the profiles (ints)
+__host__ __device__ constexpr int eval_wave_doubles(int row_budget)
+{
+    return row_budget * ROW_FIELDS + TILE_MAX_PROFILES * LONINFO_DOUBLES + TILE_MAX_PROFILES / 2;
+}
 
 struct StagedTab {
-    int lds_row0;                        // index of this lane's profile row 0 in s_lon, or -1: not staged
-    int slot;                            // lanes outside the block's window rebuild the rows of their profile on the
-    const DevParams *Pp;                 //   spot, from the instance's state (nothing of it stays in registers
-    const InstDesc *Dp;                  //   across the loop)
-    const double *fr;
-    const SplineView *spp;               // the kernel's own argument block: nine pointers that only the fall-back reads
+    int lds_row0;                        // index of this lane's profile row 0 in s_lon
+    int k_max;                           // last row of the run (grid: n_t - 1; brake ladder: the hold row n_eval)
     double dt;
+#ifdef FOT_TIMELINE
+    mutable uint64_t t_rows = 0;         // shader cycles between issuing the row reads and having them (diagnostic)
+#endif
     __device__ __forceinline__ void load(int k, LonSample &L) const
     {
-        if (lds_row0 >= 0) {
-            const double *r = s_lon + lds_row0 + k * ROW_FIELDS;
-            L.s = 0.0; L.sd = r[0]; L.sdd = r[1]; L.rx = r[2]; L.ry = r[3];
-            L.cos_r = r[4]; L.sin_r = r[5]; L.kr = r[6]; L.dkr = r[7]; L.inv_sd = r[8];
-        } else {
-            ComputeTab direct;
-            direct.sp = *spp; direct.L = profile_info(*Pp, *Dp, fr, slot, false); direct.dt = dt;
-            direct.load(k, L);
-        }
+#ifdef FOT_TIMELINE
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#endif
+        const int kk = k < k_max ? k : k_max;
+        const double *r = s_lon + lds_row0 + kk * ROW_FIELDS;
+        L.s = 0.0; L.sd = r[0]; L.sdd = r[1]; L.rx = r[2]; L.ry = r[3];
+        L.cos_r = r[4]; L.sin_r = r[5]; L.kr = r[6]; L.dkr = r[7]; L.inv_sd = r[8];
         // the row is in registers from here on: what follows (the sink's scalar warm-up loads) must not sit
         // between these reads and the wait for them
         asm volatile("" : "+v"(L.sd), "+v"(L.sdd), "+v"(L.rx), "+v"(L.ry), "+v"(L.cos_r), "+v"(L.sin_r),
                           "+v"(L.kr), "+v"(L.dkr), "+v"(L.inv_sd));
+#ifdef FOT_TIMELINE
+        t_rows += __builtin_amdgcn_s_memtime() - t0;
+#endif
     }
     // arc length s(t_k): asked for by the low-speed rules only (a few percent of the samples, but every eighth time
-    // step of a wave has such a lane) -- staged lanes re-read their profile's coefficients from the block's summaries
-    const LonInfo *info;                 // in LDS, nullptr: not staged
+    // step of a wave has such a lane) -- lanes re-read their profile's coefficients from the tile's summaries
+    const LonInfo *info;                 // in LDS
     __device__ __forceinline__ double s_at(int k) const
     {
         double s_, u0, u1, u2;
-        if (info) {
-            lon_sample(*info, k, dt, s_, u0, u1, u2);
-        } else {
-            const LonInfo Ld = profile_info(*Pp, *Dp, fr, slot, false);
-            lon_sample(Ld, k, dt, s_, u0, u1, u2);
-        }
+        lon_sample(*info, k, dt, s_, u0, u1, u2);
         return s_;
     }
 };
 
 #ifdef FOT_TIMELINE
-// diagnostic build (scripts/timeline.sh): per wave of the last k_evaluate launch -- workgroup start, wave start
-// (after the LDS prologue), wave end on the 100 MHz clock, and the chunks its strip ranges cover
+// diagnostic build (scripts/timeline.sh): per tile of the last k_evaluate launch -- tile start, start of the sample
+// loop (after the LDS rows are built), tile end on the 100 MHz clock, and the chunks its strip ranges cover
 __device__ uint64_t g_timeline[4 * 16384];
-__device__ uint64_t g_shader_clock[2 * 16384];     // s_memtime at wave start / end: shader cycles (in-kernel clock)
+__device__ uint64_t g_shader_clock[2 * 16384];     // s_memtime at loop start / end: shader cycles (in-kernel clock)
+__device__ uint64_t g_row_wait[16384];             // shader cycles lane 0 spent between issuing and having its LDS rows
+extern "C" int fot_timeline_read_rows(uint64_t *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_wait), sizeof(uint64_t) * (size_t)n_words);
+}
 extern "C" int fot_timeline_read(uint64_t *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(uint64_t) * (size_t)n_words);
@@ -507,141 +519,161 @@ extern "C" int fot_timeline_read_clock(uint64_t *out, int n_words)
 }
 #endif
 
-__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_evaluate(const EvalKernArgs a)
+// this wave's LDS writes (other lanes') before the reads that follow, and the reads before the next writes
+__device__ __forceinline__ void wave_lds_fence()
 {
-    // (the struct is the whole argument segment, so eval_kernargs() addresses exactly these fields)
-    const DevParams *__restrict__ Pp = a.Pp;
-    const SplineView sp = a.sp;
-    const InstDesc *__restrict__ desc = a.desc;
-    const InstState *__restrict__ state = a.state;
-    const int lds_profiles = a.lds_profiles, lds_knots = a.lds_knots, ablate = a.ablate;
-    const int perm_n_inst = a.perm_n_inst, perm_nb = a.perm_nb, n_waves = a.n_waves;
-    const int32_t *__restrict__ wave_inst = a.wave_inst, *__restrict__ wave_base = a.wave_base;
-    const uint32_t *__restrict__ wave_rng = a.wave_rng;
-    const f2 *__restrict__ ent32 = a.ent32;
-    uint8_t *__restrict__ cand_status = a.cand_status, *__restrict__ cand_keep = a.cand_keep;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One tile: rows of its profiles into the wave's LDS slice, then one candidate per lane.
+__device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
+                                              const InstState *__restrict__ state,
+                                              const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+                                              const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32,
+                                              const EvalKernArgs &a, const SplineView &sp_lds,
+                                              double *my_rows, int inst, int tile, int lane, int tl_tag)
+{
     const DevParams &P = *Pp;
+    const InstDesc &D = desc[inst];
+    const InstState &S = state[inst];
     const int n_total = P.n_total;
-    // --- the rows of the profiles [slot_lo, slot_lo + n_stage) of the block's instance, built straight into LDS (no
-    //     table in HBM): slot_lo is the profile of the block's first candidate; a block never spans two instances
-    // uniform batches: workgroups in (position inside the instance, descending) x (instance) order -- the long
-    // horizons and the brake ladder first, the short horizons in the last round; an instance stays on one XCD
+    const int cand0 = tile_cand0[D.shape_off + tile];
+    int n = tile_n[D.shape_off + tile];
+    if (!S.c2f_ok || cand0 >= S.n_cand) return;                 // (the brake ladder of a standing ego)
+    if (cand0 + n > S.n_cand) n = S.n_cand - cand0;
 #ifdef FOT_TIMELINE
     const uint64_t t_blk = __builtin_amdgcn_s_memrealtime();
 #endif
-    int blk = blockIdx.x;
-    if (perm_nb > 0) {
-        const int pos = blk / perm_n_inst, i = blk - pos * perm_n_inst;
-        blk = i * perm_nb + (perm_nb - 1 - pos);
+    LonInfo *s_info = (LonInfo *)(my_rows + a.row_budget * ROW_FIELDS);
+    int *s_row0 = (int *)(s_info + TILE_MAX_PROFILES);
+    // profiles of the tile's first .. last candidate (slots grow with the candidate index)
+    const int slot_lo = decode_candidate(P, D, S.frenet0, cand0).lon_slot;
+    const int n_stage = decode_candidate(P, D, S.frenet0, cand0 + n - 1).lon_slot - slot_lo + 1;
+    wave_lds_fence();                                           // the previous tile's rows are no longer read
+    int total_rows = 0, n_loop = 0;
+    for (int p = 0; p < n_stage; ++p) {                         // wave-uniform: a handful of scalar operations
+        const int r = profile_rows(P, D, slot_lo + p);
+        if (lane == p) s_row0[p] = total_rows;
+        total_rows += r;
     }
-    const int wave_first = blk * (EVAL_WG / WAVE);
-    int slot_lo = 0, n_stage = 0;
-    const int inst0 = wave_inst[wave_first];                      // wave_first < n_waves by construction of the grid
-    const InstDesc &D0 = desc[inst0];
-    const InstState &S0 = state[inst0];
-    {
-        const int idx0 = wave_base[wave_first];
-        if (S0.c2f_ok && idx0 < S0.n_cand) {
-            // profiles of the block's first .. last candidate (slots grow with the candidate index)
-            const int idx1 = idx0 + EVAL_WG - 1 < S0.n_cand - 1 ? idx0 + EVAL_WG - 1 : S0.n_cand - 1;
-            slot_lo = decode_candidate(P, D0, S0.frenet0, idx0).lon_slot;
-            const int used = decode_candidate(P, D0, S0.frenet0, idx1).lon_slot - slot_lo + 1;
-            n_stage = used < lds_profiles ? used : lds_profiles;
-        }
-    }
-    // LDS: rows [lds_profiles][n_total][ROW_FIELDS] | profile summaries [lds_profiles] | spline
-    LonInfo *s_info = (LonInfo *)(s_lon + lds_profiles * n_total * ROW_FIELDS);
-    const SplineView sp_lds = stage_spline(sp, lds_knots, (double *)(s_info + lds_profiles));
-    if ((int)threadIdx.x < n_stage) s_info[threadIdx.x] = profile_info(P, D0, S0.frenet0, slot_lo + threadIdx.x, true);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_stage * n_total; i += EVAL_WG) {
-        const int p = i / n_total, k = i - p * n_total;
+    if (lane < n_stage) s_info[lane] = profile_info(P, D, S.frenet0, slot_lo + lane, true);
+    wave_lds_fence();
+    for (int p = 0; p < n_stage; ++p) { const int nt = s_info[p].n_t; n_loop = nt > n_loop ? nt : n_loop; }
+    n_loop = __builtin_amdgcn_readfirstlane(n_loop);
+    for (int i = lane; i < total_rows; i += WAVE) {
+        int p = 0;
+        for (int pp = 1; pp < n_stage; ++pp) p = i >= s_row0[pp] ? pp : p;
+        const int k = i - s_row0[p];
         const LonInfo Lp = s_info[p];
-        if (k < Lp.n_t) {
-            LonSample ls;
-            double sddd;
-            make_lon_sample(sp_lds, Lp, k, P.dt, ls, sddd);
-            double *r = s_lon + (p * n_total + k) * ROW_FIELDS;
-            r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx; r[3] = ls.ry;
-            r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
-        }
+        LonSample ls;
+        double sddd;
+        make_lon_sample(sp_lds, Lp, k, P.dt, ls, sddd);         // (k == n_eval of a brake profile: its hold state)
+        double *r = my_rows + (int64_t)i * ROW_FIELDS;
+        r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx; r[3] = ls.ry;
+        r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
     }
-    __syncthreads();
+    wave_lds_fence();
 
-    // wave index through readfirstlane: everything derived from it (instance, descriptor) is wave-uniform -> SGPRs
-    const int wave = __builtin_amdgcn_readfirstlane((int)(wave_first + (threadIdx.x / WAVE)));
-    if (wave >= n_waves) return;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int inst = wave_inst[wave];
-    const InstDesc &D = desc[inst];
-    const InstState &S = state[inst];
-    const int idx = wave_base[wave] + lane;                    // candidate index inside the instance
-    const int64_t slot = (int64_t)D.cand_off + idx;
-    const bool live = S.c2f_ok && idx < S.n_cand;
     // lane k holds the strip range of time step k (read back with v_readlane): loaded while every lane of the
-    // wave is still active, padding lanes included
-    const uint32_t my_rng = D.ent_cap != 0 && lane < n_total && !(ablate & 1) ? wave_rng[(int64_t)wave * n_total + lane] : 0u;
+    // wave is still active, lanes without a candidate included
+    const uint32_t my_rng = D.ent_cap != 0 && lane < n_total && !(a.ablate & 1)
+                                ? wave_rng[(int64_t)(D.tile0 + tile) * n_total + lane] : 0u;
 #ifdef FOT_TIMELINE
     const uint64_t t_wave = __builtin_amdgcn_s_memrealtime();
     const uint64_t c_wave = __builtin_amdgcn_s_memtime();
-    const int tl_wave = blockIdx.x * (EVAL_WG / WAVE) + (threadIdx.x / WAVE);          // in dispatch order
+    const int tl_wave = D.tile0 + tile;
+    uint64_t tl_rows = 0;
     int tl_chunks = (int)(my_rng & 0xffffu) - (int)(my_rng >> 16);
     for (int o = 32; o > 0; o >>= 1) tl_chunks += __shfl_xor(tl_chunks, o);
 #endif
-    if (!live) {                                               // padding lane: never counted
-        cand_status[slot] = 255;
-        cand_keep[slot] = 0;
-        return;
-    }
-    const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
-    const bool staged = (unsigned)(cd.lon_slot - slot_lo) < (unsigned)n_stage;
-    const LonInfo L = staged ? s_info[cd.lon_slot - slot_lo] : profile_info(P, D, S.frenet0, cd.lon_slot, true);
-    StagedTab tab;
-    tab.lds_row0 = staged ? (cd.lon_slot - slot_lo) * n_total * ROW_FIELDS : -1;
-    tab.info = staged ? s_info + (cd.lon_slot - slot_lo) : nullptr;
-    tab.slot = cd.lon_slot; tab.Pp = Pp; tab.Dp = &D; tab.fr = S.frenet0; tab.dt = P.dt;
-    tab.spp = &eval_kernargs().sp;
-    double q[6];
-    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
-    // q[0..2] are the instance's lateral state (wave-uniform): as scalar values they end up in spilled SGPRs and come
-    // back through v_readlane in every time step -- three vector registers are cheaper
-    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
+    if (lane < n) {
+        const int idx = cand0 + lane;                            // candidate index inside the instance
+        const int64_t slot = (int64_t)D.cand_off + idx;
+        const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
+        const int p = cd.lon_slot - slot_lo;
+        const LonInfo L = s_info[p];
+        StagedTab tab;
+        tab.lds_row0 = (int)(my_rows - s_lon) + s_row0[p] * ROW_FIELDS;
+        tab.k_max = profile_rows(P, D, cd.lon_slot) - 1;
+        tab.info = s_info + p;
+        tab.dt = P.dt;
+        double q[6];
+        lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+        // q[0..2] are the instance's lateral state (wave-uniform): as scalar values they end up in spilled SGPRs and
+        // come back through v_readlane in every time step -- three vector registers are cheaper
+        asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
 
-    FusedSink sink;
-    sink.Pp = Pp; sink.Dp = &D;
-    sink.my_rng = my_rng;
-    sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
-    sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
-    sink.oxd = D.ego.x; sink.oyd = D.ego.y;
-    const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-    sink.fc = filter_const(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
-    sink.any_fatal = D.max_viol == 0;
-    sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0; sink.no_warm = (ablate & 2) != 0;
-    // loop constants as opaque register values: the compiler then keeps (or lane-spills) them instead of
-    // re-fetching each one from the parameter blocks, behind a scalar-memory wait, in every time step
-    LoopConst lc = loop_const(P, D);
-    lc.dt = uniform_f64(lc.dt); lc.lim_speed = uniform_f64(lc.lim_speed); lc.lim_accel = uniform_f64(lc.lim_accel);
-    lc.lim_curv = uniform_f64(lc.lim_curv); lc.lim_lat = uniform_f64(lc.lim_lat);
-    lc.road_lim = uniform_f64(lc.road_lim);                    // (wherever the compiler had put them)
-    lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
-    asm volatile("" : "+s"(lc.n_circ_fp));
-    CandResult r;
-    evaluate_candidate(P, D, lc, L, tab, q, n_total, sink, r);
-    const EvalKernArgs &KA = eval_kernargs();
-    KA.cand_cost[slot] = r.cost;
-    KA.cand_vlast[slot] = r.v_last;
-    KA.cand_travel[slot] = r.travel;
-    KA.cand_status[slot] = (uint8_t)r.status;
-    KA.cand_keep[slot] = (uint8_t)r.keep;
+        FusedSink sink;
+        sink.Pp = Pp; sink.Dp = &D;
+        sink.my_rng = my_rng;
+        sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
+        sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
+        sink.oxd = D.ego.x; sink.oyd = D.ego.y;
+        const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+        sink.fc = filter_const(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
+        sink.any_fatal = D.max_viol == 0;
+        sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
+        sink.no_warm = (a.ablate & 2) != 0;
+        // loop constants as opaque register values: the compiler then keeps (or lane-spills) them instead of
+        // re-fetching each one from the parameter blocks, behind a scalar-memory wait, in every time step
+        LoopConst lc = loop_const(P, D);
+        lc.dt = uniform_f64(lc.dt); lc.lim_speed = uniform_f64(lc.lim_speed); lc.lim_accel = uniform_f64(lc.lim_accel);
+        lc.lim_curv = uniform_f64(lc.lim_curv); lc.lim_lat = uniform_f64(lc.lim_lat);
+        lc.road_lim = uniform_f64(lc.road_lim);                 // (wherever the compiler had put them)
+        lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
+        asm volatile("" : "+s"(lc.n_circ_fp));
+        CandResult r;
+        evaluate_candidate(P, D, lc, L, tab, q, n_loop, sink, r);
+        const EvalKernArgs &KA = eval_kernargs();
+        KA.cand_cost[slot] = r.cost;
+        KA.cand_vlast[slot] = r.v_last;
+        KA.cand_travel[slot] = r.travel;
+        KA.cand_status[slot] = (uint8_t)r.status;
+        KA.cand_keep[slot] = (uint8_t)r.keep;
 #ifdef FOT_TIMELINE
-    if (tl_wave < 16384 && lane == __ffsll((unsigned long long)__ballot(1)) - 1) {
+        tl_rows = tab.t_rows;
+#endif
+    }
+#ifdef FOT_TIMELINE
+    tl_rows = (uint64_t)__shfl((unsigned long long)tl_rows, 0);
+    if (tl_wave < 16384 && lane == 0) {
         g_timeline[tl_wave * 4 + 0] = t_blk; g_timeline[tl_wave * 4 + 1] = t_wave;
         g_timeline[tl_wave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-        g_timeline[tl_wave * 4 + 3] = (uint64_t)tl_chunks;
+        g_timeline[tl_wave * 4 + 3] = (uint64_t)(uint32_t)tl_chunks | ((uint64_t)(uint32_t)tl_tag << 32);
         g_shader_clock[tl_wave * 2 + 0] = c_wave; g_shader_clock[tl_wave * 2 + 1] = __builtin_amdgcn_s_memtime();
+        g_row_wait[tl_wave] = tl_rows;
     }
 #endif
+}
+
+// One wave per tile.  The grid deals the tiles out position-major and XCD-aligned: workgroup b serves the instances
+// x, x + 8, ... with x = b mod 8 -- the XCD that, under round-robin placement, also ran k_cull's workgroups for them,
+// so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
+// ladder run longest), so the long tiles start early and the short ones fill the end of the launch.  The waves of a
+// workgroup share nothing but the staged spline: each has its own slice of LDS.
+__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+           const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+           const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
+{
+    // (eval_kernargs() addresses the struct's fields in the argument segment, behind the EVAL_LEAD_PTRS pointers)
+    const int waves_per_wg = (int)blockDim.x / WAVE;
+    const int wave_doubles = eval_wave_doubles(a.row_budget);
+    // LDS: per wave [rows | summaries | row offsets], then the spline (shared by the workgroup's waves)
+    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_lon + waves_per_wg * wave_doubles);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int lane = threadIdx.x & (WAVE - 1);
+    double *my_rows = s_lon + wv * wave_doubles;
+    const int x = (int)blockIdx.x & (N_XCD - 1), q = ((int)blockIdx.x >> 3) * waves_per_wg + wv;
+    const int m_x = (a.n_inst - x + N_XCD - 1) / N_XCD;            // instances x, x + 8, ...
+    if (m_x <= 0 || q >= m_x * a.max_tiles) return;
+    const int pos = q / m_x, j = q - pos * m_x;
+    const int inst = x + N_XCD * j;
+    const int n_tiles = desc[inst].n_tiles;
+    if (pos >= n_tiles) return;                                  // a shorter lattice than the batch's longest
+    evaluate_tile(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst, n_tiles - 1 - pos,
+                  lane, x);
 }
 
 // ---------------------------------------------------------------------------
@@ -654,8 +686,8 @@ k_evaluate(const EvalKernArgs a)
 // boxes of the group's time steps.  Entries of step k: the static obstacles and the dynamic obstacles of time row
 // min(k, T-1) that lie inside the candidates' bounding box of k (merged over the instance's longitudinal profiles)
 // grown by the collision radius, ordered by bin along the longer side of the box (counting sort through LDS
-// atomics), FAR32-padded to chunk pairs.  Then, per candidate wave of the instance, the chunk range its own
-// profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
+// atomics), FAR32-padded to chunk pairs.  Then, per tile of the instance (k_evaluate's unit of work), the chunk range
+// its own profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
 constexpr int CULL_KG = 8;
 constexpr int CULL_LIST = 512;          // kept obstacles per time step remembered between the two passes
 constexpr int CULL_PBOX = 128;          // profiles per instance whose boxes are kept in LDS (more: recomputed)
@@ -666,7 +698,8 @@ __global__ void __launch_bounds__(CULL_KG * WAVE)
 k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
        int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
-       uint32_t *__restrict__ wave_rng, int ablate)
+       uint32_t *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+       int ablate)
 {
     __shared__ int s_cnt[CULL_KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
     __shared__ int s_start[CULL_KG][CULL_BINS + 1];
@@ -776,7 +809,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const float mk = s_margin[kk];
     const bool live_k = bk.x0 <= bk.x1;
     const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
-    uint32_t *rng = wave_rng + (int64_t)D.wave0 * P.n_total + k;                   // + wave * n_total
+    uint32_t *rng = wave_rng + (int64_t)D.tile0 * P.n_total + k;                   // + tile * n_total
     const int count = s_start[kk][CULL_BINS];
     const int row = k < D.T - 1 ? k : D.T - 1;
     auto point = [&](int i, d2 &o, int &sid) {                                      // obstacle i at step k
@@ -827,12 +860,13 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         ent_sid[base + count + lane] = SID_STATIC;
     }
     if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = padded;
-    // chunk range of every candidate wave of the instance
-    for (int w = lane; w < D.n_waves; w += WAVE) {
+    // chunk range of every tile of the instance
+    for (int w = lane; w < D.n_tiles; w += WAVE) {
         uint32_t r = 0u;
-        const int idx0 = w * WAVE;
+        const int idx0 = tile_cand0[D.shape_off + w];
         if (live_k && idx0 < S.n_cand && !(ablate & 1)) {
-            const int idx1 = idx0 + WAVE - 1 < S.n_cand - 1 ? idx0 + WAVE - 1 : S.n_cand - 1;
+            const int last = idx0 + tile_n[D.shape_off + w] - 1;
+            const int idx1 = last < S.n_cand - 1 ? last : S.n_cand - 1;
             int s0, s1;
             wave_profile_span(P, D, n_grid_lon, idx0, idx1, s0, s1);
             Box32 wb = box_empty();
@@ -1233,7 +1267,7 @@ int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc,
 }
 
 int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
-                SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e,
+                SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, TileTable tiles,
                 hipStream_t st)
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
@@ -1243,36 +1277,37 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
     const size_t lds = sizeof(double) * 9 * (size_t)lds_knots;
     if (dtype == FOT_F32)
         k_cull<float><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const float *)static_xy,
-                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, ablate);
+                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0, tiles.n,
+                                             ablate);
     else
         k_cull<double><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const double *)static_xy,
-                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, ablate);
+                                              (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0,
+                                              tiles.n, ablate);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total, const int32_t *wave_inst,
-                    const int32_t *wave_base, int n_waves, int uniform_n_inst, EntryArrays e, CandArrays c, hipStream_t st)
+int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,
+                    int n_inst, TileTable tiles, EntryArrays e, CandArrays c, hipStream_t st)
 {
-    if (n_waves <= 0) return 0;
-    const int wpb = EVAL_WG / WAVE;
-    const size_t per_prof = sizeof(double) * ROW_FIELDS * (size_t)n_total;
-    const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
-    int lds_profiles = (int)((EVAL_LDS_BYTES - sizeof(double) * 9 * (size_t)lds_knots) / (per_prof + sizeof(LonInfo)));
-    if (lds_profiles > EVAL_LDS_PROFILES_MAX) lds_profiles = EVAL_LDS_PROFILES_MAX;
-    const size_t lds = (per_prof + sizeof(LonInfo)) * (size_t)lds_profiles + sizeof(double) * 9 * (size_t)lds_knots;
+    if (tiles.n_tiles <= 0 || n_inst <= 0) return 0;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
-    static const int no_perm = getenv("FOT_EVAL_NOPERM") ? 1 : 0;
-    const int n_blocks = (n_waves + wpb - 1) / wpb;
-    const int perm_nb = uniform_n_inst > 1 && !no_perm && n_blocks % uniform_n_inst == 0 ? n_blocks / uniform_n_inst : 0;
+    const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
+    // four waves per workgroup for batches, one for a handful of egos (a single lattice then spreads over as many CUs
+    // as it has tiles); 8 queues of ceil(n_inst / 8) * max_tiles tiles, `wpw` of them per workgroup
+    const int wpw = tiles.n_tiles >= 1024 ? EVAL_WG / WAVE : 1;
+    const int64_t per_queue = (int64_t)((n_inst + N_XCD - 1) / N_XCD) * tiles.max_tiles;
+    const int64_t n_blocks = (per_queue + wpw - 1) / wpw * N_XCD;
+    if (n_blocks > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
+    const size_t lds = sizeof(double) * ((size_t)eval_wave_doubles(tiles.row_budget) * wpw + 9 * (size_t)lds_knots);
     EvalKernArgs a;
     a.Pp = P; a.sp = sp; a.desc = desc; a.state = state;
-    a.lds_profiles = lds_profiles; a.lds_knots = lds_knots; a.ablate = ablate;
-    a.perm_n_inst = uniform_n_inst; a.perm_nb = perm_nb;
-    a.wave_inst = wave_inst; a.wave_base = wave_base; a.n_waves = n_waves;
+    a.row_budget = tiles.row_budget; a.lds_knots = lds_knots; a.ablate = ablate;
+    a.n_inst = n_inst; a.max_tiles = tiles.max_tiles;
+    a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_vlast = c.v_last; a.cand_travel = c.travel; a.cand_status = c.status; a.cand_keep = c.keep;
-    k_evaluate<<<n_blocks, EVAL_WG, lds, st>>>(a);
+    k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -312,6 +312,56 @@ FOT_HD LonInfo profile_info(const DevParams &P, const InstDesc &D, const double 
 }
 
 // ---------------------------------------------------------------------------
+// tiles: the unit of work of k_evaluate
+// ---------------------------------------------------------------------------
+
+// rows of LDS the profile in `slot` needs: one per sample; a brake-ladder profile holds its last state after n_eval
+// samples, so n_eval rows plus ONE row for the hold (lanes clamp their row index)
+FOT_HD int profile_rows(const DevParams &P, const InstDesc &D, int slot)
+{
+    const int n_grid_lon = P.n_ti * D.n_tv;
+    if (slot < n_grid_lon) return P.ti[slot / D.n_tv].n_t;
+    const int ne = P.brake[slot - n_grid_lon].n_t;
+    return ne < P.n_total ? ne + 1 : ne;
+}
+
+// rows one wave of k_evaluate may stage: three full-length profiles and a little more (the seven brake-ladder entries of
+// the default lattice then share one tile); 12 waves per CU x (rows x 72 B + summaries) stay below the 160 KB of LDS
+FOT_HD int tile_row_budget(int n_total)
+{
+    const int want = 3 * n_total + 8, cap = 176;
+    return want < cap ? want : (cap > n_total ? cap : n_total);
+}
+
+// Tile that starts at candidate `cand0` of an instance: n consecutive candidates (1..64, the candidates of the
+// generation order Ti -> tv -> di, brake ladder last), spanning at most TILE_MAX_PROFILES longitudinal profiles whose
+// rows fit `row_budget`.  Depends on the lattice shape only (planner constants + the instance's terminal-speed grid),
+// so the host (tile counts), k_frenet_state (tile table) and the CPU logic test walk the same sequence.
+FOT_HD int tile_extent(const DevParams &P, const InstDesc &D, int cand0, int row_budget)
+{
+    const int n_grid_lon = P.n_ti * D.n_tv;
+    int n = 0, rows = 0, profs = 0, c = cand0;
+    while (n < WAVE && c < D.n_cand_max && profs < TILE_MAX_PROFILES) {
+        int slot, left;                                   // profile of candidate c, candidates of it from c on
+        if (c < D.n_grid) { slot = c / P.n_di; left = (slot + 1) * P.n_di - c; }
+        else { slot = n_grid_lon + (c - D.n_grid); left = 1; }
+        const int r = profile_rows(P, D, slot);
+        if (profs > 0 && rows + r > row_budget) break;    // (a single profile always fits: row_budget >= n_total)
+        rows += r; ++profs;
+        const int take = left < WAVE - n ? left : WAVE - n;
+        n += take; c += take;
+    }
+    return n;
+}
+
+FOT_HD int count_tiles(const DevParams &P, const InstDesc &D, int row_budget)
+{
+    int t = 0;
+    for (int c = 0; c < D.n_cand_max; ++t) c += tile_extent(P, D, c, row_budget);
+    return t;
+}
+
+// ---------------------------------------------------------------------------
 // Frenet -> Cartesian of one sample
 // (reference: frenet_planner.py:792-799, coordinate_converter.py:128-158)
 // ---------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // fot_setup.hpp -- host-side planning of a batch: lattice dimensions, boundary-value inverses,
-// natural cubic spline fit, per-instance descriptors and the wave -> instance map.
+// natural cubic spline fit, per-instance descriptors and tile counts.
 // Plain C++ (no HIP), shared by libfot.so and the CPU logic tests.
 #pragma once
 
@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fot_types.h"
+#include "fot_math.hpp"
 
 namespace fot {
 
@@ -165,12 +166,42 @@ inline int build_spline(int n, const double *wx, const double *wy, HostSpline &s
 // batch layout
 // ---------------------------------------------------------------------------
 
+// Tile table of a handle: for every terminal-speed grid size n_tv (the one thing besides the planner constants that
+// shapes an instance's lattice) the tiles tile_extent() cuts it into.  Built once per handle, resident in HBM.
+struct TileShapes {
+    int row_budget = 0;
+    std::vector<int32_t> cand0, n;                 // all shapes back to back
+    int32_t off[FOT_MAX_TV + 2] = { 0 };           // shape of n_tv: entries [off[n_tv], off[n_tv + 1])
+    int tiles_of(int n_tv) const { return off[n_tv + 1] - off[n_tv]; }
+};
+
+inline void build_tile_shapes(const DevParams &P, TileShapes &T)
+{
+    T = TileShapes();
+    T.row_budget = tile_row_budget(P.n_total);
+    for (int n_tv = 0; n_tv <= FOT_MAX_TV; ++n_tv) {
+        T.off[n_tv] = (int32_t)T.cand0.size();
+        InstDesc D = InstDesc();
+        D.n_tv = n_tv;
+        D.n_grid = P.n_ti * n_tv * P.n_di;
+        D.n_cand_max = D.n_grid + P.n_brake;
+        if (n_tv == 0) continue;
+        for (int c = 0; c < D.n_cand_max;) {
+            const int n = tile_extent(P, D, c, T.row_budget);
+            T.cand0.push_back(c); T.n.push_back(n);
+            c += n;
+        }
+    }
+    T.off[FOT_MAX_TV + 1] = (int32_t)T.cand0.size();
+}
+
 struct BatchLayout {
     std::vector<InstDesc> desc;
-    std::vector<int32_t> wave_inst, wave_base;
     int n_inst = 0;
-    int n_waves = 0;
-    int64_t n_slots = 0;          // candidate slots (64 per wave)
+    int n_tiles = 0;              // tiles of the whole batch (k_evaluate's units of work: one wave each)
+    int max_tiles = 0;            // most tiles of one instance
+    int row_budget = 0;           // LDS rows per k_evaluate wave the tiles were cut for
+    int64_t n_slots = 0;          // candidate slots (instances padded to multiples of 64)
     int64_t n_lon = 0;            // longitudinal profile slots
     int max_lon = 0;              // max profiles of one instance
     int64_t n_static = 0;         // extent of the caller's static_xy that is referenced (points)
@@ -179,8 +210,8 @@ struct BatchLayout {
     bool any_obstacles = false;
 };
 
-inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fot_batch &b, BatchLayout &L,
-                              std::string &err)
+inline int build_batch_layout(const fot_params &hp, const DevParams &P, const TileShapes &shapes, const fot_batch &b,
+                              BatchLayout &L, std::string &err)
 {
     L = BatchLayout();
     if (b.n_inst < 0) { err = "n_inst < 0"; return FOT_ERR_INVALID; }
@@ -188,6 +219,7 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
     if (b.obstacle_dtype != FOT_F32 && b.obstacle_dtype != FOT_F64) { err = "obstacle_dtype"; return FOT_ERR_INVALID; }
     L.n_inst = b.n_inst;
     L.desc.resize(b.n_inst);
+    L.row_budget = shapes.row_budget;
     for (int i = 0; i < b.n_inst; ++i) {
         InstDesc &D = L.desc[i];
         D = InstDesc();
@@ -218,15 +250,19 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         D.n_grid = P.n_ti * D.n_tv * P.n_di;
         D.n_cand_max = D.n_grid + P.n_brake;
 
-        // whole k_evaluate workgroups per instance (the workgroup stages one instance's tables); the padding
-        // waves have no candidates and leave at once
-        const int n_waves_i = ((D.n_cand_max + WAVE - 1) / WAVE + WAVES_PER_GROUP - 1) / WAVES_PER_GROUP * WAVES_PER_GROUP;
-        if (L.n_slots + (int64_t)n_waves_i * WAVE > 0x7fffffffLL) { err = "batch too large"; return FOT_ERR_UNSUPPORTED; }
+        // tiles of this instance: its lattice shape's run of the handle's tile table
+        const int n_tiles_i = shapes.tiles_of(D.n_tv);
+        D.shape_off = shapes.off[D.n_tv];
+        const int64_t slots_i = ((int64_t)D.n_cand_max + WAVE - 1) / WAVE * WAVE;
+        if (L.n_slots + slots_i > 0x7fffffffLL || (int64_t)L.n_tiles + n_tiles_i > 0x7fffffffLL) {
+            err = "batch too large"; return FOT_ERR_UNSUPPORTED;
+        }
         D.cand_off = (int32_t)L.n_slots;
-        D.wave0 = (int32_t)L.wave_inst.size();
-        D.n_waves = n_waves_i;
-        for (int w = 0; w < n_waves_i; ++w) { L.wave_inst.push_back(i); L.wave_base.push_back(w * WAVE); }
-        L.n_slots += (int64_t)n_waves_i * WAVE;
+        D.tile0 = L.n_tiles;
+        D.n_tiles = n_tiles_i;
+        L.n_tiles += n_tiles_i;
+        if (n_tiles_i > L.max_tiles) L.max_tiles = n_tiles_i;
+        L.n_slots += slots_i;
         const int n_lon_i = P.n_ti * D.n_tv + P.n_brake;
         D.lon_off = (int32_t)L.n_lon;
         L.n_lon += n_lon_i;
@@ -272,7 +308,6 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const fo
         L.desc[i].n_chained = run;
         run = L.desc[i].ego.has_prev_s == FOT_PREV_S_CHAINED ? run + 1 : 0;
     }
-    L.n_waves = (int)L.wave_inst.size();
     if ((L.n_static > 0 && !b.static_xy) || (L.dyn_src_points > 0 && !b.dyn_xy)) {
         err = "obstacle offsets given without coordinates";
         return FOT_ERR_INVALID;

@@ -13,7 +13,11 @@
 namespace fot {
 
 constexpr int WAVE = 64;                 // gfx950 wavefront
-constexpr int WAVES_PER_GROUP = 4;       // waves of one k_evaluate workgroup; instances are padded to whole groups
+constexpr int WAVES_PER_GROUP = 4;       // waves of one k_evaluate workgroup
+// k_evaluate works on TILES, one per wave: up to 64 consecutive candidates of one instance whose longitudinal
+// profiles fit one wave's share of LDS (tile_extent, fot_math.hpp).
+constexpr int TILE_MAX_PROFILES = 8;     // profiles a tile may span (more brake-ladder entries: next tile)
+constexpr int N_XCD = 8;
 constexpr int LON_FIELDS = 10;           // rows of a GlobalTab table: s, s_d, s_dd, rx, ry, cos_r, sin_r, kappa_r, dkappa_r, 1/s_d
 constexpr int ST_PENDING = FOT_ST_OK;    // passed the kinematic checks, collision check outstanding
 
@@ -74,8 +78,10 @@ struct InstDesc {
     int64_t dyn_off;                     // points into the caller's dyn_xy
     int64_t ent_off;                     // first broad-phase entry slot of this instance
     int32_t ent_cap;                     // entry slots per time step (multiple of 16): S*P + n_static rounded up
-    int32_t wave0;                       // first wave of this instance
-    int32_t n_waves;                     // waves of this instance
+    int32_t tile0;                       // number of this instance's first tile in the batch (tile-range rows)
+    int32_t n_tiles;                     // tiles of this instance
+    int32_t shape_off;                   // its lattice shape's first entry in the handle's tile table
+    int32_t _pad1;
     int32_t max_viol;                    // floor(eps*S)
     int32_t n_chained;                   // instances right behind this one that continue its nearest-point cache
     int32_t _pad;

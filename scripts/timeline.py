@@ -39,7 +39,7 @@ def main():
     out = torch.zeros(N_INST * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
     bs = pb.with_device_obstacles(None, dyn.data_ptr())
     st = torch.cuda.current_stream(dev)
-    for _ in range(5):
+    for _ in range(int(os.environ.get("FOT_TIMELINE_LAUNCHES", "4000"))):    # > 1 s of back-to-back launches: the clock settles
         bp.plan_packed_device(bs, out.data_ptr(), st.cuda_stream)
     torch.cuda.synchronize()
     L = _abi.lib()
@@ -49,6 +49,15 @@ def main():
     L.fot_timeline_read.argtypes = [C.c_void_p, C.c_int]
     assert L.fot_timeline_read(raw.ctypes.data, raw.size) == 0
     t = raw.reshape(-1, 4).astype(np.int64)
+    if hasattr(L, "fot_timeline_read_rows"):
+        rw = np.zeros(16384, dtype=np.uint64)
+        L.fot_timeline_read_rows.argtypes = [C.c_void_p, C.c_int]
+        if L.fot_timeline_read_rows(rw.ctypes.data, rw.size) == 0:
+            rw = rw.astype(np.int64)[: t.shape[0]]
+            okr = t[:, 2] > t[:, 1]
+            print(f"shader cycles lane 0 spent waiting for its LDS rows, per tile: median {np.median(rw[okr]):.0f} "
+                  f"p95 {np.percentile(rw[okr], 95):.0f} (tile loop: median "
+                  f"{np.median((t[okr, 2] - t[okr, 1]) * 10 * 2.36):.0f} cycles)")
     if hasattr(L, "fot_timeline_read_clock"):                              # in-kernel shader clock of the wave loops
         ck = np.zeros(2 * 16384, dtype=np.uint64)
         L.fot_timeline_read_clock.argtypes = [C.c_void_p, C.c_int]
@@ -85,6 +94,14 @@ def main():
           f"{list_schedule(np.sort(wg)[::-1], SLOTS // WPB):.1f} us")
     print(f"list scheduling, single waves in dispatch order: {list_schedule(item, SLOTS):.1f} us; longest first: "
           f"{list_schedule(np.sort(item)[::-1], SLOTS):.1f} us")
+    tag = (t[:, 3] >> 32)[ok]
+    t[:, 3] &= 0xffffffff
+    xcc, qx, base, rnd = tag & 15, (tag >> 4) & 15, (tag >> 8) & 15, (tag >> 12) & 15
+    print("tiles by XCD id:", np.bincount(xcc, minlength=8).tolist(), " label offset seen:", np.unique(base).tolist())
+    print("tiles by steal round (0 = own queue):", np.bincount(rnd, minlength=8).tolist())
+    for r in range(int(rnd.max()) + 1):
+        m = rnd == r
+        print(f"  round {r}: {int(m.sum())} tiles, median duration {np.median(dur[ok][m]):.1f} us")
     ch = t[:, 3][ok].astype(float)
     A = np.stack([np.ones_like(ch), ch], 1)
     coef = np.linalg.lstsq(A, dur[ok], rcond=None)[0]

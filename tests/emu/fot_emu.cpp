@@ -42,7 +42,9 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
     HostSpline hs;
     if (rc == FOT_OK) rc = build_spline(n_knots, wx, wy, hs, err);
     BatchLayout L;
-    if (rc == FOT_OK) rc = build_batch_layout(*params, P, *b, L, err);
+    TileShapes shapes;
+    if (rc == FOT_OK) build_tile_shapes(P, shapes);
+    if (rc == FOT_OK) rc = build_batch_layout(*params, P, shapes, *b, L, err);
     if (rc != FOT_OK) { if (errbuf) std::strncpy(errbuf, err.c_str(), 255); return rc; }
     SplineView sp;
     sp.n = hs.n; sp.s = hs.s.data();
@@ -130,8 +132,25 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         std::vector<f2> e32(cap * P.n_total + 16, farq);
         std::vector<d2> e64(cap * P.n_total + 16, infq);
         std::vector<uint8_t> sid(cap * P.n_total + 16, SID_STATIC);
-        const int n_waves_inst = (S.n_cand + WAVE - 1) / WAVE;
-        std::vector<uint32_t> rng((size_t)std::max(n_waves_inst, 1) * P.n_total, 0u);
+        // tiles of the instance (k_evaluate's units of work): the walk the host and k_frenet_state do
+        std::vector<int> tile_c0, tile_n, tile_of((size_t)std::max(D.n_cand_max, 1), -1);
+        for (int c = 0; c < D.n_cand_max;) {
+            const int n = tile_extent(P, D, c, L.row_budget);
+            if (n < 1 || n > WAVE) return -102;
+            int s0, s1, rows = 0;                                         // the tile's profiles fit the wave's LDS rows
+            wave_profile_span(P, D, n_grid_lon, c, c + n - 1, s0, s1);
+            if (s1 - s0 + 1 > TILE_MAX_PROFILES) return -103;
+            for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
+            if (rows > L.row_budget && s1 > s0) return -104;
+            for (int i = c; i < c + n; ++i) tile_of[(size_t)i] = (int)tile_c0.size();
+            if (shapes.cand0[(size_t)D.shape_off + tile_c0.size()] != c || shapes.n[(size_t)D.shape_off + tile_c0.size()] != n)
+                return -106;                                              // the handle's table holds this very walk
+            tile_c0.push_back(c); tile_n.push_back(n);
+            c += n;
+        }
+        if ((int)tile_c0.size() != D.n_tiles) return -105;                // what build_batch_layout counted
+        const int n_tiles_inst = (int)tile_c0.size();
+        std::vector<uint32_t> rng((size_t)std::max(n_tiles_inst, 1) * P.n_total, 0u);
         if (D.ent_cap > 0) {
             const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
             const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
@@ -165,9 +184,10 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 }
                 const int count = (int)ents.size();
                 cnt[k] = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);
-                for (int w = 0; w < n_waves_inst; ++w) {
+                for (int w = 0; w < n_tiles_inst; ++w) {
+                    if (tile_c0[w] >= S.n_cand) continue;
                     int s0, s1;
-                    wave_profile_span(P, D, n_grid_lon, w * WAVE, std::min(w * WAVE + WAVE - 1, S.n_cand - 1), s0, s1);
+                    wave_profile_span(P, D, n_grid_lon, tile_c0[w], std::min(tile_c0[w] + tile_n[w] - 1, S.n_cand - 1), s0, s1);
                     Box32 wb = box_empty();
                     for (int sl = s0; sl <= s1; ++sl) box_merge(wb, pbox[(size_t)sl * P.n_total + k]);
                     const float wm = cull_margin(sq_max, wb) + box_footprint_slack(P);
@@ -191,7 +211,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
             EntryCollider ec;
             ec.init(P, D);
-            ec.rng = D.ent_cap > 0 ? rng.data() + (size_t)(idx / WAVE) * P.n_total : nullptr;
+            ec.rng = D.ent_cap > 0 ? rng.data() + (size_t)tile_of[(size_t)idx] * P.n_total : nullptr;
             ec.e32 = e32.data(); ec.e64 = e64.data(); ec.sid = sid.data();
             CandResult r;
             evaluate_candidate(P, D, loop_const(P, D), Li, GlobalTab{ tab }, q, P.n_total, ec, r);
