@@ -99,6 +99,9 @@ def parse_args():
     ap.add_argument("--overlap", type=int, default=2,
                     help="plan calls in flight in the headline leg: consecutive steps alternate between this many "
                          "handles/streams (1 = strictly serial, one leg only)")
+    ap.add_argument("--dyn-layout", choices=("spt", "tsp"), default="spt",
+                    help="layout of the obstacle tensors: spt = the reference's [S][P][T][2] (default), tsp = time-major "
+                         "[T][S][P][2] as libfot's own resampler can write it (FOT_DYN_LAYOUT_TSP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
@@ -230,7 +233,7 @@ def main():
     for b in range(n_rot):
         s0 = b * world * n_inst + rank * n_inst
         reqs = [request_from_instance(syn.config3_instance(s)) for s in range(s0, s0 + n_inst)]
-        pb = PackedBatch(reqs, obstacle_dtype=np.float32)
+        pb = PackedBatch(reqs, obstacle_dtype=np.float32, dyn_layout_tsp=args.dyn_layout == "tsp")
         d = torch.from_numpy(pb.dyn_xy).to(dev)                 # obstacle tensors resident in HBM
         reqs_rot.append(reqs); packed.append(pb); dyn_dev.append(d)
         bstructs.append(pb.with_device_obstacles(None, d.data_ptr()))
@@ -500,6 +503,23 @@ def main():
                 "note": "one fixed batch (123 MB of obstacle tensors, below the Infinity Cache size)"}
             leg5.close()
 
+    # the same serial leg on time-major tensors ([T][S][P][2], what fot_resample_predictions writes with FOT_OUT_TMAJOR)
+    layout_tsp = None
+    if world == 1 and args.dyn_layout == "spt" and not args.no_latency:
+        pbt = [PackedBatch(rq, obstacle_dtype=np.float32, dyn_layout_tsp=True) for rq in reqs_rot]
+        dt_ = [torch.from_numpy(p_.dyn_xy).to(dev) for p_ in pbt]
+        legt = Leg(1, make_planner, dev, [p_.with_device_obstacles(None, d_.data_ptr()) for p_, d_ in zip(pbt, dt_)],
+                   out_bytes, None, False)
+        kt = max(20, args.steps // 2)
+        elt, proft, _ = legt.run(max(3, args.warmup // 2), kt, profile=True)
+        layout_tsp = {"ms_per_step": elt / kt * 1e3, "steps": kt, "plan_calls_in_flight": 1,
+                      "kernel_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in proft.items()
+                                    if v["launches"]},
+                      "note": "obstacle tensors laid out [T][S][P][2] (FOT_DYN_LAYOUT_TSP); the headline uses the "
+                              "reference's [S][P][T][2]"}
+        legt.close()
+        del dt_, pbt
+
     cfg_name = "config4" if (world == 1 and n_inst == 256) else "config5" if n_inst == 512 else "config4-like"
     line = {
         "metric": "candidate trajectories/sec", "value": value, "unit": "candidates/s",
@@ -508,13 +528,15 @@ def main():
         "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if not rehearse else "synthetic (REHEARSAL of the N>1 control flow on one GPU: not a measurement)",
         "config": {"workload": "%s: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "
-                               "20-sample x 30-pedestrian x 51-step fp32 prediction distribution, eps=0; "
+                               "20-sample x 30-pedestrian x 51-step fp32 prediction distribution (layout %s), eps=0; "
                                "%d distinct batches rotated (%.0f MB of obstacle tensors per GPU)"
-                               % (cfg_name, n_inst, n_rot, obstacle_mb),
+                               % (cfg_name, n_inst, "[S][P][T][2]" if args.dyn_layout == "spt" else "[T][S][P][2]", n_rot,
+                                  obstacle_mb),
                    "instances_per_gpu": n_inst, "instances_total": n_inst * world, "rotation_batches": n_rot,
                    "plan_calls_in_flight": n_ov, "candidates_per_step": cand_total // args.steps,
                    "parallelism": "instances sharded over %d GPU(s), RCCL all-gather of %d-byte path records"
                                   % (world, _abi.RESULT_BYTES)},
+        "layout_tsp_serial": layout_tsp,
         "serial": {"ms_per_step": el1 / args.steps * 1e3, "value": cand_serial / el1, "plan_calls_in_flight": 1,
                    "steps": args.steps, "kernel_ms": kernels},
         "roofline": roofline, "roofline_issue": issue, "kernel_ms": kernels,

@@ -67,6 +67,10 @@ enum {
 enum { FOT_F32 = 0, FOT_F64 = 1 };
 /* fot_batch.dyn_dims[i][0] */
 enum { FOT_DYN_NONE = 0, FOT_DYN_SINGLE = 1, FOT_DYN_DISTRIBUTION = 2 };
+/* OR-ed into dyn_dims[i][0]: instance i's tensor is laid out [T][S][P][2] (all pedestrians of one time row
+ * contiguous: what the broad phase reads, fully coalesced) instead of the reference's [S][P][T][2].
+ * fot_resample_predictions / fot_predict_cv write it when asked to (FOT_OUT_TMAJOR). */
+#define FOT_DYN_LAYOUT_TSP 0x10
 
 /* replaces the constructor arguments of FrenetPlanner (frenet_planner.py:149-210) */
 typedef struct fot_params {
@@ -241,6 +245,9 @@ int fot_check_paths(fot_handle *h, int32_t n_paths, const int32_t *len, const in
 typedef struct fot_resample_params {
     double sgan_dt, sim_dt, plan_horizon;
 } fot_resample_params;
+/* bits of the `on_device` argument below */
+#define FOT_OUT_DEVICE 1     /* pred / out are device memory (else host memory) */
+#define FOT_OUT_TMAJOR 2     /* out is written [T][S][P][2] (FOT_DYN_LAYOUT_TSP) instead of [S][P][T][2] */
 int fot_resample_n_dense(const fot_resample_params *rp, int32_t pred_len);
 int fot_resample_predictions(fot_handle *h, const fot_resample_params *rp, int32_t S, int32_t pred_len, int32_t P,
                              const void *pred, int32_t pred_dtype, const double *anchor, const double *current,

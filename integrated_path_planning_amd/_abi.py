@@ -18,6 +18,8 @@ ST_SPEED, ST_ACCEL, ST_CURVATURE, ST_LAT_ACCEL, ST_ROAD, ST_COLLISION, ST_OK, ST
 PLAN_OK, PLAN_NO_PATH, PLAN_C2F_FAILED = 0, 1, 2
 F32, F64 = 0, 1
 DYN_NONE, DYN_SINGLE, DYN_DISTRIBUTION = 0, 1, 2
+DYN_LAYOUT_TSP = 0x10                    # OR-ed into dyn_dims[i][0]: tensor laid out [T][S][P][2]
+OUT_DEVICE, OUT_TMAJOR = 1, 2            # bits of the resampler's `on_device` argument
 
 # reference's last_check_stats keys in fot_result.stats[] order (frenet_planner.py:910-918, 324)
 STATUS_NAMES = ["max_speed_error", "max_accel_error", "max_curvature_error", "max_lat_accel_error",

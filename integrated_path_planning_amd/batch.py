@@ -68,8 +68,11 @@ def _dyn_of(req: PlanRequest):
 class PackedBatch:
     """Host-side ``fot_batch`` with the NumPy buffers that back its pointers."""
 
-    def __init__(self, requests: Sequence[PlanRequest], obstacle_dtype=np.float64):
+    def __init__(self, requests: Sequence[PlanRequest], obstacle_dtype=np.float64, dyn_layout_tsp: bool = False):
+        """dyn_layout_tsp: pack every dynamic tensor time-major, [T][S][P][2] (``FOT_DYN_LAYOUT_TSP``) -- the layout the
+        broad phase reads with fully coalesced loads and the device-side resampler can write directly."""
         n = len(requests)
+        self.dyn_layout_tsp = bool(dyn_layout_tsp)
         self.n = n
         self.np_dtype = np.dtype(obstacle_dtype)
         if self.np_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
@@ -114,13 +117,15 @@ class PackedBatch:
             self.dyn_off[i] = dyn_cursor
             if mode != _abi.DYN_NONE:
                 S, P, T = d.shape[0], d.shape[1], d.shape[2]
-                self.dyn_dims[i] = (mode, S, P, T)
+                self.dyn_dims[i] = (mode | (_abi.DYN_LAYOUT_TSP if self.dyn_layout_tsp else 0), S, P, T)
                 src = r.dist if mode == _abi.DYN_DISTRIBUTION else r.dyn
                 key = (id(src), mode)
                 if key in shared:
                     self.dyn_off[i] = shared[key]
                 else:
                     shared[key] = dyn_cursor
+                    if self.dyn_layout_tsp:
+                        d = np.transpose(d, (2, 0, 1, 3))                  # [S, P, T, 2] -> [T, S, P, 2]
                     dyns.append(np.ascontiguousarray(d, dtype=self.np_dtype).reshape(-1, 2))
                     dyn_cursor += S * P * T
         self.static_xy = (np.concatenate(statics, axis=0) if statics else np.empty((0, 2))).astype(self.np_dtype)

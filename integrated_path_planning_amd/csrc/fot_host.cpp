@@ -552,6 +552,8 @@ int resample_common(fot_handle *h, const fot_resample_params *rp, int cv, int32_
     const int T = n_dense + (current ? 1 : 0);
     if (T > FOT_MAX_NT) return fail(h, FOT_ERR_UNSUPPORTED, "more than FOT_MAX_NT time steps");
     if (T_out) *T_out = T;
+    const int tmajor = (on_device & FOT_OUT_TMAJOR) ? 1 : 0;
+    on_device &= FOT_OUT_DEVICE;
     if (S == 0 || P == 0 || T == 0) return FOT_OK;
     if (!out || (!cv && !pred) || (cv && !anchor)) return fail(h, FOT_ERR_INVALID, "NULL tensor");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -580,10 +582,10 @@ int resample_common(fot_handle *h, const fot_resample_params *rp, int cv, int32_
     if (!on_device) { HIP_TRY(h, h->dTmpC.ensure(out_bytes)); d_out = h->dTmpC.p; }
     LAUNCH_TRY(h, launch_resample(rp->sgan_dt, rp->sim_dt, staleness, S, pred_len, P, n_dense, anchor ? 1 : 0,
                                   current ? 1 : 0, cv, d_pred, cv ? FOT_F64 : pred_dtype, d_anchor, d_current, d_out,
-                                  out_dtype, st));
+                                  out_dtype, tmajor, st));
     if (sample_dist) {
         HIP_TRY(h, h->dTmpD.ensure(sizeof(double) * (size_t)S));
-        LAUNCH_TRY(h, launch_sample_dist(S, P, T, current ? 1 : 0, d_out, out_dtype, h->dTmpD.as<double>(), st));
+        LAUNCH_TRY(h, launch_sample_dist(S, P, T, current ? 1 : 0, d_out, out_dtype, tmajor, h->dTmpD.as<double>(), st));
         HIP_TRY(h, hipMemcpyAsync(sample_dist, h->dTmpD.p, sizeof(double) * (size_t)S, hipMemcpyDeviceToHost, st));
     }
     if (!on_device) HIP_TRY(h, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));

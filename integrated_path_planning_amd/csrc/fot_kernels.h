@@ -51,8 +51,9 @@ int launch_debug_margins(const DevParams *P, const InstDesc *desc, const InstSta
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
 int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
                     int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
-                    const double *current, void *out, int out_dtype, hipStream_t st);
-int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, double *dist, hipStream_t st);
+                    const double *current, void *out, int out_dtype, int tmajor, hipStream_t st);
+int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, int tmajor, double *dist,
+                       hipStream_t st);
 int launch_safety(const DevParams *P, int n, const double *ego, const int32_t *ped_off, const double *ped_pos,
                   const double *ped_vel, double ego_radius, double ped_radius, double footprint_radius, int use_fp,
                   fot_safety *out, hipStream_t st);

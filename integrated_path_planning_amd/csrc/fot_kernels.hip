@@ -245,26 +245,6 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
 }
 
 // ---------------------------------------------------------------------------
-// longitudinal profiles
-// ---------------------------------------------------------------------------
-
-// float32 bounding box (instance-local frame) of the lateral candidates of profile `slot` at time step k; empty
-// when the profile has no sample k.  See profile_box (fot_math.hpp): two end points of a segment.
-__device__ __forceinline__ Box32 profile_box_at(const DevParams &P, const InstDesc &D, const InstState &S,
-                                                const SplineView &sp, int slot, int k)
-{
-    const int n_grid_lon = P.n_ti * D.n_tv;
-    const bool brake = slot >= n_grid_lon;
-    const TimeInfo &lat_ti = brake ? P.brake[slot - n_grid_lon] : P.ti[slot / D.n_tv];
-    const LonInfo L = profile_info(P, D, S.frenet0, slot, false);
-    if (k >= L.n_t) return box_empty();
-    LonSample ls;
-    double sddd;
-    make_lon_sample(sp, L, k, P.dt, ls, sddd);
-    return profile_box(P, S.frenet0, brake, lat_ti, ls, k, L.n_eval, D.ego.x, D.ego.y);
-}
-
-// ---------------------------------------------------------------------------
 // candidate evaluation
 // ---------------------------------------------------------------------------
 
@@ -709,6 +689,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __shared__ BinMap s_bm[CULL_KG];
     __shared__ float s_margin[CULL_KG];
     __shared__ Box32 s_pbox[CULL_KG][CULL_PBOX];                 // boxes of the instance's profiles at the group's steps
+    __shared__ double s_ext[CULL_KG][FOT_MAX_TI + FOT_MAX_BRAKE][2];   // lateral extent per horizon / brake entry and step
     const DevParams &P = *Pp;
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
     const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
@@ -729,15 +710,52 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     const float slack = box_footprint_slack(P);
 
+    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
+    const int n_dyn = dyn_on ? D.S * D.P : 0;
+    const int total = D.n_static + n_dyn;
+    const bool tmajor = D.dyn_tmajor != 0;                       // [T][S][P][2] instead of the caller's [S][P][T][2]
+
+    // Pass-1 lane roles.  Caller layout: lane = (obstacle slot, step) -- the 8 lanes of one obstacle read its 8
+    // consecutive samples, a contiguous 64-byte run of the [S][P][T][2] tensor, so a wave-wide load touches 8 such runs
+    // instead of 64 scattered cache lines; the group's 8 waves share the obstacles.  T-major layout: the obstacles of
+    // one time row are contiguous, so wave w takes step k0 + w alone and its lanes read 64 consecutive obstacles.
+    const int kl = tmajor ? wv : (lane & (CULL_KG - 1));          // this lane's step inside the group
+    const int i_first = tmajor ? lane : wv * (WAVE / CULL_KG) + lane / CULL_KG;
+    constexpr int STRIDE = WAVE;                                  // obstacles between two of a lane's loads
+    const int row_l = k0 + kl < D.T - 1 ? k0 + kl : D.T - 1;
+    struct Raw { T x, y; };                                       // as stored: widened only when it is classified
+    auto fetch = [&](int i, Raw &o) {
+        o.x = (T)0; o.y = (T)0;
+        if (i >= total) return;
+        if (i < D.n_static) {
+            const int64_t in = D.static_off + i;
+            o.x = static_xy[2 * in]; o.y = static_xy[2 * in + 1];
+        } else {
+            const int j = i - D.n_static;                         // = s * P + p
+            const int64_t in = D.dyn_off + (tmajor ? (int64_t)row_l * n_dyn + j : (int64_t)j * D.T + row_l);
+            o.x = dyn_xy[2 * in]; o.y = dyn_xy[2 * in + 1];
+        }
+    };
     // wave wv: box of time step k0 + wv over all longitudinal profiles of the instance
     {
         Box32 bw = box_empty();
-        if (wv < nk && !(ablate & 8))
+        if (wv < nk && !(ablate & 8)) {
+            // lateral extents first: one per horizon (shared by its terminal speeds) and per brake-ladder entry
+            const int n_ext = P.n_ti + (S.c2f_ok ? S.n_brake : 0);
+            if (lane < n_ext) {
+                const bool brake = lane >= P.n_ti;
+                const TimeInfo &ti = brake ? P.brake[lane - P.n_ti] : P.ti[lane];
+                lateral_extent(P, S.frenet0, brake, ti, k0 + wv, brake ? ti.n_t : ti.n_t, s_ext[wv][lane][0], s_ext[wv][lane][1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             for (int w = lane; w < n_prof; w += WAVE) {
-                const Box32 o = profile_box_at(P, D, S, sp, w, k0 + wv);
-                if (w < CULL_PBOX) s_pbox[wv][w] = o;               // read again below, per candidate wave
+                const int e = extent_index(P, D, w);
+                const Box32 o = profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, s_ext[wv][e][0], s_ext[wv][e][1]);
+                if (w < CULL_PBOX) s_pbox[wv][w] = o;               // read again below, per tile
                 box_merge(bw, o);
             }
+        }
         bw.x0 = wave_min_f32(bw.x0); bw.y0 = wave_min_f32(bw.y0);
         bw.x1 = wave_max_f32(bw.x1); bw.y1 = wave_max_f32(bw.y1);
         const float mw = cull_margin(sq_max, bw) + slack;
@@ -745,47 +763,29 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         if (lane <= CULL_BINS) s_cnt[wv][lane] = 0;
     }
     __syncthreads();
-    const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
-    const int n_dyn = dyn_on ? D.S * D.P : 0;
-    const int total = D.n_static + n_dyn;
 
-    // pass 1 (all waves): histogram per step, kept obstacles remembered.  Lane = (obstacle, step): the 8 lanes of
-    // one obstacle read its 8 consecutive samples -- a contiguous 64-byte run of the caller's [S][P][T][2] tensor --
-    // so a wave-wide load touches 8 such runs instead of 64 scattered cache lines.
+    // pass 1: histogram per step, kept obstacles remembered
     {
-        const int kl = lane & (CULL_KG - 1), sub = lane / CULL_KG;            // this lane's step and obstacle slot
         const Box32 bl = s_box[kl];
         const float ml = s_margin[kl];
         const BinMap bml = s_bm[kl];
         const bool live_l = kl < nk && bl.x0 <= bl.x1 && !(ablate & 4);
-        const int row_l = k0 + kl < D.T - 1 ? k0 + kl : D.T - 1;
-        constexpr int PER_WAVE = WAVE / CULL_KG, STRIDE = CULL_KG * PER_WAVE, UNROLL = 4;
-        auto fetch = [&](int i, d2 &o) {
-            o.x = 0.0; o.y = 0.0;
-            if (i >= total) return;
-            if (i < D.n_static) {
-                const int64_t in = D.static_off + i;
-                o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
-            } else {
-                const int64_t in = D.dyn_off + (int64_t)(i - D.n_static) * D.T + row_l;   // i - n_static = s*P + p
-                o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
+        auto classify = [&](int i, const Raw &o) {
+            const float fx = (float)((double)o.x - D.ego.x), fy = (float)((double)o.y - D.ego.y);
+            if (i < total && live_l && cull_inside(bl, ml, fx, fy)) {
+                const int bin = bin_of(bml, fx, fy);
+                atomicAdd(&s_cnt[kl][bin], 1);
+                const int j = atomicAdd(&s_nin[kl], 1);
+                if (j < CULL_LIST) s_list[kl][j] = (uint32_t)i | ((uint32_t)bin << 20);
             }
         };
-        for (int i0 = wv * PER_WAVE + sub; i0 < total; i0 += UNROLL * STRIDE) {      // UNROLL gathers in flight per lane
-            d2 o[UNROLL];
+        constexpr int UNROLL = 4;                                 // gathers in flight per lane
+        for (int ib = i_first; ib < total; ib += UNROLL * STRIDE) {
+            Raw o[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) fetch(i0 + u * STRIDE, o[u]);
+            for (int u = 0; u < UNROLL; ++u) fetch(ib + u * STRIDE, o[u]);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int i = i0 + u * STRIDE;
-                const float fx = (float)(o[u].x - D.ego.x), fy = (float)(o[u].y - D.ego.y);
-                if (i < total && live_l && cull_inside(bl, ml, fx, fy)) {
-                    const int bin = bin_of(bml, fx, fy);
-                    atomicAdd(&s_cnt[kl][bin], 1);
-                    const int j = atomicAdd(&s_nin[kl], 1);
-                    if (j < CULL_LIST) s_list[kl][j] = (uint32_t)i | ((uint32_t)bin << 20);
-                }
-            }
+            for (int u = 0; u < UNROLL; ++u) classify(ib + u * STRIDE, o[u]);
         }
     }
     __syncthreads();
@@ -819,7 +819,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             o.x = (double)static_xy[2 * in]; o.y = (double)static_xy[2 * in + 1];
         } else {
             const int j = i - D.n_static;
-            const int64_t in = D.dyn_off + (int64_t)j * D.T + row;
+            const int64_t in = D.dyn_off + (tmajor ? (int64_t)row * n_dyn + j : (int64_t)j * D.T + row);
             o.x = (double)dyn_xy[2 * in]; o.y = (double)dyn_xy[2 * in + 1];
             sid = j / D.P;
         }
@@ -870,8 +870,11 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             int s0, s1;
             wave_profile_span(P, D, n_grid_lon, idx0, idx1, s0, s1);
             Box32 wb = box_empty();
-            for (int sl = s0; sl <= s1; ++sl)
-                box_merge(wb, sl < CULL_PBOX ? s_pbox[kk][sl] : profile_box_at(P, D, S, sp, sl, k));
+            for (int sl = s0; sl <= s1; ++sl) {
+                if (sl < CULL_PBOX) { box_merge(wb, s_pbox[kk][sl]); continue; }
+                const int e = extent_index(P, D, sl);
+                box_merge(wb, profile_box_at(P, D, S.frenet0, sp, sl, k, s_ext[kk][e][0], s_ext[kk][e][1]));
+            }
             const float wm = cull_margin(sq_max, wb) + slack;
             r = strip_range(bmk, wb, wm, [&](int bb) { return s_start[kk][bb]; });
         }
@@ -1126,6 +1129,7 @@ struct ResampleArgs {
     double sgan_dt, sim_dt, staleness;
     int S, pred_len, P, n_dense, T;          // T = n_dense + prepend
     int has_anchor, prepend, cv;             // cv: sources are (obs_prev, obs_last) -> constant velocity; 2: float32 obs
+    int tmajor;                              // out[k][s][p][axis] (FOT_OUT_TMAJOR) instead of out[s][p][k][axis]
 };
 
 // one thread per (sample, pedestrian, axis); out[s][p][k][axis]
@@ -1136,9 +1140,12 @@ __global__ void k_resample(ResampleArgs A, const TI *__restrict__ pred, const do
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= A.S * A.P * 2) return;
     const int ax = idx & 1, sp = idx >> 1, p = sp % A.P, smp = sp / A.P;
-    TO *dst = out + ((int64_t)sp * A.T) * 2 + ax;
+    // element (row k) of this thread's (sample, pedestrian, axis): rows are T apart in the reference's layout and a whole
+    // S x P plane apart in the T-major one (where neighbouring threads then write neighbouring addresses)
+    const int64_t k_stride = A.tmajor ? (int64_t)A.S * A.P * 2 : 2;
+    TO *dst = out + (A.tmajor ? (int64_t)sp * 2 : (int64_t)sp * A.T * 2) + ax;
     if (A.prepend) dst[0] = (TO)current[2 * p + ax];
-    dst += 2 * A.prepend;
+    dst += k_stride * A.prepend;
     if (A.cv) {                                                     // predict_cv (:188-231)
         const double cur = anchor[2 * p + ax];                      // obs_last
         double vel = 0.0;
@@ -1148,7 +1155,7 @@ __global__ void k_resample(ResampleArgs A, const TI *__restrict__ pred, const do
             vel = (cur - (double)pred[2 * p + ax]) / A.sgan_dt;     // obs_prev
         for (int i = 0; i < A.n_dense; ++i) {
             const double t = (A.sim_dt + (double)i * A.sim_dt) + A.staleness;
-            dst[2 * i] = (TO)(cur + vel * t);
+            dst[k_stride * i] = (TO)(cur + vel * t);
         }
         return;
     }
@@ -1162,14 +1169,17 @@ __global__ void k_resample(ResampleArgs A, const TI *__restrict__ pred, const do
     const bool constant = R.all_close(R.co[0]) || R.all_close(0.0);
     const double v_tail = R.tail_velocity();
     for (int i = 0; i < A.n_dense; ++i)
-        dst[2 * i] = (TO)R.at(A.sim_dt + (double)i * A.sim_dt, constant, v_tail);
+        dst[k_stride * i] = (TO)R.at(A.sim_dt + (double)i * A.sim_dt, constant, v_tail);
 }
 
 // block = sample: sum over (p, k) of the distance to the sample mean (predict_single_best :346-350)
 template <typename TO>
 __global__ void __launch_bounds__(256)
-k_sample_dist(int S, int P, int T, int skip, const TO *__restrict__ out, double *__restrict__ dist)
+k_sample_dist(int S, int P, int T, int skip, int tmajor, const TO *__restrict__ out, double *__restrict__ dist)
 {
+    auto at = [&](int q, int p, int k) {
+        return out + (tmajor ? ((int64_t)k * S + q) * P + p : ((int64_t)q * P + p) * T + k) * 2;
+    };
     const int smp = blockIdx.x;
     const int n = P * (T - skip);
     double acc = 0.0;
@@ -1177,11 +1187,11 @@ k_sample_dist(int S, int P, int T, int skip, const TO *__restrict__ out, double 
         const int p = i / (T - skip), k = i - p * (T - skip) + skip;  // the prepended current position is not part of it
         double mx = 0.0, my = 0.0;
         for (int q = 0; q < S; ++q) {
-            const TO *e = out + (((int64_t)q * P + p) * T + k) * 2;
+            const TO *e = at(q, p, k);
             mx += (double)e[0]; my += (double)e[1];
         }
         mx /= (double)S; my /= (double)S;
-        const TO *e = out + (((int64_t)smp * P + p) * T + k) * 2;
+        const TO *e = at(smp, p, k);
         const double dx = (double)e[0] - mx, dy = (double)e[1] - my;
         acc += sqrt(dx * dx + dy * dy);
     }
@@ -1349,14 +1359,14 @@ int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipSt
 
 int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
                     int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
-                    const double *current, void *out, int out_dtype, hipStream_t st)
+                    const double *current, void *out, int out_dtype, int tmajor, hipStream_t st)
 {
     const int total = S * P * 2;
     if (total <= 0) return 0;
     ResampleArgs A;
     A.sgan_dt = sgan_dt; A.sim_dt = sim_dt; A.staleness = staleness;
     A.S = S; A.pred_len = pred_len; A.P = P; A.n_dense = n_dense; A.T = n_dense + (prepend ? 1 : 0);
-    A.has_anchor = has_anchor; A.prepend = prepend; A.cv = cv;
+    A.has_anchor = has_anchor; A.prepend = prepend; A.cv = cv; A.tmajor = tmajor;
     const int bs = 128, grid = (total + bs - 1) / bs;
     if (pred_dtype == FOT_F32 && out_dtype == FOT_F32)
         k_resample<float, float><<<grid, bs, 0, st>>>(A, (const float *)pred, anchor, current, (float *)out);
@@ -1370,11 +1380,12 @@ int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int 
     return 0;
 }
 
-int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, double *dist, hipStream_t st)
+int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, int tmajor, double *dist,
+                       hipStream_t st)
 {
     if (S <= 0) return 0;
-    if (out_dtype == FOT_F32) k_sample_dist<float><<<S, 256, 0, st>>>(S, P, T, skip, (const float *)out, dist);
-    else k_sample_dist<double><<<S, 256, 0, st>>>(S, P, T, skip, (const double *)out, dist);
+    if (out_dtype == FOT_F32) k_sample_dist<float><<<S, 256, 0, st>>>(S, P, T, skip, tmajor, (const float *)out, dist);
+    else k_sample_dist<double><<<S, 256, 0, st>>>(S, P, T, skip, tmajor, (const double *)out, dist);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -391,7 +391,9 @@ FOT_HD void frenet_to_cart(const LonSample &L, double d, double d_d, double d_dd
     const double tan_d = dp * inv_om;
     const double inv_cos = h * inv_om;
     const double krdp = L.dkr * d + L.kr * dp;
-    const double kappa = (((dpp + krdp * tan_d) * cos_d * cos_d) * inv_om + L.kr) * cos_d * inv_om;
+    // kappa = ((d'' + krdp tan) cos^2 / (1-kd) + kr) cos / (1-kd); with cos = (1-kd)/h the factors (1-kd) cancel:
+    //       = ((d'' + krdp tan) (1-kd) / h^2 + kr) / h
+    const double kappa = ((dpp + krdp * tan_d) * omkd * (inv_h * inv_h) + L.kr) * inv_h;
     const double dtp = h * kappa - L.kr;
     o.x = L.rx - L.sin_r * d;
     o.y = L.ry + L.cos_r * d;
@@ -759,20 +761,61 @@ FOT_HD bool cull_inside(const Box32 &b, float m, float fx, float fy)
 // candidates' points lie on the segment of the path normal between the two extreme offsets; brake-ladder
 // profiles have the single offset d0.  Footprint circle centres lie within max|circ_off| of these points, which
 // box_footprint_slack() adds to the cull margin.  NaN points (beyond the path end) are never kept and are skipped.
+// lateral offsets [d0, d1] the candidates of one horizon (d1 == d0 for a brake-ladder entry) span at sample k: the
+// two extreme targets of the lateral grid.  Depends on the horizon only, not on the terminal speed: k_cull derives it
+// once per (horizon, step) for all the profiles that share it.
+FOT_HD void lateral_extent(const DevParams &P, const double *fr, bool brake, const TimeInfo &ti, int k, int n_eval,
+                           double &d0, double &d1)
+{
+    double q[6], u0, u1, u2;
+    lat_coeffs(fr, brake ? fr[3] : -(double)P.n_side * P.d_road_w, ti, q);
+    lat_sample(q, k, n_eval, P.dt, d0, u0, u1, u2);
+    d1 = d0;
+    if (!brake) {
+        lat_coeffs(fr, (double)(P.n_di - 1 - P.n_side) * P.d_road_w, ti, q);
+        lat_sample(q, k, n_eval, P.dt, d1, u0, u1, u2);
+    }
+}
+
+// box of the two end points of the segment (rx, ry) + d * normal, d in {d0, d1}
+FOT_HD Box32 segment_box(double rx, double ry, double cos_r, double sin_r, double d0, double d1, double ox, double oy)
+{
+    Box32 b = box_empty();
+    const double x0 = rx - sin_r * d0, y0 = ry + cos_r * d0, x1 = rx - sin_r * d1, y1 = ry + cos_r * d1;
+    if (x0 == x0 && y0 == y0) box_add(b, (float)(x0 - ox), (float)(y0 - oy));
+    if (x1 == x1 && y1 == y1) box_add(b, (float)(x1 - ox), (float)(y1 - oy));
+    return b;
+}
+
 FOT_HD Box32 profile_box(const DevParams &P, const double *fr, bool brake, const TimeInfo &ti, const LonSample &ls,
                          int k, int n_eval, double ox, double oy)
 {
-    Box32 b = box_empty();
-    const int n_side = brake ? 1 : 2;
-    for (int e = 0; e < n_side; ++e) {
-        const double di = brake ? fr[3] : (e == 0 ? -(double)P.n_side : (double)(P.n_di - 1 - P.n_side)) * P.d_road_w;
-        double q[6], d, u0, u1, u2;
-        lat_coeffs(fr, di, ti, q);
-        lat_sample(q, k, n_eval, P.dt, d, u0, u1, u2);
-        const double x = ls.rx - ls.sin_r * d, y = ls.ry + ls.cos_r * d;
-        if (x == x && y == y) box_add(b, (float)(x - ox), (float)(y - oy));
-    }
-    return b;
+    double d0, d1;
+    lateral_extent(P, fr, brake, ti, k, n_eval, d0, d1);
+    return segment_box(ls.rx, ls.ry, ls.cos_r, ls.sin_r, d0, d1, ox, oy);
+}
+
+// The same box from a pre-computed lateral extent, with only what it needs of the reference frame: position and unit
+// tangent at s(t_k) -- no curvature, and the tangent normalised with the fast reciprocal square root (the box is a
+// conservative float32 hull with a margin of millimetres; 1e-15 of tangent direction is nothing to it).
+FOT_HD Box32 profile_box_at(const DevParams &P, const InstDesc &D, const double *fr, const SplineView &sp, int slot,
+                            int k, double d0, double d1)
+{
+    const LonInfo L = profile_info(P, D, fr, slot, false);
+    if (k >= L.n_t) return box_empty();
+    double s_, u0, u1, u2;
+    lon_sample(L, k, P.dt, s_, u0, u1, u2);
+    SplinePt p;
+    spline_point(sp, s_, p);
+    const double inv = fast_rsqrt(p.dx * p.dx + p.dy * p.dy);
+    return segment_box(p.x, p.y, p.dx * inv, p.dy * inv, d0, d1, D.ego.x, D.ego.y);
+}
+
+// index of a profile's lateral extent in a per-step table: horizons first, then the brake ladder
+FOT_HD int extent_index(const DevParams &P, const InstDesc &D, int slot)
+{
+    const int n_grid_lon = P.n_ti * D.n_tv;
+    return slot < n_grid_lon ? slot / D.n_tv : P.n_ti + (slot - n_grid_lon);
 }
 
 FOT_HD float box_footprint_slack(const DevParams &P)

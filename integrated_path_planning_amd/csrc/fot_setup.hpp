@@ -278,7 +278,8 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const Ti
         D.dyn_mode = FOT_DYN_NONE;
         if (b.dyn_off && b.dyn_dims) {
             const int32_t *dm = b.dyn_dims + 4 * i;
-            const int mode = dm[0];
+            const int mode = dm[0] & ~FOT_DYN_LAYOUT_TSP;
+            D.dyn_tmajor = (dm[0] & FOT_DYN_LAYOUT_TSP) ? 1 : 0;
             int S = dm[1], Pn = dm[2], T = dm[3];
             if (mode != FOT_DYN_NONE && mode != FOT_DYN_SINGLE && mode != FOT_DYN_DISTRIBUTION) {
                 err = "dyn_dims mode"; return FOT_ERR_INVALID;

@@ -81,7 +81,7 @@ struct InstDesc {
     int32_t tile0;                       // number of this instance's first tile in the batch (tile-range rows)
     int32_t n_tiles;                     // tiles of this instance
     int32_t shape_off;                   // its lattice shape's first entry in the handle's tile table
-    int32_t _pad1;
+    int32_t dyn_tmajor;                  // 1: the dynamic tensor is [T][S][P][2] (FOT_DYN_LAYOUT_TSP), 0: [S][P][T][2]
     int32_t max_viol;                    // floor(eps*S)
     int32_t n_chained;                   // instances right behind this one that continue its nearest-point cache
     int32_t _pad;

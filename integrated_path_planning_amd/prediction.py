@@ -91,15 +91,18 @@ class PredictionResampler:
 
     # -- device tensors (what the planner consumes through fot_plan_batch_device) ------------------------
     def resample_device(self, pred_ptr: int, pred_dtype, S: int, P: int, anchor_pos, current, staleness: float,
-                        out_ptr: int, out_dtype, stream: Optional[int] = None, want_sample_dist: bool = False
-                        ) -> Tuple[int, Optional[np.ndarray]]:
-        """pred [S][pred_len][P][2] and out [S][P][T][2] are device pointers; returns (T, sample_dist)."""
+                        out_ptr: int, out_dtype, stream: Optional[int] = None, want_sample_dist: bool = False,
+                        t_major: bool = False) -> Tuple[int, Optional[np.ndarray]]:
+        """pred [S][pred_len][P][2] and out [S][P][T][2] are device pointers; returns (T, sample_dist).
+        t_major: out is written [T][S][P][2] -- the layout the planner's broad phase reads fully coalesced; hand it on
+        with ``PackedBatch(..., dyn_layout_tsp=True)`` / ``_abi.DYN_LAYOUT_TSP`` in ``dyn_dims``."""
         dist = np.zeros(S) if want_sample_dist else None
         t_out = C.c_int32(0)
         code = lambda d: _abi.F32 if np.dtype(d) == np.dtype(np.float32) else _abi.F64
         keep = (_host_pd(anchor_pos), _host_pd(current))
         _abi.check(self.engine._h, self._lib.fot_resample_predictions(
             self.engine._h, C.byref(self.params), S, self.pred_len, P, C.c_void_p(pred_ptr), code(pred_dtype), keep[0],
-            keep[1], float(staleness), C.c_void_p(out_ptr), code(out_dtype), 1, C.byref(t_out),
+            keep[1], float(staleness), C.c_void_p(out_ptr), code(out_dtype),
+            _abi.OUT_DEVICE | (_abi.OUT_TMAJOR if t_major else 0), C.byref(t_out),
             None if dist is None else dist.ctypes.data_as(_dp), C.c_void_p(stream) if stream else None))
         return t_out.value, dist

@@ -108,7 +108,17 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             for (int k = 0; k < Li.n_t; ++k) {
                 LonSample ls; double sddd;
                 make_lon_sample(sp, Li, k, P.dt, ls, sddd);
-                pbox[(size_t)slot * P.n_total + k] = profile_box(P, S.frenet0, brake, lat_ti, ls, k, Li.n_eval, D.ego.x, D.ego.y);
+                {   // the box k_cull derives (extent per horizon + position / tangent only) ...
+                    double d0, d1;
+                    lateral_extent(P, S.frenet0, brake, lat_ti, k, Li.n_eval, d0, d1);
+                    pbox[(size_t)slot * P.n_total + k] = profile_box_at(P, D, S.frenet0, sp, slot, k, d0, d1);
+                    // ... agrees with the one built from the full row
+                    const Box32 ref = profile_box(P, S.frenet0, brake, lat_ti, ls, k, Li.n_eval, D.ego.x, D.ego.y);
+                    const Box32 &got = pbox[(size_t)slot * P.n_total + k];
+                    const bool both_empty = !(ref.x0 <= ref.x1) && !(got.x0 <= got.x1);
+                    if (!both_empty && (fabsf(ref.x0 - got.x0) > 1e-4f || fabsf(ref.x1 - got.x1) > 1e-4f ||
+                                        fabsf(ref.y0 - got.y0) > 1e-4f || fabsf(ref.y1 - got.y1) > 1e-4f)) return -107;
+                }
                 box_merge(boxes[k], pbox[(size_t)slot * P.n_total + k]);
                 tab[0 * FOT_MAX_NT + k] = ls.s; tab[1 * FOT_MAX_NT + k] = ls.sd; tab[2 * FOT_MAX_NT + k] = ls.sdd;
                 tab[3 * FOT_MAX_NT + k] = ls.rx; tab[4 * FOT_MAX_NT + k] = ls.ry;

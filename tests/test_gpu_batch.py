@@ -356,3 +356,30 @@ def test_one_handle_alternating_streams_is_ordered():
         got = outs[i].cpu().numpy().tobytes()
         assert got == want[i % 4][: len(got)], f"plan call {i} differs from the serial run"
         assert torch.equal(obs[i], obs[0]), f"resample {i} was disturbed"
+
+
+def test_time_major_obstacle_layout_gives_identical_records():
+    """FOT_DYN_LAYOUT_TSP: the same tensors packed [T][S][P][2] -- records and candidate tables are those of the
+    reference layout; a ragged batch (single-sample, distributions of different S/P/T, static points, none)."""
+    kw = dict(syn.CONFIG3_PLANNER, chance_epsilon=0.1, collision_margin_inflation=1.15)
+    bp = BatchPlanner(waypoints=WP, **kw)
+    c3 = [syn.config3_instance(700 + i) for i in range(10)]
+    e = lambda inst: dict(x=inst.ego[0], y=inst.ego[1], yaw=inst.ego[2], v=inst.ego[3], a=inst.ego[4])
+    reqs = [PlanRequest(**e(c3[0]), dist=c3[0].dist),
+            PlanRequest(**e(c3[1]), dyn=c3[1].dist[0]),
+            PlanRequest(**e(c3[2]), dist=c3[2].dist[:7, :11, :33], static=syn.config2_instance(3).static),
+            PlanRequest(**e(c3[3])),
+            PlanRequest(**e(c3[4]), dist=c3[4].dist[:64 // 4, :, :1]),
+            PlanRequest(**e(c3[5]), dist=np.concatenate([c3[5].dist] * 3, axis=1)),           # 90 pedestrians
+            PlanRequest(**e(c3[6]), dyn=c3[6].dist[3, :5, :60 // 2])]
+    reqs += [request_from_instance(c) for c in c3[7:]]
+    ref = bp.plan_batch(reqs, obstacle_dtype=np.float32)
+    tables = [bp.candidates(i) for i in range(len(reqs))]
+    got = bp.plan_packed(PackedBatch(reqs, np.float32, dyn_layout_tsp=True))
+    assert bytes(got.records) == bytes(ref.records)
+    for i in range(len(reqs)):
+        for a, b in zip(bp.candidates(i), tables[i]):
+            np.testing.assert_array_equal(a, b, err_msg=f"inst {i}")
+    got64 = bp.plan_packed(PackedBatch(reqs, np.float64, dyn_layout_tsp=True))
+    ref64 = bp.plan_batch(reqs, obstacle_dtype=np.float64)
+    assert bytes(got64.records) == bytes(ref64.records)

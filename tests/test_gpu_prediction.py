@@ -104,6 +104,20 @@ def test_device_resident_handover_into_planner(engine):
     assert_record_matches_oracle(rec, oracle_plan_for_request(orc, params, sp, rq), label="resample->plan")
     assert rs.best_sample(dist) == orc.best_sample(got_t.astype(np.float64))[0]
 
+    # the same hand-over in the layout the broad phase wants: the resampler writes [T][S][P][2] (FOT_OUT_TMAJOR), the
+    # batch says so (FOT_DYN_LAYOUT_TSP); tensor = the transposed one above bit for bit, plan record identical
+    obs_tm = torch.zeros((T, S, P, 2), dtype=torch.float32, device=dev)
+    t2, dist2 = rs.resample_device(raw_dev.data_ptr(), np.float32, S, P, p0, cur, staleness, obs_tm.data_ptr(),
+                                   np.float32, stream.cuda_stream, want_sample_dist=True, t_major=True)
+    assert t2 == T
+    assert torch.equal(obs_tm, obs_dev.permute(2, 0, 1, 3).contiguous())
+    np.testing.assert_array_equal(dist2, dist)
+    pb_tm = PackedBatch([req], np.float32, dyn_layout_tsp=True)
+    out_tm = torch.zeros(_abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    engine.plan_packed_device(pb_tm.with_device_obstacles(None, obs_tm.data_ptr()), out_tm.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(out_tm, out)
+
 
 def test_predict_cv_float32_observation_mode(engine):
     rng = np.random.default_rng(12)
