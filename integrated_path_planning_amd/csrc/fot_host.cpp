@@ -107,6 +107,7 @@ struct fot_handle {
     int lanes_cfg = 1;                       // sub-batches a large batch is split into
     int lanes_used = 0;                      // lanes of the most recent plan call
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
+    PinnedBuf hSmallIn, hSmallOut;           // ... and, for small calls, pinned host blocks the kernels use directly
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
     bool last_valid = false;
     // profiling: event pairs around kernel launches
@@ -447,6 +448,7 @@ void fot_destroy(fot_handle *h)
     DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dShapes, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
+    h->hSmallIn.release(); h->hSmallOut.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->order_done) (void)hipEventDestroy(h->order_done);
@@ -708,6 +710,24 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
     const size_t elem = batch->obstacle_dtype == FOT_F32 ? sizeof(float) : sizeof(double);
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t st_bytes = (size_t)probe.n_static * 2 * elem, dy_bytes = (size_t)probe.dyn_src_points * 2 * elem;
+    const size_t out_bytes = sizeof(fot_result) * (size_t)batch->n_inst;
+    // A plan step for one or a few egos is latency, not bandwidth: its obstacle points (read once, by k_cull) and its
+    // records (written once, by k_select) then travel straight between the kernels and pinned host memory -- two copy
+    // operations and their synchronisation less per call.
+    constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
+    if (st_bytes + dy_bytes <= SMALL_CALL_BYTES && out_bytes <= SMALL_CALL_BYTES) {
+        const size_t dy_off = align256(st_bytes);
+        HIP_TRY(h, h->hSmallIn.ensure(dy_off + dy_bytes + 256));
+        HIP_TRY(h, h->hSmallOut.ensure(out_bytes));
+        char *in = (char *)h->hSmallIn.p;
+        if (st_bytes) std::memcpy(in, batch->static_xy, st_bytes);
+        if (dy_bytes) std::memcpy(in + dy_off, batch->dyn_xy, dy_bytes);
+        rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream);
+        if (rc != FOT_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(out, h->hSmallOut.p, out_bytes);
+        return FOT_OK;
+    }
     HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
     HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
     HIP_TRY(h, h->dOut.ensure(sizeof(fot_result) * (size_t)batch->n_inst));
