@@ -127,9 +127,12 @@ def self_launch(args):
 class Leg:
     """One timed configuration of the step loop: `n_ov` handles on `n_ov` streams, batches rotated."""
 
-    def __init__(self, n_ov, make_planner, dev, batches, out_bytes, pg, rehearse):
+    def __init__(self, n_ov, make_planner, dev, batches, out_bytes, pg, rehearse, n_inst=0, wire_bytes=0):
         import torch
         self.torch, self.dev, self.n_ov, self.pg, self.rehearse = torch, dev, n_ov, pg, rehearse
+        self.n_inst = n_inst
+        self.wire_dev = [torch.zeros(max(n_inst * wire_bytes, 1), dtype=torch.uint8, device=dev)
+                         for _ in range(n_ov)] if rehearse else None
         self.planners = [make_planner() for _ in range(n_ov)]
         # explicit streams only: a NULL stream handed to fot_plan_batch_device means "the handle's own stream", which
         # neither torch's default stream nor the collective that follows would wait for
@@ -148,12 +151,15 @@ class Leg:
             if self.pg is None:
                 self.planners[b].plan_packed_device(bstruct, self.outs[b].data_ptr(), self.streams[b].cuda_stream)
                 return
-            j, out, _ = self.pg.slot()                          # free again: the gather that last read it is done
+            j, send, _ = self.pg.slot()                         # free again: the gather that last read it is done
+            st = self.streams[b].cuda_stream
+            self.planners[b].plan_packed_device(bstruct, self.outs[b].data_ptr(), st)
+            # the records travel in the compact wire form (fot_pack_records_device, same stream)
             if self.rehearse:
-                self.planners[b].plan_packed_device(bstruct, self.outs[b].data_ptr(), self.streams[b].cuda_stream)
-                out.copy_(self.outs[b])                         # (synchronous D2H: rehearsal only)
+                self.planners[b].pack_records_device(self.n_inst, self.outs[b].data_ptr(), self.wire_dev[b].data_ptr(), st)
+                send.copy_(self.wire_dev[b])                    # (synchronous D2H: rehearsal only)
             else:
-                self.planners[b].plan_packed_device(bstruct, out.data_ptr(), self.streams[b].cuda_stream)
+                self.planners[b].pack_records_device(self.n_inst, self.outs[b].data_ptr(), send.data_ptr(), st)
             self.pg.launch(j)
 
     def fence(self):
@@ -243,10 +249,13 @@ def main():
     def make_planner():
         return BatchPlanner(waypoints=wp, device=local_rank, **kw)
 
+    from integrated_path_planning_amd.distributed import pack_records_host, wire_record_bytes
+    wire_bytes = wire_record_bytes(int(round(5.0 / kw["dt"])) + 1)         # CONFIG3_PLANNER: max_t 5 s
+
     def make_pg(depth):
-        # N > 1: the selected-path records of every rank are all-gathered (RCCL over xGMI) in every step; the gather of
-        # step i runs on the collective's stream while step i+1 plans into the other buffer pair
-        return PipelinedAllGather(out_bytes, world, torch.device("cpu") if rehearse else dev,
+        # N > 1: the selected-path records of every rank are all-gathered (RCCL over xGMI) in every step, in the compact
+        # wire form; the gather of step i runs on the collective's stream while step i+1 plans into the other buffers
+        return PipelinedAllGather(n_inst * wire_bytes, world, torch.device("cpu") if rehearse else dev,
                                   depth=depth) if world > 1 else None
 
     def reduce_max(x):
@@ -259,7 +268,7 @@ def main():
     # ---- serial leg: one plan call in flight; per-kernel HIP events -> kernel_ms, roofline
     n_ov = max(1, min(args.overlap, 4))
     pg1 = make_pg(2)
-    leg1 = Leg(1, make_planner, dev, bstructs, out_bytes, pg1, rehearse)
+    leg1 = Leg(1, make_planner, dev, bstructs, out_bytes, pg1, rehearse, n_inst, wire_bytes)
     el1, prof, first1 = leg1.run(args.warmup, args.steps, profile=True)
     el1 = reduce_max(el1)
     # the same leg once more without the event pairs around every launch (they cost a few microseconds per kernel)
@@ -268,7 +277,7 @@ def main():
     # ---- headline leg
     if n_ov > 1:
         pg = make_pg(max(2, n_ov))
-        leg = Leg(n_ov, make_planner, dev, bstructs, out_bytes, pg, rehearse)
+        leg = Leg(n_ov, make_planner, dev, bstructs, out_bytes, pg, rehearse, n_inst, wire_bytes)
         elapsed, _, first = leg.run(args.warmup, args.steps, profile=False)
         elapsed = reduce_max(elapsed)
     else:
@@ -303,19 +312,24 @@ def main():
     gathered_ok = None
     if world > 1:
         # one more gathered step on batch 0: every rank's slice of the gathered tensor must hold that rank's records
-        j, out, recv = pg.slot()
+        assert bp.n_total_samples * 60 + 176 <= wire_bytes
+        j, send, recv = pg.slot()
+        bp.plan_packed_device(bstructs[0], chk.data_ptr(), stream.cuda_stream)
         if rehearse:
-            bp.plan_packed_device(bstructs[0], chk.data_ptr(), stream.cuda_stream)
-            out.copy_(chk)
+            wtmp = torch.zeros(n_inst * wire_bytes, dtype=torch.uint8, device=dev)
+            bp.pack_records_device(n_inst, chk.data_ptr(), wtmp.data_ptr(), stream.cuda_stream)
+            send.copy_(wtmp)
         else:
-            bp.plan_packed_device(bstructs[0], out.data_ptr(), stream.cuda_stream)
+            send.zero_()
+            bp.pack_records_device(n_inst, chk.data_ptr(), send.data_ptr(), stream.cuda_stream)
         pg.launch(j)
         g = pg.drain().cpu().numpy()
         torch.cuda.synchronize(dev)
-        rb = _abi.RESULT_BYTES
-        mine = g[rank * n_inst * rb:(rank + 1) * n_inst * rb]
-        allrec = (_abi.Result * (world * n_inst)).from_buffer_copy(g.tobytes())
-        gathered_ok = bool(np.array_equal(mine, recs0_host) and all(r.n_cand > 0 for r in allrec))
+        mine = g[rank * n_inst * wire_bytes:(rank + 1) * n_inst * wire_bytes]
+        want = pack_records_host(recs0, n_inst, bp.n_total_samples)       # the host packer on this rank's own records
+        from integrated_path_planning_amd.distributed import unpack_records
+        allrec = unpack_records(g, world * n_inst, bp.n_total_samples)
+        gathered_ok = bool(np.array_equal(mine, want) and all(r.n_cand > 0 for r in allrec))
         ok_t = torch.tensor([1 if gathered_ok else 0], dtype=torch.int64, device="cpu" if rehearse else dev)
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         gathered_ok = bool(ok_t.item())
@@ -537,8 +551,8 @@ def main():
                                   obstacle_mb),
                    "instances_per_gpu": n_inst, "instances_total": n_inst * world, "rotation_batches": n_rot,
                    "plan_calls_in_flight": n_ov, "candidates_per_step": cand_total // args.steps,
-                   "parallelism": "instances sharded over %d GPU(s), RCCL all-gather of %d-byte path records"
-                                  % (world, _abi.RESULT_BYTES)},
+                   "parallelism": "instances sharded over %d GPU(s), RCCL all-gather of %d-byte wire records (fot_result: "
+                                  "%d bytes)" % (world, wire_bytes, _abi.RESULT_BYTES)},
         "layout_tsp_serial": layout_tsp,
         "serial": {"ms_per_step": el1 / args.steps * 1e3, "value": cand_serial / el1, "plan_calls_in_flight": 1,
                    "steps": args.steps, "kernel_ms": kernels,

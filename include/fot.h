@@ -274,6 +274,27 @@ int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const 
                              const double *ped_pos, const double *ped_vel, double ego_radius, double ped_radius,
                              int32_t use_footprint, fot_safety *out);
 
+/* ---- compact wire form of the records, for the all-gather of selected paths across GPUs ------------
+ * fot_result is the host view (float64, FOT_MAX_NT slots per array: 7 856 bytes).  On the wire a record is
+ *   fot_wire_header (176 bytes) | float path[15][n_total] (fot_result array order t .. c) | padding to 256 bytes
+ * e.g. 3 328 bytes at n_total = 51.  The header keeps cost, the state updates and the Frenet start state in float64;
+ * the path samples travel as float32 (2^-24 relative: 6e-6 m at 100 m, inside the 1e-5 the north star allows).
+ * n_total = round(max_t / dt) + 1 of the planner (fot_wire_n_total).  Pack / unpack on the host are pure format
+ * conversions (no GPU); fot_pack_records_device converts device-resident records on `stream`. */
+typedef struct fot_wire_header {
+    int32_t status, best_index, n_cand, n_keep;
+    double cost;
+    int32_t stats[8];
+    int32_t stats_valid, n_total;
+    double new_last_kappa, new_prev_s;
+    double frenet0[6], ref0[6];
+} fot_wire_header;
+int32_t fot_wire_n_total(const fot_handle *h);
+int32_t fot_wire_record_bytes(int32_t n_total);
+int fot_pack_records_device(fot_handle *h, int32_t n, const fot_result *records_dev, void *wire_dev, void *stream);
+int fot_pack_records_host(int32_t n_total, int32_t n, const fot_result *records, void *wire);
+int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result *records);
+
 /* ---- measurement (no reference counterpart: the reference times plan() with perf_counter,
  *      integrated_simulator.py:575-585) ----
  * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the

@@ -66,6 +66,13 @@ class Result(C.Structure):
                 + [(f, _ARR) for f in PATH_FIELDS])
 
 
+class WireHeader(C.Structure):
+    _fields_ = [("status", C.c_int32), ("best_index", C.c_int32), ("n_cand", C.c_int32), ("n_keep", C.c_int32),
+                ("cost", C.c_double), ("stats", C.c_int32 * 8), ("stats_valid", C.c_int32), ("n_total", C.c_int32),
+                ("new_last_kappa", C.c_double), ("new_prev_s", C.c_double),
+                ("frenet0", C.c_double * 6), ("ref0", C.c_double * 6)]
+
+
 class ResampleParams(C.Structure):
     _fields_ = [("sgan_dt", C.c_double), ("sim_dt", C.c_double), ("plan_horizon", C.c_double)]
 
@@ -93,7 +100,8 @@ SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_se
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
            "fot_debug_candidate_path", "fot_debug_margins", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
-           "fot_predict_cv", "fot_safety_metrics_batch", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
+           "fot_predict_cv", "fot_safety_metrics_batch", "fot_wire_n_total", "fot_wire_record_bytes",
+           "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 4                      # FOT_PROFILE_KERNELS (include/fot.h)
 MARGIN_GROUPS = 8                        # FOT_MARGIN_GROUPS
 MARGIN_NAMES = ["speed", "accel", "curvature", "lat_accel", "road", "collision", "stop_filter", "structural"]
@@ -186,6 +194,11 @@ def lib():
     L.fot_predict_cv.argtypes = [vp, C.POINTER(ResampleParams), C.c_int32, C.c_int32, vp, vp, C.c_int32, dp,
                                  C.c_double, vp, C.c_int32, C.c_int32, ip, vp]
     L.fot_safety_metrics_batch.argtypes = [vp, C.c_int32, dp, ip, dp, dp, C.c_double, C.c_double, C.c_int32, C.POINTER(Safety)]
+    L.fot_wire_n_total.argtypes = [vp]
+    L.fot_wire_record_bytes.argtypes = [C.c_int32]
+    L.fot_pack_records_device.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.fot_pack_records_host.argtypes = [C.c_int32, C.c_int32, vp, vp]
+    L.fot_unpack_records.argtypes = [C.c_int32, C.c_int32, vp, vp]
     L.fot_profile_enable.argtypes = [vp, C.c_int]
     L.fot_profile_read.argtypes = [vp, C.c_int, ip, dp]
     L.fot_profile_kernel_name.argtypes = [C.c_int]

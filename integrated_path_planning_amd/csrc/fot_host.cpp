@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -825,6 +826,81 @@ int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (!meta[1]) return fail(h, FOT_ERR_INVALID, "candidate index out of range");
     if (n_t) *n_t = meta[0];
+    return FOT_OK;
+}
+
+int32_t fot_wire_n_total(const fot_handle *h) { return h ? h->P.n_total : FOT_ERR_INVALID; }
+
+int32_t fot_wire_record_bytes(int32_t n_total)
+{
+    if (n_total < 1 || n_total > FOT_MAX_NT) return FOT_ERR_INVALID;
+    return (int32_t)align256(sizeof(fot_wire_header) + sizeof(float) * 15 * (size_t)n_total);
+}
+
+int fot_pack_records_device(fot_handle *h, int32_t n, const fot_result *records_dev, void *wire_dev, void *stream)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n <= 0) return n == 0 ? FOT_OK : fail(h, FOT_ERR_INVALID, "n < 0");
+    if (!records_dev || !wire_dev) return fail(h, FOT_ERR_INVALID, "NULL buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    LAUNCH_TRY(h, launch_pack_wire(n, h->P.n_total, fot_wire_record_bytes(h->P.n_total), records_dev,
+                                   (unsigned char *)wire_dev, st));
+    return FOT_OK;
+}
+
+static_assert(offsetof(fot_result, s) - offsetof(fot_result, t) == sizeof(double) * FOT_MAX_NT &&
+              offsetof(fot_result, c) - offsetof(fot_result, t) == sizeof(double) * FOT_MAX_NT * 14,
+              "the 15 path arrays of fot_result are contiguous");
+
+int fot_pack_records_host(int32_t n_total, int32_t n, const fot_result *records, void *wire)
+{
+    const int32_t stride = fot_wire_record_bytes(n_total);
+    if (stride < 0 || n < 0 || (n > 0 && (!records || !wire))) return FOT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        const fot_result &R = records[i];
+        unsigned char *w = (unsigned char *)wire + (size_t)i * stride;
+        std::memset(w, 0, (size_t)stride);
+        fot_wire_header H;
+        std::memset(&H, 0, sizeof(H));
+        H.status = R.status; H.best_index = R.best_index; H.n_cand = R.n_cand; H.n_keep = R.n_keep;
+        H.cost = R.cost; H.stats_valid = R.stats_valid; H.n_total = n_total;
+        H.new_last_kappa = R.new_last_kappa; H.new_prev_s = R.new_prev_s;
+        std::memcpy(H.stats, R.stats, sizeof(H.stats));
+        std::memcpy(H.frenet0, R.frenet0, sizeof(H.frenet0));
+        std::memcpy(H.ref0, R.ref0, sizeof(H.ref0));
+        std::memcpy(w, &H, sizeof(H));
+        float *path = (float *)(w + sizeof(H));
+        const double *arr = R.t;
+        for (int f = 0; f < 15; ++f)
+            for (int k = 0; k < n_total; ++k) path[f * n_total + k] = (float)arr[f * FOT_MAX_NT + k];
+    }
+    return FOT_OK;
+}
+
+int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result *records)
+{
+    const int32_t stride = fot_wire_record_bytes(n_total);
+    if (stride < 0 || n < 0 || (n > 0 && (!records || !wire))) return FOT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        const unsigned char *w = (const unsigned char *)wire + (size_t)i * stride;
+        fot_wire_header H;
+        std::memcpy(&H, w, sizeof(H));
+        if (H.n_total != n_total) return FOT_ERR_INVALID;
+        fot_result &R = records[i];
+        std::memset(&R, 0, sizeof(R));
+        R.status = H.status; R.best_index = H.best_index; R.n_cand = H.n_cand; R.n_keep = H.n_keep;
+        R.cost = H.cost; R.stats_valid = H.stats_valid;
+        R.new_last_kappa = H.new_last_kappa; R.new_prev_s = H.new_prev_s;
+        std::memcpy(R.stats, H.stats, sizeof(H.stats));
+        std::memcpy(R.frenet0, H.frenet0, sizeof(H.frenet0));
+        std::memcpy(R.ref0, H.ref0, sizeof(H.ref0));
+        const float *path = (const float *)(w + sizeof(H));
+        double *arr = R.t;
+        const int keep = H.n_keep < n_total ? H.n_keep : n_total;
+        for (int f = 0; f < 15; ++f)
+            for (int k = 0; k < keep; ++k) arr[f * FOT_MAX_NT + k] = (double)path[f * n_total + k];
+    }
     return FOT_OK;
 }
 

@@ -48,6 +48,7 @@ int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState 
                       SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st);
 int launch_debug_margins(const DevParams *P, const InstDesc *desc, const InstState *state, SplineView sp, int inst,
                          EntryArrays e, int cap, double *out, hipStream_t st);
+int launch_pack_wire(int n, int n_total, int stride, const fot_result *src, unsigned char *dst, hipStream_t st);
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
 int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
                     int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,

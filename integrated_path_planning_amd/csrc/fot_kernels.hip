@@ -1042,6 +1042,32 @@ k_debug_margins(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ d
 }
 
 // ---------------------------------------------------------------------------
+// wire form of the records (fot_pack_records_device): one wave per record
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(WAVE)
+k_pack_wire(int n, int n_total, int stride, const fot_result *__restrict__ src, unsigned char *__restrict__ dst)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const fot_result &R = src[i];
+    unsigned char *w = dst + (int64_t)i * stride;
+    fot_wire_header *H = (fot_wire_header *)w;
+    if (lane == 0) {
+        H->status = R.status; H->best_index = R.best_index; H->n_cand = R.n_cand; H->n_keep = R.n_keep;
+        H->cost = R.cost; H->stats_valid = R.stats_valid; H->n_total = n_total;
+        H->new_last_kappa = R.new_last_kappa; H->new_prev_s = R.new_prev_s;
+    }
+    if (lane < 8) H->stats[lane] = R.stats[lane];
+    if (lane < 6) { H->frenet0[lane] = R.frenet0[lane]; H->ref0[lane] = R.ref0[lane]; }
+    float *path = (float *)(w + sizeof(fot_wire_header));
+    const double *arr = R.t;                                  // the 15 arrays are contiguous, FOT_MAX_NT doubles each
+    for (int f = 0; f < 15; ++f)
+        if (lane < n_total) path[f * n_total + lane] = (float)arr[f * FOT_MAX_NT + lane];
+    // padding bytes stay as they are (never read)
+}
+
+// ---------------------------------------------------------------------------
 // spline evaluation (fot_spline_eval)
 // ---------------------------------------------------------------------------
 
@@ -1345,6 +1371,14 @@ int launch_debug_margins(const DevParams *P, const InstDesc *desc, const InstSta
 {
     if (cap <= 0) return 0;
     k_debug_margins<<<(cap + WAVE - 1) / WAVE, WAVE, 0, st>>>(P, desc, state, sp, inst, e.cnt, e.e64, e.sid, cap, out);
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pack_wire(int n, int n_total, int stride, const fot_result *src, unsigned char *dst, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    k_pack_wire<<<n, WAVE, 0, st>>>(n, n_total, stride, src, dst);
     FOT_LAUNCH_CHECK();
     return 0;
 }

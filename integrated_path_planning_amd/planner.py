@@ -165,6 +165,17 @@ class BatchPlanner:
         _abi.check(self._h, self._lib.fot_plan_batch_device(self._h, C.byref(batch_struct), C.c_void_p(out_dev_ptr),
                                                             C.c_void_p(stream) if stream else None))
 
+    @property
+    def n_total_samples(self) -> int:
+        """round(max_t / dt) + 1: samples per full-length candidate (the wire form's array length)."""
+        return int(self._lib.fot_wire_n_total(self._h))
+
+    def pack_records_device(self, n: int, records_dev_ptr: int, wire_dev_ptr: int, stream: Optional[int] = None):
+        """fot_result[n] in HBM -> compact wire records in HBM (fot_pack_records_device), enqueued on ``stream``."""
+        _abi.check(self._h, self._lib.fot_pack_records_device(self._h, int(n), C.c_void_p(records_dev_ptr),
+                                                              C.c_void_p(wire_dev_ptr),
+                                                              C.c_void_p(stream) if stream else None))
+
     def synchronize(self):
         _abi.check(self._h, self._lib.fot_synchronize(self._h))
 
