@@ -7,20 +7,22 @@ N episodes that share planner parameters and reference path advance together, an
 
 * ONE constant-velocity prediction launch over the pedestrians of all running episodes (row f1),
 * ONE safety-metrics launch before planning and one after the ego update (row f3),
-* ONE ``fot_plan_batch`` holding every escalation level of every episode (row f2),
+* ONE ``fot_plan_batch`` with the current configuration of every episode and, only in steps where some first attempt
+  fails, ONE more with every further escalation level of the failed episodes (row f2),
 * ONE nearest-point launch for the goal test,
 
-instead of N x (1 + up to 3 retries) sequential ``plan()`` calls.  Pedestrians are replayed tracks -- the contract of the
-reference's ``ReplayPedestrianSource`` (src/simulation/replay_source.py:31-118); the Social-Force simulator and the
-Social-GAN network are outside SURVEY 8.  ``save_results`` writes ``trajectory.npz`` with the reference's keys, dtypes
-and array shapes (integrated_simulator.py:906-982), so the existing analysis scripts read it unchanged.
+instead of N x (1 + up to 3 retries) sequential ``plan()`` calls.  All per-episode state (ego, state machine, planner
+caches, pedestrian frame) lives in arrays; the reference's scalar control flow is restated as masked array updates, and
+the histories are recorded as per-step arrays that turn into ``StepRecord`` objects only when read.  Pedestrians are
+replayed tracks -- the contract of the reference's ``ReplayPedestrianSource`` (src/simulation/replay_source.py:31-118);
+the Social-Force simulator and the Social-GAN network are outside SURVEY 8.  ``save_results`` writes
+``trajectory.npz`` with the reference's keys, dtypes and array shapes (integrated_simulator.py:906-982), so the
+existing analysis scripts read it unchanged.
 
-The control logic on the host is the reference's scalar logic; all arithmetic on candidate paths, predictions and
-metrics runs in libfot.
+All arithmetic on candidate paths, predictions and metrics runs in libfot.
 """
 from __future__ import annotations
 
-import copy
 import os
 import time
 from collections import deque
@@ -34,7 +36,8 @@ from .data_structures import EgoVehicleState, FrenetPath
 from .footprint import EgoFootprint
 from .planner import BatchPlanner
 from .prediction import PredictionResampler
-from .state_machine import FailSafeStateMachine, SpeculativePlanningCycle, VehicleState
+from . import _abi
+from .state_machine import FailSafeStateMachine, VehicleState
 
 
 class ReplayPedestrians:
@@ -102,22 +105,6 @@ class Observer:
         return self.timestamps[-1] if self.timestamps else None
 
 
-class _PlannerState:
-    """The per-episode state a FrenetPlanner keeps between calls; the engine is shared by all episodes."""
-
-    class _Conv:
-        _prev_s: Optional[float] = None
-
-    def __init__(self, engine: BatchPlanner):
-        self.engine = engine
-        self.converter = _PlannerState._Conv()
-        self._last_kappa = 0.0
-        self.last_check_stats = None
-
-    def reset_ego_curvature(self) -> None:
-        self._last_kappa = 0.0
-
-
 @dataclass
 class StepRecord:
     """What SimulationResult holds of one step (data_structures.py:256-281), as plain arrays."""
@@ -132,20 +119,100 @@ class StepRecord:
     processing_times: Dict[str, float]
 
 
+_STATES = (VehicleState.NORMAL, VehicleState.CAUTION, VehicleState.EMERGENCY)      # array code 0, 1, 2
+
+
+class _VectorStateMachine:
+    """``FailSafeStateMachine`` (state_machine.py here, src/core/state_machine.py:29-278 in the reference) for all
+    episodes at once: the same transitions and planner configurations, as masked array updates.  Codes 0 / 1 / 2 =
+    NORMAL / CAUTION / EMERGENCY."""
+
+    def __init__(self, config, n: int):
+        one = FailSafeStateMachine(config)                       # the scalar class resolves the configuration keys
+        c = config
+        self.clr_caution, self.clr_emergency = one.clearance_caution, one.clearance_emergency
+        self.trig_c, self.trig_h = one.trigger_clearance_caution, one.trigger_time_headway
+        self.env_decel, self.env_standoff = one.envelope_decel, one.envelope_standoff
+        self.target = float(c.ego_target_speed)
+        self.c_accel = c.ego_max_accel * getattr(c, "state_machine_caution_accel_multiplier", 1.5)
+        self.c_speed_mult = getattr(c, "state_machine_caution_speed_multiplier", 0.8)
+        self.c_speed = c.ego_max_speed * self.c_speed_mult
+        self.e_accel = c.ego_max_accel * getattr(c, "state_machine_emergency_accel_multiplier", 3.0)
+        self.e_lat = getattr(c, "ego_max_lat_accel", 3.0) * getattr(c, "state_machine_emergency_lat_accel_multiplier", 2.0)
+        self.state = np.zeros(n, np.int64)
+        self.fails = np.zeros(n, np.int64)
+        self.clear = np.full(n, np.inf)                          # _last_clearance
+        self.clear_ahead = np.full(n, np.inf)                    # _last_clearance_ahead
+
+    def config(self, state: np.ndarray, clear_ahead: np.ndarray):
+        """_get_planner_config (:181-247) -> target speed, overrides [n, 4] (NaN = absent), max_stop (NaN = None)."""
+        n = len(state)
+        fin = np.isfinite(clear_ahead)
+        has_env = fin & (self.env_decel > 0.0)
+        v_env = np.sqrt(2.0 * self.env_decel * np.maximum(np.where(fin, clear_ahead, 0.0) - self.env_standoff, 0.0))
+        stop_room = np.where(fin, np.maximum(np.where(fin, clear_ahead, 0.0) - 0.2, 0.05), np.nan)
+        target = np.full(n, self.target)
+        ov = np.full((n, 4), np.nan)
+        stop = np.full(n, np.nan)
+        nm, ca, em = state == 0, state == 1, state == 2
+        target = np.where(nm & has_env & (v_env < self.target), v_env, target)
+        t_ca = np.where(has_env, np.minimum(self.target * self.c_speed_mult, v_env), self.target * self.c_speed_mult)
+        target = np.where(ca, t_ca, target)
+        stop = np.where(ca & has_env & (v_env <= 0.0), stop_room, stop)
+        ov[ca, 1], ov[ca, 0] = self.c_accel, self.c_speed
+        target = np.where(em, 0.0, target)
+        ov[em, 1], ov[em, 3] = self.e_accel, self.e_lat
+        if self.env_decel > 0.0:
+            stop = np.where(em, stop_room, stop)
+        return target, ov, stop
+
+    def update(self, sel: np.ndarray, found: np.ndarray, clearance: np.ndarray, clearance_ahead: np.ndarray,
+               speed: np.ndarray) -> None:
+        """update() (:116-179) for the episodes ``sel`` (index array): observe the metrics, then the transitions."""
+        self.clear[sel], self.clear_ahead[sel] = clearance, clearance_ahead
+        st, fl = self.state[sel], self.fails[sel]
+        trigger = self.trig_c + self.trig_h * np.maximum(speed, 0.0)
+        nm, ca, em = st == 0, st == 1, st == 2
+        new_st, new_fl = st.copy(), fl.copy()
+        a = nm & ~found
+        new_st[a] = 1; new_fl[a] = fl[a] + 1
+        b = nm & found & (trigger > 0.0) & (clearance < trigger)
+        new_st[b] = 1; new_fl[b] = 0
+        new_fl[nm & found & ~b] = 0
+        c1 = ca & found & (fl == 0)
+        new_st[c1 & (clearance > np.maximum(self.clr_caution, trigger))] = 0
+        c2 = ca & ~c1 & ~found
+        new_st[c2] = 2; new_fl[c2] = fl[c2] + 1
+        new_fl[ca & ~c1 & found] = 0
+        new_st[em & found & (clearance > self.clr_emergency)] = 1
+        self.state[sel], self.fails[sel] = new_st, new_fl
+
+
+class EpisodeHistory:
+    """One episode's steps as a read-only sequence of ``StepRecord`` built on demand from the loop's per-step arrays."""
+
+    def __init__(self, loop: "BatchedClosedLoop", e: int):
+        self._loop, self._e, self._steps = loop, e, []
+
+    def __len__(self):
+        return len(self._steps)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self._loop._record(self._steps[i], self._e)
+
+
 @dataclass
 class Episode:
-    peds: ReplayPedestrians
-    observer: Observer
-    ego: EgoVehicleState
-    sm: FailSafeStateMachine
-    pstate: _PlannerState
-    cycle: SpeculativePlanningCycle
-    goal_prev_s: Optional[float] = None          # nearest-point cache of the simulator's own converter (:873)
-    last_clearance: float = float("inf")
-    time: float = 0.0
-    step_count: int = 0
-    history: List[StepRecord] = field(default_factory=list)
+    history: EpisodeHistory
     termination_reason: Optional[str] = None
+    step_count: int = 0
 
 
 def _cfg(config, name, default=None):
@@ -196,7 +263,13 @@ class BatchedClosedLoop:
     config: the scenario dictionary (or an object with the same attributes) the reference's SimulationConfig is
     built from; ped_tracks: one [T, N_i, 2] array of replayed pedestrian positions per episode (frame spacing
     config.dt, frame 0 = time 0 before warm-up); ego_initial_states: optional per-episode [x, y, yaw, v, a].
+
+    The state of all episodes lives in arrays (ego, state machine, planner caches, pedestrian frames); a lock step is a
+    fixed sequence of array operations and five libfot calls, whatever the number of episodes.  Histories are recorded
+    as per-step arrays and turned into ``StepRecord`` objects only when somebody reads them.
     """
+
+    MAX_REPLAN = 3                                               # integrated_simulator.py:383
 
     def __init__(self, config, ped_tracks: Sequence[np.ndarray], ego_initial_states: Optional[Sequence] = None,
                  device: int = -1, engine=None, resampler=None):
@@ -230,20 +303,26 @@ class BatchedClosedLoop:
         n = len(ped_tracks)
         if ego_initial_states is None:
             ego_initial_states = [c.ego_initial_state] * n
-        self.episodes: List[Episode] = []
-        for tracks, e0 in zip(ped_tracks, ego_initial_states):
-            e0 = np.asarray(e0, float)
-            sm = FailSafeStateMachine(c)
-            ps = _PlannerState(self.engine)
-            ego = EgoVehicleState(x=e0[0], y=e0[1], yaw=e0[2], v=e0[3], a=e0[4], jerk=e0[5] if len(e0) > 5 else 0.0,
-                                  timestamp=0.0)
-            ego.state = sm.current_state
-            ep = Episode(peds=ReplayPedestrians(tracks, c.dt), observer=Observer(c.obs_len, c.dt, self.sgan_dt),
-                         ego=ego, sm=sm, pstate=ps,
-                         cycle=SpeculativePlanningCycle(ps, sm, c.ego_target_speed, max_replan_attempts=3))
-            if engine is None:
-                ep.cycle._path_kw = {"as_arrays": True}
-            self.episodes.append(ep)
+        # ---- pedestrians: replayed tracks, every episode on the same clock (replay_source.py:31-118)
+        self.peds = [ReplayPedestrians(tr, c.dt) for tr in ped_tracks]
+        self.n_frames = np.array([p.n_frames for p in self.peds])
+        self.ped_off = np.concatenate([[0], np.cumsum([p.n_peds for p in self.peds])]).astype(np.int64)
+        self.frame, self.ped_time = 0, 0.0
+        self.observer = Observer(c.obs_len, c.dt, self.sgan_dt)      # one sampling clock; samples = all episodes' peds
+        # ---- ego, state machine and planner caches as arrays
+        e0 = np.array([np.asarray(v, float)[:5] for v in ego_initial_states], dtype=float).reshape(n, 5)
+        self.ego = e0.copy()                                         # x, y, yaw, v, a
+        self.jerk = np.array([float(np.asarray(v, float)[5]) if len(v) > 5 else 0.0 for v in ego_initial_states])
+        self.sm = _VectorStateMachine(c, n)
+        self.prev_s = np.full(n, np.nan)                             # planner.converter._prev_s (NaN: not set yet)
+        self.last_kappa = np.zeros(n)                                # planner._last_kappa
+        self.goal_prev_s = np.full(n, np.nan)                        # the simulator's own converter (:873)
+        self.last_clearance = np.full(n, np.inf)
+        self.last_stats = np.full((n, 8), -1, np.int64)              # last_check_stats (-1 row: None)
+        self.time = 0.0
+        self.alive = np.ones(n, bool)
+        self._steps: List[dict] = []
+        self.episodes: List[Episode] = [Episode(EpisodeHistory(self, e)) for e in range(n)]
         self._warmup()
 
     def close(self) -> None:
@@ -259,147 +338,245 @@ class BatchedClosedLoop:
         self.close()
 
     # ------------------------------------------------------------------------------------------------------
+    def _ped_frame(self, which: str, sel: np.ndarray) -> np.ndarray:
+        """positions / velocities of the episodes ``sel`` at the current frame, concatenated [sum P, 2]."""
+        return np.concatenate([getattr(self.peds[e], which)[min(self.frame, self.n_frames[e] - 1)] for e in sel], axis=0)
+
+    def _advance_pedestrians(self) -> None:
+        self.frame += 1
+        self.ped_time += self.dt
+        every = np.arange(len(self.peds))
+        self.observer.update(self._ped_frame("trajectories", every), self.ped_time)
+
     def _warmup(self) -> None:
         """integrated_simulator.py:406-422: fill the observers before time 0."""
         c = self.config
-        steps = int(c.obs_len * self.sgan_dt / c.dt)
-        for ep in self.episodes:
-            for _ in range(steps):
-                ep.peds.step()
-                ep.observer.update(ep.peds.positions, ep.peds.time)
+        for _ in range(int(c.obs_len * self.sgan_dt / c.dt)):
+            self._advance_pedestrians()
 
     @property
     def running(self) -> List[Episode]:
-        return [ep for ep in self.episodes if ep.termination_reason is None]
+        return [ep for ep, a in zip(self.episodes, self.alive) if a]
 
-    def _metrics(self, eps: List[Episode]) -> List[Dict[str, Any]]:
-        egos = [[ep.ego.x, ep.ego.y, ep.ego.yaw, ep.ego.v] for ep in eps]
-        m = self.engine.safety_metrics(egos, [ep.peds.positions for ep in eps],
-                                       [ep.peds.current_velocities for ep in eps], self.ego_radius, self.ped_radius,
-                                       use_footprint=self.footprint is not None)
-        return [{"min_distance": float(r["min_distance"]), "collision": bool(r["collision"]), "ttc": float(r["ttc"]),
-                 "clearance": float(r["clearance"]), "clearance_ahead": float(r["clearance_ahead"])} for r in m]
+    def _metrics(self, sel, off, pos, vel):
+        egos = np.stack([self.ego[sel, 0], self.ego[sel, 1], self.ego[sel, 2], self.ego[sel, 3]], axis=1)
+        return self.engine.safety_metrics_cat(egos, off, pos, vel, self.ego_radius, self.ped_radius,
+                                              use_footprint=self.footprint is not None)
 
-    def _predict(self, eps: List[Episode]):
-        """_update_prediction (:424-527) for every episode; one CV launch over all ready episodes' pedestrians."""
-        preds: List[Optional[np.ndarray]] = [None] * len(eps)
-        dyns: List[np.ndarray] = [None] * len(eps)
-        ready = [i for i, ep in enumerate(eps) if ep.observer.is_ready]
+    def _predict(self, sel, off, pos):
+        """_update_prediction (:424-527): one CV launch over the pedestrians of all running episodes.  Returns the
+        prediction [sum P, T, 2] (None while the observer fills) and, per episode, whether the current positions are
+        prepended (:503-511)."""
         t0 = time.perf_counter()
-        if ready:
-            groups: Dict[float, List[int]] = {}
-            for i in ready:                                          # lock-step episodes share their staleness
-                ep = eps[i]
-                last = ep.observer.last_sample_time
-                stale = max(ep.peds.time - last, 0.0) if last is not None else 0.0
-                groups.setdefault(stale, []).append(i)
-            for stale, idx in groups.items():
-                obs = [np.stack(list(eps[i].observer.history)[-2:], axis=0) for i in idx]   # CV reads the last two samples
-                cat = np.concatenate(obs, axis=1)                    # [obs_len, sum P, 2]
-                out = self.resampler.predict_cv(cat, staleness=stale, float32_observations=True)
-                o = 0
-                for i, ob in zip(idx, obs):
-                    preds[i] = out[o:o + ob.shape[1]]
-                    o += ob.shape[1]
-        t_pred = (time.perf_counter() - t0) / max(len(ready), 1)
-        for i, ep in enumerate(eps):
-            cur = ep.peds.positions[:, None, :]
-            d = preds[i] if preds[i] is not None else cur              # not ready: current positions only (:495-498)
-            # np.allclose(d[:, 0], cur[:, 0]) of the reference (rtol 1e-5, atol 1e-8; finite inputs), without its overhead
-            if preds[i] is not None and not (d.shape[1] >= 1 and bool(
-                    np.all(np.abs(d[:, 0, :] - cur[:, 0, :]) <= 1e-8 + 1e-5 * np.abs(cur[:, 0, :])))):
-                d = np.concatenate([cur, d], axis=1)                    # prepend the t=0 positions (:503-511)
-            dyns[i] = d
-        return preds, dyns, t_pred
-
-    def _apply_emergency_stop(self, ep: Episode, old_a: float) -> None:
-        """integrated_simulator.py:749-802."""
-        c = self.config
-        ego = copy.copy(ep.ego)
-        cap = getattr(c, "ego_emergency_decel", None)
-        if cap is None:
-            cap = c.ego_max_accel * 2.0
-        clearance = ep.last_clearance
-        if np.isfinite(clearance):
-            stop_room = max(clearance - 0.2, 0.05)
-            required = ego.v ** 2 / (2.0 * stop_room)
-        else:
-            required = cap
-        max_dec = float(np.clip(required, c.ego_max_accel, cap))
-        ego.x += ego.v * np.cos(ego.yaw) * c.dt
-        ego.y += ego.v * np.sin(ego.yaw) * c.dt
-        ego.v = max(0.0, ego.v - max_dec * c.dt)
-        new_a = -max_dec if ego.v > 0 else 0.0
-        ego.jerk = (new_a - old_a) / c.dt
-        ego.a = new_a
-        ego.timestamp = ep.time + c.dt
-        ep.ego = ego
-        ep.pstate.reset_ego_curvature()
-
-    def _update_ego(self, ep: Episode, path: Optional[FrenetPath]) -> None:
-        """integrated_simulator.py:655-676."""
-        old_a = ep.ego.a
-        if path is not None and len(path) >= 2:
-            ego = path.get_state_at_index(1)
-            ego.jerk = (ego.a - old_a) / self.dt
-            ego.timestamp = ep.time + self.dt
-            ego.state = ep.sm.current_state
-            ep.ego = ego
-        else:
-            self._apply_emergency_stop(ep, old_a)
-            ep.ego.state = ep.sm.current_state
+        pred = None
+        if self.observer.is_ready:
+            rows = np.concatenate([np.arange(self.ped_off[e], self.ped_off[e + 1]) for e in sel])
+            hist = self.observer.history
+            obs = np.stack([hist[-2][rows], hist[-1][rows]], axis=0)          # CV reads the last two samples
+            last = self.observer.last_sample_time
+            stale = max(self.ped_time - last, 0.0) if last is not None else 0.0
+            pred = self.resampler.predict_cv(obs, staleness=stale, float32_observations=True)
+        t_pred = (time.perf_counter() - t0) / len(sel)
+        if pred is None:
+            return None, np.zeros(len(sel), bool), t_pred
+        # np.allclose(pred[:, 0], current) of the reference (rtol 1e-5, atol 1e-8; finite inputs), per episode
+        close = np.all(np.abs(pred[:, 0, :] - pos) <= 1e-8 + 1e-5 * np.abs(pos), axis=1)
+        same = np.logical_and.reduceat(close, off[:-1]) if len(close) else np.zeros(len(sel), bool)
+        return pred, ~same, t_pred
 
     # ------------------------------------------------------------------------------------------------------
     def step(self) -> int:
         """One lock step of every running episode (integrated_simulator.py:678-747); returns how many ran."""
-        eps = self.running
-        if not eps:
+        sel = np.flatnonzero(self.alive)
+        n = len(sel)
+        if n == 0:
             return 0
-        for ep in eps:                                                # 1. pedestrians + observer
-            ep.peds.step()
-            ep.observer.update(ep.peds.positions, ep.peds.time)
-        preds, dyns, t_pred = self._predict(eps)                      # 2. prediction
-        metrics = self._metrics(eps)                                  # 3. planning cycle (:529-653)
+        c, sm = self.config, self.sm
+        self._advance_pedestrians()                                   # 1. pedestrians + observer
+        counts = (self.ped_off[sel + 1] - self.ped_off[sel]).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(counts)])
+        pos = self._ped_frame("trajectories", sel)
+        vel = self._ped_frame("velocities", sel)
+        pred, prepend, t_pred = self._predict(sel, off, pos)          # 2. prediction
+        m = self._metrics(sel, off, pos, vel)                         # 3. planning cycle (:529-653)
         t0 = time.perf_counter()
-        reqs: List[PlanRequest] = []
-        plans = []
-        static = self.static_obstacle_points                          # (fot_batch.static_off is a prefix array: one copy per request)
-        for ep, dyn, m in zip(eps, dyns, metrics):
-            ep.last_clearance = m.get("clearance_ahead", m.get("clearance", float("inf")))
-            ladder, r, budget = ep.cycle.prepare(ep.ego, static, dyn, m)
-            plans.append((len(reqs), ladder, budget))
-            reqs.extend(r)
-        res = self.engine.plan_batch(reqs)
-        t_plan = (time.perf_counter() - t0) / len(eps)
-        for ep, (base, ladder, budget), m, pred in zip(eps, plans, metrics, preds):
-            ego_before = ep.ego
-            out = ep.cycle.finish(ladder, budget, res, base, ego_before, m)
-            if out.retries:                                           # the retries re-label the current state (:613-615)
-                ep.ego = copy.copy(ep.ego)
-                ep.ego.state = out.states[-1]
-            self._update_ego(ep, out.planned_path)                    # 4. ego update
-            ep._pending = (pred, out.planned_path)
-        after = self._metrics(eps)                                    # 5. result metrics on the new ego state
-        goal = self.engine.frenet_states([PlanRequest(ep.ego.x, ep.ego.y, ep.ego.yaw, ep.ego.v, ep.ego.a,
-                                                      prev_s=ep.goal_prev_s) for ep in eps])[2]
-        for ep, m, s_now in zip(eps, after, goal):
-            pred, path = ep._pending
-            stats = ep.pstate.last_check_stats
-            if stats is not None:
-                m["n_collision_rejected"] = stats.get("collision_error", 0)
-            ep.history.append(StepRecord(ep.time, ep.ego, ep.peds.positions.copy(), ep.peds.current_velocities.copy(),
-                                         ep.peds.goals.copy(), pred, path, m,
-                                         {"prediction": t_pred, "planning": t_plan}))
-            ep.time += self.dt
-            ep.step_count += 1
-            ep.goal_prev_s = float(s_now)
-            if m["collision"]:                                        # run(): :864-883
-                ep.termination_reason = "collision"
-            elif self.s_end - float(s_now) < 2.0:
-                ep.termination_reason = "goal"
-        return len(eps)
+        clearance, clearance_ahead = m["clearance"].copy(), m["clearance_ahead"].copy()
+        self.last_clearance[sel] = clearance_ahead
+        speed = self.ego[sel, 3].copy()
+        # --- level 0 of every episode = the current state's configuration (issued from LAST step's clearance)
+        st0 = sm.state[sel]
+        n_lvl = np.minimum(3 - st0, 1 + self.MAX_REPLAN)             # NORMAL -> CAUTION -> EMERGENCY, then no change
+        everyone = np.arange(n)
+        # --- obstacles: the same static points for every request; one dynamic tensor per episode, shared by its levels
+        pts = self.static_obstacle_points
+        if pred is None:                                              # not ready: current positions only (:495-498)
+            dyn, t_len = pos[:, None, :], np.ones(n, np.int64)
+        elif prepend.all():
+            dyn, t_len = np.concatenate([pos[:, None, :], pred], axis=1), np.full(n, pred.shape[1] + 1, np.int64)
+        elif not prepend.any():
+            dyn, t_len = pred, np.full(n, pred.shape[1], np.int64)
+        else:                                                         # mixed: the shorter tensors end one sample early
+            T1 = pred.shape[1] + 1
+            dyn = np.concatenate([pos[:, None, :], pred], axis=1)
+            ped_pre = np.repeat(prepend, counts)
+            dyn[~ped_pre, :-1] = pred[~ped_pre]
+            t_len = np.where(prepend, T1, T1 - 1)
+        T_alloc = dyn.shape[1]
+        if t_len.min() != T_alloc:                                    # mixed case: per-episode [P, t_len, 2] blocks
+            blocks = [np.ascontiguousarray(dyn[off[i]:off[i + 1], :t_len[i]]).reshape(-1, 2) for i in range(n)]
+            d_xy = np.concatenate(blocks, axis=0)
+            d_off_ep = np.concatenate([[0], np.cumsum(counts * t_len)])[:-1]
+        else:
+            d_xy = np.ascontiguousarray(dyn).reshape(-1, 2)
+            d_off_ep = off[:-1] * T_alloc
 
-    def run(self, n_steps: Optional[int] = None) -> List[List[StepRecord]]:
+        def plan(who, state, clear_ahead, prev_s, chain):
+            """one plan() per entry: episode who[i] under the configuration of `state[i]`; chain[i]: nearest-point
+            cache handed over from the entry before (the next escalation level of the same episode)"""
+            tgt, ov, stop = sm.config(state, clear_ahead)
+            r = len(who)
+            ego = np.zeros(r, dtype=self.engine.EGO_DT)
+            for col, f in enumerate(("x", "y", "yaw", "v", "a")):
+                ego[f] = self.ego[sel, col][who]
+            ego["last_kappa"] = self.last_kappa[sel][who]
+            ego["has_prev_s"] = np.where(chain, 2, ~np.isnan(prev_s))
+            ego["prev_s"] = np.where(chain | np.isnan(prev_s), 0.0, prev_s)
+            s_xy = np.tile(pts, (r, 1)) if len(pts) else None
+            s_off = np.arange(r + 1, dtype=np.int64) * len(pts) if len(pts) else None
+            d_dims = np.stack([np.where(counts[who] > 0, 1, 0), np.ones(r, np.int64), counts[who], t_len[who]], axis=1)
+            return self.engine.plan_arrays(ego, tgt, ov, stop, s_xy, s_off, d_xy, d_off_ep[who], d_dims)
+
+        rec = plan(everyone, st0, sm.clear_ahead[sel], self.prev_s[sel], np.zeros(n, bool))
+        # --- replay of the retry loop (:576-653).  Episodes whose first attempt failed get every further escalation
+        #     level they can reach planned in ONE more launch (the configurations update(False, ...) would issue on THIS
+        #     step's metrics, nearest-point cache chained from attempt to attempt); the control flow is then replayed.
+        found_all = rec["status"] == 0
+        cur = everyone.copy()                                         # record of each episode's current attempt
+        path_rec = np.full(n, -1, np.int64)
+        failed = np.flatnonzero(~found_all[:n] & (n_lvl > 1))
+        if len(failed):
+            extra = n_lvl[failed] - 1
+            who = np.repeat(failed, extra)
+            base1 = np.concatenate([[0], np.cumsum(extra)])[:-1]
+            lvl = 1 + np.arange(len(who)) - np.repeat(base1, extra)
+            nps0 = rec["new_prev_s"][who]
+            rec = np.concatenate([rec, plan(who, st0[who] + lvl, clearance_ahead[who],
+                                            np.where(np.isnan(nps0), self.prev_s[sel][who], nps0), lvl > 1)])
+            found_all = rec["status"] == 0
+            next_rec = np.full(n, -1, np.int64)                       # record of level 1 of each failed episode
+            next_rec[failed] = n + base1
+        t_plan = (time.perf_counter() - t0) / n
+
+        def adopt(which, r):                                          # planner state after a plan() call
+            nps = rec["new_prev_s"][r]
+            e = sel[which]
+            self.prev_s[e] = np.where(np.isnan(nps), self.prev_s[e], nps)
+            self.last_stats[e] = np.where(rec["stats_valid"][r][:, None] != 0, rec["stats"][r], -1)
+            ok = found_all[r]
+            self.last_kappa[e[ok]] = rec["new_last_kappa"][r[ok]]
+            path_rec[which[ok]] = r[ok]
+
+        adopt(everyone, cur)
+        found = found_all[cur]
+        issued = st0.copy()                                           # state of the configuration the attempt ran under
+        sm.update(sel, found, clearance, clearance_ahead, speed)
+        retries = np.zeros(n, np.int64)
+        active = ~found & (sm.state[sel] != issued) & (retries < self.MAX_REPLAN) & (retries + 1 < n_lvl)
+        while active.any():
+            w = np.flatnonzero(active)
+            cur[w] = np.where(retries[w] == 0, next_rec[w], cur[w] + 1)
+            retries[w] += 1
+            adopt(w, cur[w])
+            ok = found_all[cur[w]]
+            found[w[ok]] = True
+            issued[w] = sm.state[sel[w]]
+            again = w[~ok]
+            if len(again):
+                sm.update(sel[again], np.zeros(len(again), bool), clearance[again], clearance_ahead[again], speed[again])
+            active = np.zeros(n, bool)
+            active[again] = (sm.state[sel[again]] != issued[again]) & (retries[again] < self.MAX_REPLAN) & \
+                            (retries[again] + 1 < n_lvl[again])
+        # --- 4. ego update (:655-676) or emergency stop (:749-802)
+        old_a = self.ego[sel, 4].copy()
+        keep = np.where(path_rec >= 0, rec["n_keep"][np.maximum(path_rec, 0)], 0)
+        follow = keep >= 2
+        new_ego = self.ego[sel].copy()
+        jerk = np.zeros(n)
+        if follow.any():
+            r = path_rec[follow]
+            for col, f in enumerate(("x", "y", "yaw", "v", "a")):
+                new_ego[follow, col] = rec[f][r, 1]
+            jerk[follow] = (new_ego[follow, 4] - old_a[follow]) / self.dt
+        brake = ~follow
+        if brake.any():
+            x, y, yaw, v = (self.ego[sel, k][brake] for k in range(4))
+            cap = getattr(c, "ego_emergency_decel", None)
+            if cap is None:
+                cap = c.ego_max_accel * 2.0
+            clr = self.last_clearance[sel][brake]
+            fin = np.isfinite(clr)
+            required = np.where(fin, v ** 2 / (2.0 * np.maximum(np.where(fin, clr, 1.0) - 0.2, 0.05)), cap)
+            max_dec = np.clip(required, c.ego_max_accel, cap)
+            nv = np.maximum(0.0, v - max_dec * c.dt)
+            na = np.where(nv > 0, -max_dec, 0.0)
+            new_ego[brake, 0] = x + v * np.cos(yaw) * c.dt
+            new_ego[brake, 1] = y + v * np.sin(yaw) * c.dt
+            new_ego[brake, 3], new_ego[brake, 4] = nv, na
+            jerk[brake] = (na - old_a[brake]) / c.dt
+            self.last_kappa[sel[brake]] = 0.0                         # planner.reset_ego_curvature()
+        self.ego[sel], self.jerk[sel] = new_ego, jerk
+        # --- 5. result metrics on the new ego state, goal test (:864-883)
+        after = self._metrics(sel, off, pos, vel)
+        s_now = self.engine.nearest_s_arrays(new_ego[:, 0], new_ego[:, 1], new_ego[:, 2], new_ego[:, 3], new_ego[:, 4],
+                                             self.goal_prev_s[sel])
+        self.goal_prev_s[sel] = s_now
+        chosen = np.maximum(path_rec, 0)
+        kmax = int(keep.max()) if n else 0
+        slot = np.full(len(self.episodes), -1, np.int64)
+        slot[sel] = everyone
+        self._steps.append(dict(
+            time=self.time, slot=slot, off=off, ego=new_ego, jerk=jerk, state=sm.state[sel].copy(), pos=pos, vel=vel,
+            pred=pred, after=after, stats=self.last_stats[sel].copy(), has_path=path_rec >= 0, keep=keep,
+            cost=rec["cost"][chosen], paths={f: rec[f][chosen, :kmax].copy() for f in _abi.PATH_FIELDS},
+            t_pred=t_pred, t_plan=t_plan, sel=sel))
+        k = len(self._steps) - 1
+        collided = after["collision"] != 0
+        at_goal = self.s_end - s_now < 2.0
+        for i, e in enumerate(sel):
+            ep = self.episodes[e]
+            ep.history._steps.append(k)
+            ep.step_count += 1
+            if collided[i]:
+                ep.termination_reason = "collision"
+            elif at_goal[i]:
+                ep.termination_reason = "goal"
+        self.alive[sel[collided | at_goal]] = False
+        self.time += self.dt
+        return n
+
+    def _record(self, k: int, e: int) -> StepRecord:
+        """StepRecord of episode e at lock step k, from the step's arrays."""
+        s = self._steps[k]
+        i = int(s["slot"][e])
+        lo, hi = int(s["off"][i]), int(s["off"][i + 1])
+        ego = EgoVehicleState(*(float(v) for v in s["ego"][i]), jerk=float(s["jerk"][i]), timestamp=s["time"] + self.dt)
+        ego.state = _STATES[int(s["state"][i])]
+        path = None
+        if s["has_path"][i]:
+            kn = int(s["keep"][i])
+            path = FrenetPath(**{f: s["paths"][f][i, :kn].copy() for f in _abi.PATH_FIELDS})
+            path.cost = float(s["cost"][i])
+        a = s["after"][i]
+        m = {"min_distance": float(a["min_distance"]), "collision": bool(a["collision"]), "ttc": float(a["ttc"]),
+             "clearance": float(a["clearance"]), "clearance_ahead": float(a["clearance_ahead"])}
+        if s["stats"][i, 0] >= 0:
+            m["n_collision_rejected"] = int(s["stats"][i, _abi.ST_COLLISION])
+        p = self.peds[e]
+        return StepRecord(s["time"], ego, s["pos"][lo:hi].copy(), s["vel"][lo:hi].copy(), p.goals.copy(),
+                          None if s["pred"] is None else s["pred"][lo:hi], path, m,
+                          {"prediction": s["t_pred"], "planning": s["t_plan"]})
+
+    def run(self, n_steps: Optional[int] = None) -> List[EpisodeHistory]:
         if n_steps is None:
             n_steps = int(self.config.total_time / self.config.dt)
         for _ in range(n_steps):
@@ -414,6 +591,8 @@ class BatchedClosedLoop:
     @staticmethod
     def trajectory_arrays(history: List[StepRecord]) -> Dict[str, np.ndarray]:
         """The arrays of trajectory.npz (integrated_simulator.py:906-982): same keys, dtypes and shapes."""
+        history = list(history)                                       # (a lazy EpisodeHistory builds its records once)
+
         def planned(f):
             return np.array([np.array(getattr(r.planned_path, f)) if r.planned_path is not None else np.array([])
                              for r in history], dtype=object)

@@ -182,6 +182,10 @@ int upload_spline(fot_handle *h)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Calls whose inputs and outputs stay below this size skip the copy operations: the kernels read / write pinned host
+// memory directly (fot_plan_batch, fot_safety_metrics_batch, fot_frenet_state_batch, the host path of the resampler).
+constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
+
 const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_select" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
@@ -564,6 +568,36 @@ int resample_common(fot_handle *h, const fot_resample_params *rp, int cv, int32_
     // small per-pedestrian inputs: anchor | current  (and obs_prev for cv) through the handle's scratch
     const size_t row = sizeof(double) * 2 * (size_t)P;
     { int r = order_begin(h, st); if (r != FOT_OK) return r; }  // the scratch below is shared by every entry point
+    {
+        const size_t in_elem_ = pred_dtype == FOT_F32 ? 4 : 8, out_elem_ = out_dtype == FOT_F32 ? 4 : 8;
+        const size_t in_b = cv ? 0 : in_elem_ * 2 * (size_t)P * (size_t)S * pred_len;
+        const size_t out_b = out_elem_ * 2 * (size_t)S * P * T;
+        if (!on_device && 3 * align256(row) + align256(in_b) <= SMALL_CALL_BYTES &&
+            out_b + sizeof(double) * (size_t)S <= SMALL_CALL_BYTES) {
+            // small host call: everything through pinned memory the kernels access directly
+            HIP_TRY(h, h->hSmallIn.ensure(3 * align256(row) + align256(in_b)));
+            HIP_TRY(h, h->hSmallOut.ensure(align256(out_b) + sizeof(double) * (size_t)S));
+            char *p = (char *)h->hSmallIn.p;
+            const double *pa = nullptr, *pc = nullptr;
+            const void *pp = nullptr;
+            if (anchor) { std::memcpy(p, anchor, row); pa = (const double *)p; }
+            if (current) { std::memcpy(p + align256(row), current, row); pc = (const double *)(p + align256(row)); }
+            if (cv) { if (pred) { std::memcpy(p + 2 * align256(row), pred, row); pp = p + 2 * align256(row); } }
+            else { std::memcpy(p + 3 * align256(row), pred, in_b); pp = p + 3 * align256(row); }
+            char *po = (char *)h->hSmallOut.p;
+            LAUNCH_TRY(h, launch_resample(rp->sgan_dt, rp->sim_dt, staleness, S, pred_len, P, n_dense, anchor ? 1 : 0,
+                                          current ? 1 : 0, cv, pp, cv ? FOT_F64 : pred_dtype, pa, pc, po, out_dtype,
+                                          tmajor, st));
+            if (sample_dist)
+                LAUNCH_TRY(h, launch_sample_dist(S, P, T, current ? 1 : 0, po, out_dtype, tmajor,
+                                                 (double *)(po + align256(out_b)), st));
+            { int r = order_end(h, st); if (r != FOT_OK) return r; }
+            HIP_TRY(h, hipStreamSynchronize(st));
+            std::memcpy(out, po, out_b);
+            if (sample_dist) std::memcpy(sample_dist, po + align256(out_b), sizeof(double) * (size_t)S);
+            return FOT_OK;
+        }
+    }
     HIP_TRY(h, h->dTmpA.ensure(3 * row + 64));
     char *scr = (char *)h->dTmpA.p;
     const double *d_anchor = nullptr, *d_current = nullptr;
@@ -643,6 +677,22 @@ int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const 
     { int r = order_begin(h, st); if (r != FOT_OK) return r; }
     const size_t ego_b = sizeof(double) * 4 * (size_t)n, off_b = align256(sizeof(int32_t) * ((size_t)n + 1));
     const size_t ped_b = sizeof(double) * 2 * std::max<size_t>(n_ped, 1);
+    if (align256(ego_b) + off_b + 2 * align256(ped_b) <= SMALL_CALL_BYTES && sizeof(fot_safety) * (size_t)n <= SMALL_CALL_BYTES) {
+        // small call: the kernel reads its inputs from, and writes its results to, pinned host memory (no copy operations)
+        HIP_TRY(h, h->hSmallIn.ensure(align256(ego_b) + off_b + 2 * align256(ped_b)));
+        HIP_TRY(h, h->hSmallOut.ensure(sizeof(fot_safety) * (size_t)n));
+        char *p = (char *)h->hSmallIn.p;
+        char *p_off = p + align256(ego_b), *p_pos = p_off + off_b, *p_vel = p_pos + align256(ped_b);
+        std::memcpy(p, ego, ego_b);
+        std::memcpy(p_off, ped_off, sizeof(int32_t) * ((size_t)n + 1));
+        if (n_ped) { std::memcpy(p_pos, ped_pos, sizeof(double) * 2 * n_ped); std::memcpy(p_vel, ped_vel, sizeof(double) * 2 * n_ped); }
+        LAUNCH_TRY(h, launch_safety(h->dP.as<DevParams>(), n, (const double *)p, (const int32_t *)p_off, (const double *)p_pos,
+                                    (const double *)p_vel, ego_radius, ped_radius, h->params.footprint_radius,
+                                    use_footprint, (fot_safety *)h->hSmallOut.p, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        std::memcpy(out, h->hSmallOut.p, sizeof(fot_safety) * (size_t)n);
+        return FOT_OK;
+    }
     HIP_TRY(h, h->dTmpA.ensure(align256(ego_b) + off_b));
     HIP_TRY(h, h->dTmpB.ensure(2 * align256(ped_b)));
     HIP_TRY(h, h->dTmpC.ensure(sizeof(fot_safety) * (size_t)n));
@@ -715,8 +765,7 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
     // A plan step for one or a few egos is latency, not bandwidth: its obstacle points (read once, by k_cull) and its
     // records (written once, by k_select) then travel straight between the kernels and pinned host memory -- two copy
     // operations and their synchronisation less per call.
-    constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
-    if (st_bytes + dy_bytes <= SMALL_CALL_BYTES && out_bytes <= SMALL_CALL_BYTES) {
+    if (st_bytes + dy_bytes <= 2 * SMALL_CALL_BYTES && out_bytes <= 8 * SMALL_CALL_BYTES) {   // (records stream out while k_select runs)
         const size_t dy_off = align256(st_bytes);
         HIP_TRY(h, h->hSmallIn.ensure(dy_off + dy_bytes + 256));
         HIP_TRY(h, h->hSmallOut.ensure(out_bytes));
@@ -756,6 +805,22 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
     }
     HIP_TRY(h, hipSetDevice(h->device));
     { int r = order_begin(h, h->stream); if (r != FOT_OK) return r; }
+    if (sizeof(InstDesc) * (size_t)n <= SMALL_CALL_BYTES) {      // small call: straight from / into pinned host memory
+        HIP_TRY(h, h->hSmallIn.ensure(sizeof(InstDesc) * (size_t)n));
+        HIP_TRY(h, h->hSmallOut.ensure(sizeof(InstState) * (size_t)n));
+        std::memcpy(h->hSmallIn.p, desc.data(), sizeof(InstDesc) * (size_t)n);
+        LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), (const InstDesc *)h->hSmallIn.p,
+                                          (InstState *)h->hSmallOut.p, n, MetaImport(), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const InstState *stp = (const InstState *)h->hSmallOut.p;
+        for (int i = 0; i < n; ++i) {
+            if (frenet) std::memcpy(frenet + 6 * (size_t)i, stp[i].frenet0, sizeof(double) * 6);
+            if (ref) std::memcpy(ref + 6 * (size_t)i, stp[i].ref0, sizeof(double) * 6);
+            if (new_prev_s) new_prev_s[i] = stp[i].new_prev_s;
+            if (ok) ok[i] = stp[i].c2f_ok;
+        }
+        return FOT_OK;
+    }
     HIP_TRY(h, h->dTmpA.ensure(sizeof(InstDesc) * (size_t)n));
     HIP_TRY(h, h->dTmpB.ensure(sizeof(InstState) * (size_t)n));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, desc.data(), sizeof(InstDesc) * (size_t)n, hipMemcpyHostToDevice, h->stream));

@@ -28,6 +28,24 @@ def _as_dp(a: np.ndarray):
     return a.ctypes.data_as(_dp)
 
 
+def _addr(a: np.ndarray) -> int:
+    """Address of a C-contiguous array (``ndarray.ctypes`` builds a helper object per access: microseconds that count in
+    the array interfaces below, which make a dozen pointers per call)."""
+    return a.__array_interface__["data"][0]
+
+
+_vp = C.c_void_p
+_FAST = {}
+
+
+def _fast(lib, name, *argtypes):
+    """The same exported function with untyped pointer arguments (addresses as ints)."""
+    f = _FAST.get(name)
+    if f is None:
+        f = _FAST[name] = C.CFUNCTYPE(C.c_int, *argtypes)((name, lib))
+    return f
+
+
 def spline_arrays(path) -> List[np.ndarray]:
     """Knots and CubicSpline1D coefficients of a CubicSpline2D-like object
     (reference attributes: .s, .sx.{a,b,c,d}, .sy.{a,b,c,d}; cubic_spline.py:30-45, 201-204)."""
@@ -175,6 +193,79 @@ class BatchPlanner:
         _abi.check(self._h, self._lib.fot_pack_records_device(self._h, int(n), C.c_void_p(records_dev_ptr),
                                                               C.c_void_p(wire_dev_ptr),
                                                               C.c_void_p(stream) if stream else None))
+
+    # -- array interfaces: whole batches as NumPy arrays, no per-request Python objects (closed_loop.py) -----------
+    RESULT_DT = np.dtype(_abi.Result)
+    EGO_DT = np.dtype(_abi.Ego)
+    SAFETY_DT = np.dtype(_abi.Safety)
+
+    def plan_arrays(self, ego: np.ndarray, target_speed: np.ndarray, overrides: np.ndarray, max_stop: np.ndarray,
+                    static_xy: Optional[np.ndarray], static_off: Optional[np.ndarray], dyn_xy: Optional[np.ndarray],
+                    dyn_off: Optional[np.ndarray], dyn_dims: Optional[np.ndarray]) -> np.ndarray:
+        """n plan() calls given column-wise (``fot_plan_batch`` with host arrays): ``ego`` structured [n] of ``EGO_DT``
+        (has_prev_s 2 = chained on the request before), ``overrides`` [n, 4] float64 (NaN = key absent; max_speed,
+        max_accel, max_curvature, max_lat_accel), ``max_stop`` [n] (NaN = None), obstacles as in ``fot_batch`` (float64).
+        Returns the records as a structured array of ``RESULT_DT``."""
+        n = int(ego.shape[0])
+        out = np.zeros(max(n, 1), dtype=self.RESULT_DT)
+        if n == 0:
+            return out[:0]
+        b = _abi.Batch()
+        b.n_inst = n
+        b.obstacle_dtype = _abi.F64
+        ego = np.ascontiguousarray(ego, dtype=self.EGO_DT)
+        tgt = np.ascontiguousarray(target_speed, dtype=np.float64)
+        ov = np.ascontiguousarray(overrides, dtype=np.float64).reshape(n, 4)
+        ms = np.ascontiguousarray(max_stop, dtype=np.float64)
+        b.ego = C.cast(_addr(ego), C.POINTER(_abi.Ego))
+        b.target_speed = C.cast(_addr(tgt), _dp)
+        b.overrides = C.cast(_addr(ov), C.POINTER(_abi.Overrides))
+        b.max_stop_distance = C.cast(_addr(ms), _dp)
+        keep = [ego, tgt, ov, ms]
+        if static_xy is not None and static_off is not None and len(static_xy):
+            sx = np.ascontiguousarray(static_xy, dtype=np.float64)
+            so = np.ascontiguousarray(static_off, dtype=np.int32)
+            b.static_xy, b.static_off = _addr(sx), C.cast(_addr(so), _ip)
+            keep += [sx, so]
+        if dyn_xy is not None and dyn_off is not None and len(dyn_xy):
+            dx = np.ascontiguousarray(dyn_xy, dtype=np.float64)
+            do = np.ascontiguousarray(dyn_off, dtype=np.int64)
+            dd = np.ascontiguousarray(dyn_dims, dtype=np.int32).reshape(n, 4)
+            b.dyn_xy, b.dyn_off = _addr(dx), C.cast(_addr(do), C.POINTER(C.c_int64))
+            b.dyn_dims = C.cast(_addr(dd), _ip)
+            keep += [dx, do, dd]
+        f = _fast(self._lib, "fot_plan_batch", _vp, _vp, _vp)
+        _abi.check(self._h, f(self._h, C.addressof(b), _addr(out)))
+        return out
+
+    def safety_metrics_cat(self, egos: np.ndarray, ped_off: np.ndarray, ped_pos: np.ndarray, ped_vel: np.ndarray,
+                           ego_radius: float, ped_radius: float, use_footprint: bool = True) -> np.ndarray:
+        """``safety_metrics`` with the pedestrians of all egos concatenated: ego i owns rows [ped_off[i], ped_off[i+1])."""
+        ego = np.ascontiguousarray(egos, dtype=np.float64).reshape(-1, 4)
+        n = ego.shape[0]
+        off = np.ascontiguousarray(ped_off, dtype=np.int32)
+        pos = np.ascontiguousarray(ped_pos, dtype=np.float64)
+        vel = np.ascontiguousarray(ped_vel, dtype=np.float64)
+        out = np.zeros(max(n, 1), dtype=self.SAFETY_DT)
+        f = _fast(self._lib, "fot_safety_metrics_batch", _vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
+                  C.c_int32, _vp)
+        _abi.check(self._h, f(self._h, n, _addr(ego), _addr(off), _addr(pos) if pos.size else None,
+                              _addr(vel) if vel.size else None, float(ego_radius), float(ped_radius),
+                              int(bool(use_footprint)), _addr(out)))
+        return out[:n]
+
+    def nearest_s_arrays(self, x, y, yaw, v, a, prev_s) -> np.ndarray:
+        """new_prev_s of ``fot_frenet_state_batch`` for n egos given column-wise (prev_s NaN = no cached arc length)."""
+        n = len(x)
+        ego = np.zeros(max(n, 1), dtype=self.EGO_DT)
+        ego["x"][:n], ego["y"][:n], ego["yaw"][:n], ego["v"][:n], ego["a"][:n] = x, y, yaw, v, a
+        ps = np.asarray(prev_s, dtype=np.float64)
+        ego["has_prev_s"][:n] = ~np.isnan(ps)
+        ego["prev_s"][:n] = np.where(np.isnan(ps), 0.0, ps)
+        nps = np.zeros(max(n, 1))
+        f = _fast(self._lib, "fot_frenet_state_batch", _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp)
+        _abi.check(self._h, f(self._h, n, _addr(ego), None, None, _addr(nps), None))
+        return nps[:n]
 
     def synchronize(self):
         _abi.check(self._h, self._lib.fot_synchronize(self._h))

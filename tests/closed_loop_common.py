@@ -64,7 +64,61 @@ class OracleEngine:
             fp.cost = float(o.cost)
             return fp
 
-        return SimpleNamespace(records=recs, stats=lambda j: outs[j].stats, path=path)
+        return SimpleNamespace(records=recs, stats=lambda j: outs[j].stats, path=path, outs=outs)
+
+    # -- the array interfaces BatchedClosedLoop drives (planner.BatchPlanner.plan_arrays / safety_metrics_cat /
+    #    nearest_s_arrays), on top of the methods above
+    RESULT_DT = np.dtype(_abi.Result)
+    EGO_DT = np.dtype(_abi.Ego)
+
+    def plan_arrays(self, ego, target_speed, overrides, max_stop, static_xy, static_off, dyn_xy, dyn_off, dyn_dims):
+        from integrated_path_planning_amd.batch import PlanRequest
+        n = len(ego)
+        keys = ("max_speed", "max_accel", "max_curvature", "max_lat_accel")
+        reqs = []
+        for i in range(n):
+            ov = {k: float(overrides[i, j]) for j, k in enumerate(keys) if not np.isnan(overrides[i, j])} or None
+            st = None
+            if static_xy is not None:
+                st = np.asarray(static_xy)[int(static_off[i]):int(static_off[i + 1])]
+            dyn = None
+            if dyn_xy is not None and dyn_dims[i][0] == 1:
+                P, T = int(dyn_dims[i][2]), int(dyn_dims[i][3])
+                dyn = np.asarray(dyn_xy)[int(dyn_off[i]):int(dyn_off[i]) + P * T].reshape(P, T, 2)
+            e = ego[i]
+            reqs.append(PlanRequest(x=float(e["x"]), y=float(e["y"]), yaw=float(e["yaw"]), v=float(e["v"]), a=float(e["a"]),
+                                    target_speed=float(target_speed[i]), last_kappa=float(e["last_kappa"]),
+                                    prev_s=float(e["prev_s"]) if e["has_prev_s"] == 1 else None,
+                                    chain_prev_s=bool(e["has_prev_s"] == 2), overrides=ov,
+                                    max_stop_distance=None if np.isnan(max_stop[i]) else float(max_stop[i]),
+                                    static=st, dyn=dyn))
+        res = self.plan_batch(reqs)
+        out = np.zeros(n, dtype=self.RESULT_DT)
+        for i in range(n):
+            o = res.outs[i]
+            out["status"][i], out["best_index"][i], out["n_cand"][i] = o.status, o.best_index, o.n_cand
+            out["new_prev_s"][i], out["new_last_kappa"][i] = o.new_prev_s, o.new_last_kappa
+            out["cost"][i] = o.cost if o.status == 0 else np.inf
+            if o.stats is not None:
+                out["stats_valid"][i] = 1
+                out["stats"][i] = [o.stats.get(k, 0) for k in _abi.STATUS_NAMES]
+            if o.status == 0:
+                k = len(o.path["x"])
+                out["n_keep"][i] = k
+                for f in _abi.PATH_FIELDS:
+                    out[f][i, :k] = o.path[f]
+        return out
+
+    def safety_metrics_cat(self, egos, ped_off, ped_pos, ped_vel, ego_radius, ped_radius, use_footprint=True):
+        pos = [ped_pos[int(ped_off[i]):int(ped_off[i + 1])] for i in range(len(egos))]
+        vel = [ped_vel[int(ped_off[i]):int(ped_off[i + 1])] for i in range(len(egos))]
+        return self.safety_metrics(egos, pos, vel, ego_radius, ped_radius, use_footprint)
+
+    def nearest_s_arrays(self, x, y, yaw, v, a, prev_s):
+        from integrated_path_planning_amd.batch import PlanRequest
+        return self.frenet_states([PlanRequest(x[i], y[i], yaw[i], v[i], a[i],
+                                               prev_s=None if np.isnan(prev_s[i]) else float(prev_s[i]))
+                                   for i in range(len(x))])[2]
 
     def safety_metrics(self, egos, pos, vel, ego_radius, ped_radius, use_footprint=True):
         out = np.zeros(len(egos), dtype=[("min_distance", "f8"), ("ttc", "f8"), ("clearance", "f8"),
