@@ -414,6 +414,24 @@ FOT_HD void load_lon_sample(const double *tab, int k, LonSample &L)
     L.inv_sd = tab[9 * FOT_MAX_NT + k];
 }
 
+// spline_frame with ONE reciprocal square root instead of a square root and five divisions: with r = (x'^2 + y'^2)^-1/2
+// the tangent is (x', y') r, kappa = a r^3 and kappa' = (b - 3 a c r^2) r^3.  Every tile of k_evaluate rebuilds the rows of
+// its profiles, so the frame costs as much as it is allowed to: the Newton-refined r is good to a few units in the
+// last place, which is what the per-sample transform (fast_rcp / fast_rsqrt too) works with anyway.
+FOT_HD void spline_frame_fast(const SplinePt &p, double &cos_r, double &sin_r, double &kappa, double &dkappa)
+{
+    const double d = p.dx * p.dx + p.dy * p.dy;
+    const double r = fast_rsqrt(d);
+    const double r2 = r * r, r3 = r2 * r;
+    cos_r = p.dx * r;
+    sin_r = p.dy * r;
+    const double a = p.dx * p.ddy - p.dy * p.ddx;
+    const double b = p.dx * p.dddy - p.dy * p.dddx;
+    const double c = p.dx * p.ddx + p.dy * p.ddy;
+    kappa = a * r3;
+    dkappa = (b - 3.0 * a * c * r2) * r3;
+}
+
 // one entry of the longitudinal table: profile state + reference frame at s
 FOT_HD void make_lon_sample(const SplineView &sp, const LonInfo &L, int k, double dt, LonSample &o, double &sddd)
 {
@@ -421,8 +439,8 @@ FOT_HD void make_lon_sample(const SplineView &sp, const LonInfo &L, int k, doubl
     SplinePt p;
     spline_point(sp, o.s, p);
     o.rx = p.x; o.ry = p.y;
-    spline_frame(p, o.cos_r, o.sin_r, o.kr, o.dkr);
-    o.inv_sd = fabs(o.sd) > 1e-3 ? 1.0 / o.sd : 0.0;            // EPS_S_DOT
+    spline_frame_fast(p, o.cos_r, o.sin_r, o.kr, o.dkr);
+    o.inv_sd = fabs(o.sd) > 1e-3 ? fast_rcp(o.sd) : 0.0;        // EPS_S_DOT
 }
 
 // ---------------------------------------------------------------------------

@@ -97,3 +97,27 @@ def test_more_profiles_than_the_cull_box_cache():
             PlanRequest(8.0, -0.2, 0.02, 4.0, 0.3, target_speed=7.5, dyn=dyn)]
     res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
     assert res.records[0].n_cand > 279 * 3
+
+
+def test_lattice_shapes_across_tile_boundaries():
+    """k_evaluate's tiles (<= 64 candidates, <= 3 full-length profiles, LDS row budget) on lattices that stress their
+    construction: a lateral grid wider than a wave (141 offsets: several tiles per profile), a single-offset grid (one
+    candidate per profile: tiles end on the profile limit, not on 64 lanes), many brake-ladder entries, and instances
+    with different terminal-speed grids (different tile tables) in one batch."""
+    rng = np.random.default_rng(9)
+    dyn = np.array([22.0, 0.5]) + rng.normal(0, 5.0, (12, 1, 2)) + np.cumsum(rng.normal(0, 0.1, (12, 41, 2)), axis=1)
+    static = np.column_stack([rng.uniform(5, 50, 25), rng.uniform(-6, 6, 25)])
+    cases = [
+        dict(dt=0.1, min_t=3.8, max_t=4.0, max_road_width=7.0, d_road_w=0.1, robot_radius=0.8, obstacle_radius=0.2),
+        dict(dt=0.1, min_t=3.0, max_t=4.0, max_road_width=0.2, d_road_w=0.5, robot_radius=0.8, obstacle_radius=0.2),
+        dict(dt=0.2, min_t=6.4, max_t=6.6, max_road_width=2.0, d_road_w=0.5, robot_radius=0.8, obstacle_radius=0.2),
+    ]
+    for kw in cases:
+        bp = BatchPlanner(waypoints=(WX, WY), **kw)
+        reqs = [PlanRequest(3.0, 0.2, 0.01, 6.0, 0.2, target_speed=8.0, dyn=dyn, static=static),
+                PlanRequest(9.0, -0.3, -0.02, 3.0, -0.4, target_speed=1.2, dyn=dyn),          # fewer terminal speeds
+                PlanRequest(15.0, 0.0, 0.0, 0.05, 0.0, target_speed=4.1, static=static),      # standing: no brake ladder
+                PlanRequest(5.0, 0.4, 0.03, 9.0, 0.0, target_speed=11.0, dyn=dyn[:, :7])]
+        res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
+        assert len({res.records[i].n_cand for i in range(len(reqs))}) >= 3
+        bp.close()
