@@ -595,12 +595,14 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         sink.any_fatal = D.max_viol == 0;
         sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
         sink.no_warm = (a.ablate & 2) != 0;
-        // loop constants as opaque register values: the compiler then keeps (or lane-spills) them instead of
-        // re-fetching each one from the parameter blocks, behind a scalar-memory wait, in every time step
+        // loop constants as opaque register values: the compiler then keeps them instead of re-fetching each one from
+        // the parameter blocks, behind a scalar-memory wait, in every time step
         LoopConst lc = loop_const(P, D);
-        lc.dt = uniform_f64(lc.dt); lc.lim_speed = uniform_f64(lc.lim_speed); lc.lim_accel = uniform_f64(lc.lim_accel);
-        lc.lim_curv = uniform_f64(lc.lim_curv); lc.lim_lat = uniform_f64(lc.lim_lat);
-        lc.road_lim = uniform_f64(lc.road_lim);                 // (wherever the compiler had put them)
+        // The limits live in VECTOR registers although they are wave-uniform: as scalars they do not fit next to the two
+        // chunk buffers, get lane-spilled and come back through ~27 v_readlane per time step -- vector issue slots of a
+        // kernel that is bound by exactly those (r02: 0.257 -> 0.242 ms).  12 VGPRs; the kernel still fits 168.
+        asm volatile("" : "+v"(lc.dt), "+v"(lc.lim_speed), "+v"(lc.lim_accel), "+v"(lc.lim_curv), "+v"(lc.lim_lat),
+                          "+v"(lc.road_lim));
         lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
         asm volatile("" : "+s"(lc.n_circ_fp));
         CandResult r;

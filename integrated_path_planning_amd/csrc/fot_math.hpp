@@ -608,6 +608,9 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
     CheckAcc acc;
     check_init(acc);
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FOT_EVAL_UNROLL)
+#pragma unroll FOT_EVAL_UNROLL
+#endif
     for (int k = 0; k < n_loop; ++k) {
       // table row first (every lane: rows past n_t exist and are ignored), then the sink's per-step prologue:
       // k_evaluate issues its scalar warm-up loads there, after the row has arrived
