@@ -207,6 +207,12 @@ int fot_debug_candidate_path(fot_handle *h, int32_t inst, int32_t index, double 
 #define FOT_MARGIN_GROUPS 8
 int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins);
 
+/* Test hook.  A plan call of a few egos cuts every candidate's time range into up to 4 segments evaluated by
+ * different waves and merged (the decisions are the same: every per-candidate accumulator of _check_paths /
+ * _path_is_collision_free merges associatively); large batches walk it in one piece.  n_seg = 1..4 forces the number
+ * of segments for the handle's later plan calls, 0 restores the choice by batch size. */
+int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
+
 /* FrenetPlanner._path_is_collision_free (frenet_planner.py:1035-1233) for n_paths externally
  * supplied paths against ONE obstacle set.  x, y, yaw, t: [n_paths][FOT_MAX_NT] host, len[n_paths];
  * static_xy [n_static][2] double host; dyn [S][P][T][2] double host with mode as in dyn_dims.

@@ -96,6 +96,7 @@ struct fot_handle {
     hipEvent_t order_done = nullptr;
     hipStream_t order_stream = nullptr;
     bool order_valid = false;
+    int eval_segments = 0;               // fot_debug_set_eval_segments
     fot_params params;
     DevParams P;
     DevBuf dP;
@@ -271,6 +272,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     tt.cand0 = h->dShapes.as<int32_t>();
     tt.n = h->dShapes.as<int32_t>() + h->shapes.cand0.size();
     tt.n_tiles = L.n_tiles; tt.max_tiles = L.max_tiles; tt.row_budget = L.row_budget;
+    tt.eval_segments = h->eval_segments;
     const DevParams *dP = h->dP.as<DevParams>();
     const SplineView sv = spline_view(h);
     CandArrays ca;
@@ -966,6 +968,14 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
         for (int f = 0; f < 15; ++f)
             for (int k = 0; k < keep; ++k) arr[f * FOT_MAX_NT + k] = (double)path[f * n_total + k];
     }
+    return FOT_OK;
+}
+
+int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n_seg < 0 || n_seg > 4) return fail(h, FOT_ERR_INVALID, "fot_debug_set_eval_segments: 0 (automatic) .. 4");
+    h->eval_segments = n_seg;
     return FOT_OK;
 }
 

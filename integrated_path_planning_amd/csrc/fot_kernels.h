@@ -32,6 +32,7 @@ struct MetaImport {
 struct TileTable {
     const int32_t *cand0 = nullptr, *n = nullptr;
     int n_tiles = 0, max_tiles = 0, row_budget = 0;
+    int eval_segments = 0;              // time segments per tile in k_evaluate: 0 = by batch size, 1..4 forced (tests)
 };
 
 // every launcher returns 0 or the hipError_t of the launch

@@ -443,6 +443,10 @@ __host__ __device__ constexpr int eval_wave_doubles(int row_budget)
 {
     return row_budget * ROW_FIELDS + TILE_MAX_PROFILES * LONINFO_DOUBLES + TILE_MAX_PROFILES / 2;
 }
+// A tile cut into time segments (k_evaluate_split): what a later segment hands to the wave of segment 0, per lane
+constexpr int SEG_MAX = 4;
+constexpr int SEG_F64 = 5, SEG_I32 = 4;  // Jp, d_last, v_last, max_step2, hit_mask | flags, first_nan, k_last, hit
+constexpr int SEG_DOUBLES = (SEG_F64 + SEG_I32 / 2) * WAVE;
 
 struct StagedTab {
     int lds_row0;                        // index of this lane's profile row 0 in s_lon
@@ -506,13 +510,18 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
-// One tile: rows of its profiles into the wave's LDS slice, then one candidate per lane.
+// One tile: rows of its profiles into LDS, then one candidate per lane.  SPLIT == false: the wave owns the tile and
+// its slice of LDS (my_rows).  SPLIT == true: the workgroup's n_seg waves share the tile -- they build the rows
+// together, wave `seg` walks the time steps [seg, seg + 1) * ceil(n_loop / n_seg) of every candidate, and wave 0 merges
+// the segments (seg_merge) through `s_part`.
+template <bool SPLIT>
 __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
                                               const InstState *__restrict__ state,
                                               const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
                                               const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32,
                                               const EvalKernArgs &a, const SplineView &sp_lds,
-                                              double *my_rows, int inst, int tile, int lane, int tl_tag)
+                                              double *my_rows, int inst, int tile, int lane, int tl_tag,
+                                              int seg = 0, int n_seg = 1, double *s_part = nullptr)
 {
     const DevParams &P = *Pp;
     const InstDesc &D = desc[inst];
@@ -530,18 +539,19 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     // profiles of the tile's first .. last candidate (slots grow with the candidate index)
     const int slot_lo = decode_candidate(P, D, S.frenet0, cand0).lon_slot;
     const int n_stage = decode_candidate(P, D, S.frenet0, cand0 + n - 1).lon_slot - slot_lo + 1;
-    wave_lds_fence();                                           // the previous tile's rows are no longer read
+    const auto lds_fence = [] { if constexpr (SPLIT) __syncthreads(); else wave_lds_fence(); };
+    if constexpr (!SPLIT) wave_lds_fence();                     // the previous tile's rows are no longer read
     int total_rows = 0, n_loop = 0;
     for (int p = 0; p < n_stage; ++p) {                         // wave-uniform: a handful of scalar operations
         const int r = profile_rows(P, D, slot_lo + p);
-        if (lane == p) s_row0[p] = total_rows;
+        if (lane == p && seg == 0) s_row0[p] = total_rows;
         total_rows += r;
     }
-    if (lane < n_stage) s_info[lane] = profile_info(P, D, S.frenet0, slot_lo + lane, true);
-    wave_lds_fence();
+    if (lane < n_stage && seg == 0) s_info[lane] = profile_info(P, D, S.frenet0, slot_lo + lane, true);
+    lds_fence();
     for (int p = 0; p < n_stage; ++p) { const int nt = s_info[p].n_t; n_loop = nt > n_loop ? nt : n_loop; }
     n_loop = __builtin_amdgcn_readfirstlane(n_loop);
-    for (int i = lane; i < total_rows; i += WAVE) {
+    for (int i = seg * WAVE + lane; i < total_rows; i += n_seg * WAVE) {
         int p = 0;
         for (int pp = 1; pp < n_stage; ++pp) p = i >= s_row0[pp] ? pp : p;
         const int k = i - s_row0[p];
@@ -553,7 +563,11 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx; r[3] = ls.ry;
         r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
     }
-    wave_lds_fence();
+    lds_fence();
+    // this wave's time steps
+    const int seg_len = (n_loop + n_seg - 1) / n_seg;
+    const int k0 = SPLIT ? seg * seg_len : 0;
+    const int k1 = SPLIT ? (k0 + seg_len < n_loop ? k0 + seg_len : n_loop) : n_loop;
 
     // lane k holds the strip range of time step k (read back with v_readlane): loaded while every lane of the
     // wave is still active, lanes without a candidate included
@@ -567,13 +581,20 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     int tl_chunks = (int)(my_rng & 0xffffu) - (int)(my_rng >> 16);
     for (int o = 32; o > 0; o >>= 1) tl_chunks += __shfl_xor(tl_chunks, o);
 #endif
+    // per-lane state that outlives the segment loop in the split form
+    SegState g;
+    seg_init(g);
+    LonInfo L;
+    StagedTab tab;
+    uint64_t hit_mask = 0;
+    bool hit = false;
+    int64_t slot = 0;
     if (lane < n) {
         const int idx = cand0 + lane;                            // candidate index inside the instance
-        const int64_t slot = (int64_t)D.cand_off + idx;
+        slot = (int64_t)D.cand_off + idx;
         const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
         const int p = cd.lon_slot - slot_lo;
-        const LonInfo L = s_info[p];
-        StagedTab tab;
+        L = s_info[p];
         tab.lds_row0 = (int)(my_rows - s_lon) + s_row0[p] * ROW_FIELDS;
         tab.k_max = profile_rows(P, D, cd.lon_slot) - 1;
         tab.info = s_info + p;
@@ -605,17 +626,51 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
                           "+v"(lc.road_lim));
         lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
         asm volatile("" : "+s"(lc.n_circ_fp));
+        evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);
+        hit_mask = sink.hit_mask; hit = sink.hit;
+#ifdef FOT_TIMELINE
+        tl_rows = tab.t_rows;
+#endif
+    }
+    if constexpr (SPLIT) {
+        // segments 1.. leave their state in LDS, the wave of segment 0 folds them in, in time order
+        double *pf = s_part + (seg - 1) * SEG_DOUBLES;
+        int *pi = (int *)(pf + SEG_F64 * WAVE);
+        if (seg > 0 && lane < n) {
+            pf[0 * WAVE + lane] = g.Jp; pf[1 * WAVE + lane] = g.d_last; pf[2 * WAVE + lane] = g.v_last;
+            pf[3 * WAVE + lane] = g.acc.max_step2; ((uint64_t *)pf)[4 * WAVE + lane] = hit_mask;
+            pi[0 * WAVE + lane] = (int)g.acc.fl; pi[1 * WAVE + lane] = g.first_nan;
+            pi[2 * WAVE + lane] = g.k_last; pi[3 * WAVE + lane] = hit ? 1 : 0;
+        }
+        __syncthreads();
+        if (seg != 0) return;
+        if (lane < n) {
+            for (int sg = 1; sg < n_seg; ++sg) {
+                if (sg * seg_len >= L.n_t) break;                // that segment held no sample of this candidate
+                const double *qf = s_part + (sg - 1) * SEG_DOUBLES;
+                const int *qi = (const int *)(qf + SEG_F64 * WAVE);
+                SegState nx;
+                nx.Jp = qf[0 * WAVE + lane]; nx.d_last = qf[1 * WAVE + lane]; nx.v_last = qf[2 * WAVE + lane];
+                nx.acc.max_step2 = qf[3 * WAVE + lane];
+                nx.acc.fl = (uint32_t)qi[0 * WAVE + lane]; nx.first_nan = qi[1 * WAVE + lane];
+                nx.k_last = qi[2 * WAVE + lane];
+                if (seg_merge(g, nx)) {
+                    hit_mask |= ((const uint64_t *)qf)[4 * WAVE + lane];
+                    hit |= qi[3 * WAVE + lane] != 0;
+                }
+            }
+            hit |= __popcll(hit_mask) > D.max_viol;
+        }
+    }
+    if (lane < n) {
         CandResult r;
-        evaluate_candidate(P, D, lc, L, tab, q, n_loop, sink, r);
+        finish_candidate(P, D, L, tab, g, hit, r);
         const EvalKernArgs &KA = eval_kernargs();
         KA.cand_cost[slot] = r.cost;
         KA.cand_vlast[slot] = r.v_last;
         KA.cand_travel[slot] = r.travel;
         KA.cand_status[slot] = (uint8_t)r.status;
         KA.cand_keep[slot] = (uint8_t)r.keep;
-#ifdef FOT_TIMELINE
-        tl_rows = tab.t_rows;
-#endif
     }
 #ifdef FOT_TIMELINE
     tl_rows = (uint64_t)__shfl((unsigned long long)tl_rows, 0);
@@ -654,8 +709,35 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int inst = x + N_XCD * j;
     const int n_tiles = desc[inst].n_tiles;
     if (pos >= n_tiles) return;                                  // a shorter lattice than the batch's longest
-    evaluate_tile(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst, n_tiles - 1 - pos,
-                  lane, x);
+    evaluate_tile<false>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst,
+                         n_tiles - 1 - pos, lane, x);
+}
+
+// The same for a handful of egos (fewer tiles than the GPU has SIMDs): a tile alone on its SIMD is a chain of
+// ~50 dependent time steps of ~1.1 us, so the workgroup's waves (blockDim.x / 64 <= SEG_MAX) take a time segment
+// each of ONE tile and its first wave merges them.  One workgroup per tile, same tile order.
+__global__ void __launch_bounds__(SEG_MAX * WAVE)
+k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
+                 const InstState *__restrict__ state, const int32_t *__restrict__ tile_cand0,
+                 const int32_t *__restrict__ tile_n, const uint32_t *__restrict__ wave_rng,
+                 const f2 *__restrict__ ent32, const EvalKernArgs a)
+{
+    const int n_seg = (int)blockDim.x / WAVE;
+    const int wave_doubles = eval_wave_doubles(a.row_budget);
+    // LDS: [rows | summaries | row offsets] of the tile, the segments' hand-over, then the spline
+    double *s_part = s_lon + wave_doubles;
+    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_part + (SEG_MAX - 1) * SEG_DOUBLES);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int x = (int)blockIdx.x & (N_XCD - 1), q = (int)blockIdx.x >> 3;
+    const int m_x = (a.n_inst - x + N_XCD - 1) / N_XCD;
+    if (m_x <= 0 || q >= m_x * a.max_tiles) return;
+    const int pos = q / m_x, j = q - pos * m_x;
+    const int inst = x + N_XCD * j;
+    const int n_tiles = desc[inst].n_tiles;
+    if (pos >= n_tiles) return;
+    evaluate_tile<true>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst,
+                        n_tiles - 1 - pos, lane, x, seg, n_seg, s_part);
 }
 
 // ---------------------------------------------------------------------------
@@ -1333,11 +1415,15 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
     // four waves per workgroup for batches, one for a handful of egos (a single lattice then spreads over as many CUs
     // as it has tiles); 8 queues of ceil(n_inst / 8) * max_tiles tiles, `wpw` of them per workgroup
-    const int wpw = tiles.n_tiles >= 1024 ? EVAL_WG / WAVE : 1;
+    // Fewer tiles than a quarter of the GPU's SIMDs: every tile is cut into time segments (k_evaluate_split).
+    int n_seg = tiles.n_tiles <= 256 ? SEG_MAX : tiles.n_tiles <= 512 ? 2 : 1;
+    if (tiles.eval_segments >= 1 && tiles.eval_segments <= SEG_MAX) n_seg = tiles.eval_segments;
+    const int wpw = n_seg > 1 ? 1 : tiles.n_tiles >= 1024 ? EVAL_WG / WAVE : 1;
     const int64_t per_queue = (int64_t)((n_inst + N_XCD - 1) / N_XCD) * tiles.max_tiles;
     const int64_t n_blocks = (per_queue + wpw - 1) / wpw * N_XCD;
     if (n_blocks > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
-    const size_t lds = sizeof(double) * ((size_t)eval_wave_doubles(tiles.row_budget) * wpw + 9 * (size_t)lds_knots);
+    const size_t lds = sizeof(double) * ((size_t)eval_wave_doubles(tiles.row_budget) * wpw + 9 * (size_t)lds_knots
+                                         + (n_seg > 1 ? (size_t)(SEG_MAX - 1) * SEG_DOUBLES : 0));
     EvalKernArgs a;
     a.Pp = P; a.sp = sp; a.desc = desc; a.state = state;
     a.row_budget = tiles.row_budget; a.lds_knots = lds_knots; a.ablate = ablate;
@@ -1345,7 +1431,11 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_vlast = c.v_last; a.cand_travel = c.travel; a.cand_status = c.status; a.cand_keep = c.keep;
-    k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
+    if (n_seg > 1)
+        k_evaluate_split<<<(unsigned)n_blocks, n_seg * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng,
+                                                                        e.e32, a);
+    else
+        k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     FOT_LAUNCH_CHECK();
     return 0;
 }

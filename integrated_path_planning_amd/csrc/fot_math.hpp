@@ -596,22 +596,44 @@ struct ComputeTab {
     }
 };
 
+// What a candidate carries from one time step to the next, apart from the sink's collision state.  A candidate's
+// time range may be cut into consecutive segments evaluated independently (k_evaluate does that for a handful of
+// egos, where a tile alone on its SIMD is a chain of dependent steps): every field merges associatively
+// (seg_merge), and a segment that starts at k0 > 0 first rebuilds sample k0 - 1 as its predecessor.
+struct SegState {
+    CheckAcc acc;
+    double Jp, d_last, v_last;
+    int first_nan, k_last;
+};
+
+FOT_HD void seg_init(SegState &g)
+{
+    check_init(g.acc);
+    g.Jp = 0.0; g.d_last = 0.0; g.v_last = 0.0;
+    g.first_nan = -1; g.k_last = -1;
+}
+
+// time steps [k0, k1) of one candidate
 template <class Tab, class Sink>
-FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LoopConst &C, const LonInfo &L,
-                               const Tab &lon_tab, const double *q, int n_loop, Sink &sink, CandResult &out)
+FOT_HD void evaluate_segment(const DevParams &P, const LoopConst &C, const LonInfo &L, const Tab &lon_tab,
+                             const double *q, int k0, int k1, Sink &sink, SegState &g)
 {
     const int n_t = L.n_t;
-    double Jp = 0.0, d_last = 0.0;
-    int first_nan = -1;
-    double v_last = 0.0;
-    int k_last = -1;                                     // last sample of the kept prefix seen so far
-    CheckAcc acc;
-    check_init(acc);
-
+    CheckAcc &acc = g.acc;
+    if (k0 > 0 && k0 - 1 < n_t) {                        // predecessor of the segment's first sample
+        LonSample ls;
+        lon_tab.load(k0 - 1, ls);
+        double d, d_d, d_dd, d_ddd;
+        lat_sample(q, k0 - 1, L.n_eval, C.dt, d, d_d, d_dd, d_ddd);
+        CartSample c;
+        frenet_to_cart(ls, d, d_d, d_dd, c);
+        acc.prev.x = c.x; acc.prev.y = c.y; acc.prev.cos_t = c.cos_t; acc.prev.sin_t = c.sin_t;
+        acc.prev.kappa = c.kappa; acc.prev.v = c.v; acc.prev.a = c.a; acc.prev.d = d;
+    }
 #if defined(__HIP_DEVICE_COMPILE__) && defined(FOT_EVAL_UNROLL)
 #pragma unroll FOT_EVAL_UNROLL
 #endif
-    for (int k = 0; k < n_loop; ++k) {
+    for (int k = k0; k < k1; ++k) {
       // table row first (every lane: rows past n_t exist and are ignored), then the sink's per-step prologue:
       // k_evaluate issues its scalar warm-up loads there, after the row has arrived
       LonSample ls;
@@ -620,12 +642,12 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
       if (k < n_t) {
         double d, d_d, d_dd, d_ddd;
         lat_sample(q, k, L.n_eval, C.dt, d, d_d, d_dd, d_ddd);
-        Jp += d_ddd * d_ddd;
-        d_last = d;
+        g.Jp += d_ddd * d_ddd;
+        g.d_last = d;
         CartSample c;
         frenet_to_cart(ls, d, d_d, d_dd, c);
         check_flag(acc, isfinite(c.omkd) && c.omkd <= 0.05, CK_SINGULAR);   // SINGULARITY_EPS, any sample
-        if (!(acc.fl & CK_SEEN_NAN) && isnan(c.x)) { acc.fl |= CK_SEEN_NAN; first_nan = k; }
+        if (!(acc.fl & CK_SEEN_NAN) && isnan(c.x)) { acc.fl |= CK_SEEN_NAN; g.first_nan = k; }
         if (!(acc.fl & CK_SEEN_NAN)) {
             PathSample ps;
             ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
@@ -638,29 +660,60 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
             } else {
                 sink.put(k, 0, c.x, c.y, alive);
             }
-            v_last = c.v; k_last = k;
+            g.v_last = c.v; g.k_last = k;
         }
       }
       sink.row_end(k);
     }
+}
 
+// g (segments up to some k) followed by n (the segment that starts there and holds a sample below n_t).  Returns
+// false when g already ended the kept prefix (a NaN sample): n's checks and collision points then do not count.
+FOT_HD bool seg_merge(SegState &g, const SegState &n)
+{
+    g.Jp += n.Jp;
+    g.d_last = n.d_last;
+    g.acc.fl |= n.acc.fl & CK_SINGULAR;
+    if (g.acc.fl & CK_SEEN_NAN) return false;
+    g.acc.fl |= n.acc.fl;
+    if (n.acc.max_step2 > g.acc.max_step2) g.acc.max_step2 = n.acc.max_step2;
+    if (n.acc.fl & CK_SEEN_NAN) g.first_nan = n.first_nan;
+    if (n.k_last >= 0) { g.k_last = n.k_last; g.v_last = n.v_last; }
+    return true;
+}
+
+template <class Tab>
+FOT_HD void finish_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
+                             const SegState &g, bool collided, CandResult &out)
+{
+    const int n_t = L.n_t;
     int keep = n_t;
-    if (acc.fl & CK_SEEN_NAN) keep = first_nan >= 2 ? first_nan : 0;
-    if (acc.fl & CK_SINGULAR) keep = 0;
+    if (g.acc.fl & CK_SEEN_NAN) keep = g.first_nan >= 2 ? g.first_nan : 0;
+    if (g.acc.fl & CK_SINGULAR) keep = 0;
 
-    const double Jd = d_last * d_last;
+    const double Jd = g.d_last * g.d_last;
     const double dv = D.target_speed - L.sd_last;
     const double Jt = (double)(n_t - 1) * P.dt;
-    const double lat = P.k_j * Jp + P.k_t * Jt + P.k_d * Jd;
+    const double lat = P.k_j * g.Jp + P.k_t * Jt + P.k_d * Jd;
     const double lon = P.k_j * L.Js + P.k_t * Jt + P.k_s_dot * (dv * dv);
     out.cost = P.k_lat * lat + P.k_lon * lon;
 
-    int st = check_status(D, acc, keep);
-    if (st == ST_PENDING && sink.collided()) st = FOT_ST_COLLISION;       // only candidates that pass everything else       // only candidates that pass everything else
+    int st = check_status(D, g.acc, keep);
+    if (st == ST_PENDING && collided) st = FOT_ST_COLLISION;              // only candidates that pass everything else
     out.status = st;
     out.keep = keep;
-    out.v_last = v_last;
-    out.travel = k_last >= 0 ? lon_tab.s_at(k_last) - lon_tab.s_at(0) : 0.0;     // NaN is sticky: sample 0 was valid
+    out.v_last = g.v_last;
+    out.travel = g.k_last >= 0 ? lon_tab.s_at(g.k_last) - lon_tab.s_at(0) : 0.0;   // NaN is sticky: sample 0 was valid
+}
+
+template <class Tab, class Sink>
+FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const LoopConst &C, const LonInfo &L,
+                               const Tab &lon_tab, const double *q, int n_loop, Sink &sink, CandResult &out)
+{
+    SegState g;
+    seg_init(g);
+    evaluate_segment(P, C, L, lon_tab, q, 0, n_loop, sink, g);
+    finish_candidate(P, D, L, lon_tab, g, sink.collided(), out);
 }
 
 // ---------------------------------------------------------------------------

@@ -306,6 +306,11 @@ class BatchPlanner:
             _abi.check(self._h, n)
         return out[: min(n, cap)]
 
+    def set_eval_segments(self, n_seg: int) -> None:
+        """Test hook (``fot_debug_set_eval_segments``): time segments per candidate in the evaluation kernel,
+        1..4 forced, 0 = chosen by batch size."""
+        _abi.check(self._h, self._lib.fot_debug_set_eval_segments(self._h, int(n_seg)))
+
     def candidate_path(self, index: int, inst: int = 0) -> FrenetPath:
         """Candidate ``index`` of the last plan call as generated + converted, before truncation."""
         arr = np.zeros((15, _abi.MAX_NT))

@@ -236,6 +236,37 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 }
                 if (want != r.status || rk.keep != r.keep) return -100;
             }
+            for (int n_seg = 2; n_seg <= 4; ++n_seg) {   // k_evaluate_split: time segments merged == the single walk
+                const int n_loop = P.n_total, seg_len = (n_loop + n_seg - 1) / n_seg;
+                const LoopConst lc = loop_const(P, D);
+                SegState g;
+                uint64_t hit_mask = 0;
+                bool hit = false;
+                for (int sg = 0; sg < n_seg; ++sg) {
+                    if (sg > 0 && sg * seg_len >= Li.n_t) break;
+                    EntryCollider es;
+                    es.init(P, D);
+                    es.rng = ec.rng; es.e32 = ec.e32; es.e64 = ec.e64; es.sid = ec.sid;
+                    SegState part;
+                    seg_init(part);
+                    evaluate_segment(P, lc, Li, GlobalTab{ tab }, q, sg * seg_len, std::min(n_loop, (sg + 1) * seg_len),
+                                     es, part);
+                    bool counts = true;
+                    if (sg == 0) g = part; else counts = seg_merge(g, part);
+                    if (counts) { hit_mask |= es.hit_mask; hit |= es.hit; }
+                }
+                int pc = 0;
+                for (uint64_t m = hit_mask; m; m &= m - 1) ++pc;
+                hit |= pc > D.max_viol;
+                CandResult rs;
+                finish_candidate(P, D, Li, GlobalTab{ tab }, g, hit, rs);
+                if (rs.status != r.status || rs.keep != r.keep) return -110;
+                if (std::memcmp(&rs.v_last, &r.v_last, sizeof(double)) || std::memcmp(&rs.travel, &r.travel, sizeof(double)))
+                    return -111;
+                if (!(std::fabs(rs.cost - r.cost) <= 1e-12 * std::fabs(r.cost)) && !(std::isnan(rs.cost) && std::isnan(r.cost))
+                    && rs.cost != r.cost)
+                    return -112;
+            }
             int st = r.status;
             st = final_status(st, r.v_last, r.travel, D.max_stop);
             if (st < 8) cnt_st[st]++;

@@ -108,6 +108,7 @@ def random_request(rng, sp, kw, dense=False):
 N_SEEDS = int(os.environ.get("FOT_FUZZ_SEEDS", "40"))
 SEED_BASE = int(os.environ.get("FOT_FUZZ_BASE", "0"))
 N_DENSE = int(os.environ.get("FOT_FUZZ_DENSE_SEEDS", "8"))
+FORCE_SEGMENTS = int(os.environ.get("FOT_FUZZ_SEGMENTS", "0"))      # 1..4: every case with that many time segments
 
 
 @pytest.mark.parametrize("seed", range(SEED_BASE, SEED_BASE + N_SEEDS))
@@ -132,6 +133,8 @@ def run_seed(seed, n_inst, dense):
         okw["footprint_offsets"], okw["footprint_radius"] = list(fp.offsets), fp.radius
     params, sp = orc.make_params(**okw), orc.Spline(wx, wy)
     bp = BatchPlanner(waypoints=(wx, wy), **kw)
+    if FORCE_SEGMENTS:
+        bp.set_eval_segments(FORCE_SEGMENTS)
     reqs = [random_request(rng, sp, kw, dense) for _ in range(n_inst)]
     res = bp.plan_batch(reqs)
     for i, rq in enumerate(reqs):
@@ -144,3 +147,45 @@ def run_seed(seed, n_inst, dense):
         eps_band.check_status_table(bp, i, status, want.cand_status, label)
         np.testing.assert_allclose(cost, want.cand_cost, rtol=TIGHT, atol=TIGHT, err_msg=label)
         assert_record_matches_oracle(res.records[i], want, label=label)
+
+
+
+@pytest.mark.parametrize("seed,dense", [(s, False) for s in range(900, 912)] + [(500900 + s, True) for s in range(4)])
+def test_time_segments_agree(seed, dense):
+    """The evaluation kernel walks a candidate's time range in one piece (batches) or in 2..4 segments merged
+    afterwards (a handful of egos): every per-candidate table and the record must not depend on the cut."""
+    rng = np.random.default_rng(1000 + seed)
+    wx, wy = random_path(rng)
+    kw = random_planner_kwargs(rng)
+    if dense:
+        kw.update(max_curvature=10.0, max_accel=max(kw["max_accel"], 5.0))
+    okw = dict(kw)
+    fp = okw.pop("footprint", None)
+    if fp is not None:
+        okw["footprint_offsets"], okw["footprint_radius"] = list(fp.offsets), fp.radius
+    sp = orc.Spline(wx, wy)
+    bp = BatchPlanner(waypoints=(wx, wy), **kw)
+    reqs = [random_request(rng, sp, kw, dense) for _ in range(3)]
+    tables, records = [], []
+    for n_seg in (1, 2, 3, 4):
+        bp.set_eval_segments(n_seg)
+        res = bp.plan_batch(reqs)
+        tables.append([bp.candidates(i) for i in range(len(reqs))])
+        records.append(res.records)
+    bp.set_eval_segments(0)
+    for n_seg, tab, rec in zip((2, 3, 4), tables[1:], records[1:]):
+        for i in range(len(reqs)):
+            label = f"seed {seed} inst {i} segments {n_seg}"
+            c1, s1, k1, n1 = tables[0][i]
+            c, s, k, n = tab[i]
+            np.testing.assert_array_equal(s, s1, err_msg=label)
+            np.testing.assert_array_equal(k, k1, err_msg=label)
+            np.testing.assert_array_equal(n, n1, err_msg=label)
+            np.testing.assert_allclose(c, c1, rtol=1e-12, atol=0, err_msg=label)
+            a, b = rec[i], records[0][i]
+            assert (a.status, a.best_index, a.n_keep) == (b.status, b.best_index, b.n_keep), label
+            assert list(a.stats) == list(b.stats), label
+            if a.status == 0:
+                for f in ("x", "y", "yaw", "v", "a", "c", "s", "d"):
+                    np.testing.assert_array_equal(np.ctypeslib.as_array(getattr(a, f))[: a.n_keep],
+                                                  np.ctypeslib.as_array(getattr(b, f))[: b.n_keep], err_msg=label)
