@@ -262,7 +262,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
     HIP_TRY(h, w.dEnt64.ensure(sizeof(d2) * n_ent));
     HIP_TRY(h, w.dEntSid.ensure(n_ent));
-    HIP_TRY(h, w.dWaveRng.ensure(sizeof(uint32_t) * (size_t)P.n_total * (size_t)std::max(L.n_tiles, 1)));
+    HIP_TRY(h, w.dWaveRng.ensure(sizeof(TileStep) * (size_t)P.n_total * (size_t)std::max(L.n_tiles, 1)));
 
     // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
     w.staging_pending = true;
@@ -281,7 +281,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
 
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
-    ea.sid = w.dEntSid.as<uint8_t>(); ea.rng = w.dWaveRng.as<uint32_t>();
+    ea.sid = w.dEntSid.as<uint8_t>(); ea.rng = w.dWaveRng.as<TileStep>();
     {
         ProfScope ps(h, 0, st);
         MetaImport imp;
@@ -997,7 +997,7 @@ int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)
     HIP_TRY(h, h->dTmpB.ensure(bytes));
     EntryArrays ea;
     ea.cnt = w->dEntCnt.as<int32_t>(); ea.e32 = w->dEnt32.as<f2>(); ea.e64 = w->dEnt64.as<d2>();
-    ea.sid = w->dEntSid.as<uint8_t>(); ea.rng = w->dWaveRng.as<uint32_t>();
+    ea.sid = w->dEntSid.as<uint8_t>(); ea.rng = w->dWaveRng.as<TileStep>();
     LAUNCH_TRY(h, launch_debug_margins(h->dP.as<DevParams>(), (const InstDesc *)w->dMeta.p, w->dState.as<InstState>(),
                                        spline_view(h), local, ea, m, h->dTmpB.as<double>(), h->stream));
     HIP_TRY(h, hipMemcpyAsync(margins, h->dTmpB.p, bytes, hipMemcpyDeviceToHost, h->stream));

@@ -12,13 +12,22 @@ struct CandArrays {
     uint8_t *status, *keep;
 };
 
+// What k_cull leaves per (tile, time step) for k_evaluate: the chunk range the tile's own profiles can reach
+// (c_lo << 16 | c_hi) and the float32 filter thresholds valid for every collision point of the tile at that step
+// (filter_threshold / filter_threshold_sure at the bound of |x| + |y| over the tile's box, fot_math.hpp box_thresholds).
+struct TileStep {
+    uint32_t rng;
+    float thr, thr_sure;
+    uint32_t pad;
+};
+
 // broad-phase entry lists in HBM: per instance n_total * ent_cap slots
 struct EntryArrays {
     int32_t *cnt;      // [n_inst][n_total] entries of each time step (multiple of 8)
     f2 *e32;           // instance-local float32 coordinates
     d2 *e64;           // exact coordinates
     uint8_t *sid;      // prediction sample of the entry, SID_STATIC for static obstacles
-    uint32_t *rng;     // [n_tiles][n_total] chunk range of each tile: c_lo << 16 | c_hi
+    TileStep *rng;     // [n_tiles][n_total] what a tile needs of time step k: chunk range + float32 thresholds
 };
 
 // descriptors still in pinned host memory, to be moved into HBM by k_frenet_state (h_desc == nullptr: already there)

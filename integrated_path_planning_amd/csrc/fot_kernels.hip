@@ -313,7 +313,7 @@ struct EvalKernArgs {
     const DevParams *Pp; SplineView sp; const InstDesc *desc; const InstState *state;
     int row_budget, lds_knots, ablate, n_inst, max_tiles;
     const int32_t *tile_cand0, *tile_n;
-    const uint32_t *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
+    const TileStep *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
     double *cand_cost, *cand_vlast, *cand_travel; uint8_t *cand_status, *cand_keep;
 };
 // k_evaluate's argument segment: EVAL_LEAD_PTRS read-only pointers (passed on their own so that they carry
@@ -328,17 +328,19 @@ struct FusedSink {
     const DevParams *Pp;
     const InstDesc *Dp;
     uint32_t my_rng;                     // lane k: strip range of time step k of this wave (0: nothing to test)
+    float my_thr, my_thr_sure;           // lane k: the float32 thresholds of time step k (TileStep)
+    float my_thr_fatal;                  // lane k: my_thr_sure where a certain hit settles the candidate (no chance
+                                         // budget), else -1
+    float thr, thr_fatal;                // of the current time step (wave-uniform)
     const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
     int chunks_per_k;                    // ent_cap / 8
     double oxd, oyd;
-    FilterConst fc;
     uint64_t hit_mask;
     int viol;
     bool hit;
     int c_lo, n_chunks;                  // chunk range of the current time step
     uint32_t pf;                         // destination of the warm-up loads below, reserved until they have landed
     bool no_warm;
-    bool any_fatal;                      // max_viol == 0: the first violation rejects the candidate
 
     // Reads the range of time step k and touches the first cache lines of its chunks, so that they are on their
     // way into the scalar cache while the sample arithmetic runs.  The loads are hand-issued and their (unused)
@@ -349,6 +351,8 @@ struct FusedSink {
         const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)my_rng, k);
         c_lo = (int)(r >> 16);
         n_chunks = (int)(r & 0xffffu) - c_lo;
+        thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr), k));
+        thr_fatal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_fatal), k));
         if (n_chunks > 0 && !no_warm) {
             const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
             asm volatile("s_load_dword %0, %1, 0x0\n\t"
@@ -369,8 +373,6 @@ struct FusedSink {
         if (n_chunks == 0) return;                                // wave-uniform
         if (!alive || hit) return;                                // lanes whose collision outcome is already settled
         float fx = (float)(px - oxd), fy = (float)(py - oyd);
-        const float thr = filter_threshold(fc, fx, fy);
-        const float thr_sure = any_fatal ? filter_threshold_sure(fc, fx, fy) : -1.0f;
         bool sure = false;                                        // some obstacle is certainly within its radius
         const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
         for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
@@ -389,29 +391,30 @@ struct FusedSink {
                 sload_chunk_ahead<64>(cb, cp, fx);
                 const float ma = min_sqdist32_f16(ca, fx, fy);
                 near_bits = (near_bits << 1) | (uint32_t)(ma <= thr);
-                sure |= ma <= thr_sure;
+                sure |= ma <= thr_fatal;
                 swait_chunk(cb);
                 sload_chunk_ahead<128>(ca, cp, fx);
                 const float mb = min_sqdist32_f16(cb, fx, fy);
                 near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
-                sure |= mb <= thr_sure;
+                sure |= mb <= thr_fatal;
                 swait_chunk(ca);
                 cp += 2;
             }
             // a single violation is fatal (no chance constraint budget): a certain float32 hit settles the candidate
             if (sure) { hit = true; return; }
-            if (near_bits != 0) exact(k, c0, nb, near_bits, px, py, fx, fy, thr, filter_threshold_sure(fc, fx, fy));
+            if (near_bits != 0) exact(k, c0, nb, near_bits, px, py, fx, fy);
         }
     }
 
     // rare: exact float64 re-check of the chunks whose float32 distance came within the threshold
     __device__ __forceinline__ void exact(int k, int c0, int nb, uint32_t near_bits, double px, double py, float fx,
-                                          float fy, float thr, float thr_sure)
+                                          float fy)
     {
         const DevParams &P = *Pp;
         const InstDesc &D = *Dp;
         const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
         const EvalKernArgs &KA = eval_kernargs();
+        const float thr_sure = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_sure), k));
         const d2 *e64 = KA.ent64 + D.ent_off;
         const uint8_t *sid = KA.ent_sid + D.ent_off;
         const int64_t base = ((int64_t)k * chunks_per_k + c_lo) * ENT_CHUNK;
@@ -518,7 +521,7 @@ template <bool SPLIT>
 __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
                                               const InstState *__restrict__ state,
                                               const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
-                                              const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32,
+                                              const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32,
                                               const EvalKernArgs &a, const SplineView &sp_lds,
                                               double *my_rows, int inst, int tile, int lane, int tl_tag,
                                               int seg = 0, int n_seg = 1, double *s_part = nullptr)
@@ -571,8 +574,11 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 
     // lane k holds the strip range of time step k (read back with v_readlane): loaded while every lane of the
     // wave is still active, lanes without a candidate included
-    const uint32_t my_rng = D.ent_cap != 0 && lane < n_total && !(a.ablate & 1)
-                                ? wave_rng[(int64_t)(D.tile0 + tile) * n_total + lane] : 0u;
+    TileStep my_step = { 0u, 0.0f, 0.0f, 0u };
+    if (D.ent_cap != 0 && lane < n_total && !(a.ablate & 1)) my_step = wave_rng[(int64_t)(D.tile0 + tile) * n_total + lane];
+    const uint32_t my_rng = my_step.rng;
+    // (while every lane is active: the time-step loop reads lane k of these, candidate or not)
+    const float my_thr_fatal = D.max_viol == 0 ? my_step.thr_sure : -1.0f;
 #ifdef FOT_TIMELINE
     const uint64_t t_wave = __builtin_amdgcn_s_memrealtime();
     const uint64_t c_wave = __builtin_amdgcn_s_memtime();
@@ -589,12 +595,17 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     uint64_t hit_mask = 0;
     bool hit = false;
     int64_t slot = 0;
-    if (lane < n) {
-        const int idx = cand0 + lane;                            // candidate index inside the instance
+    // Lanes 0 .. n_total-1 hold the per-step values of the tile (my_step) that the time-step loop reads ACROSS lanes
+    // (v_readlane of lane k): they must be active wherever the compiler may place a copy of those registers, so they
+    // all enter the region below -- a lane without a candidate walks an empty path (n_t = 0).
+    const bool has_cand = lane < n;
+    if (has_cand || lane < n_total) {
+        const int idx = cand0 + (has_cand ? lane : 0);           // candidate index inside the instance
         slot = (int64_t)D.cand_off + idx;
         const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
         const int p = cd.lon_slot - slot_lo;
         L = s_info[p];
+        if (!has_cand) L.n_t = 0;
         tab.lds_row0 = (int)(my_rows - s_lon) + s_row0[p] * ROW_FIELDS;
         tab.k_max = profile_rows(P, D, cd.lon_slot) - 1;
         tab.info = s_info + p;
@@ -608,12 +619,11 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         FusedSink sink;
         sink.Pp = Pp; sink.Dp = &D;
         sink.my_rng = my_rng;
+        sink.my_thr = my_step.thr; sink.my_thr_sure = my_step.thr_sure; sink.thr = 0.0f; sink.thr_fatal = -1.0f;
+        sink.my_thr_fatal = my_thr_fatal;
         sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
         sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
         sink.oxd = D.ego.x; sink.oyd = D.ego.y;
-        const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
-        sink.fc = filter_const(sq_dyn > P.sq_r ? sq_dyn : P.sq_r, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
-        sink.any_fatal = D.max_viol == 0;
         sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
         sink.no_warm = (a.ablate & 2) != 0;
         // loop constants as opaque register values: the compiler then keeps them instead of re-fetching each one from
@@ -636,7 +646,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         // segments 1.. leave their state in LDS, the wave of segment 0 folds them in, in time order
         double *pf = s_part + (seg - 1) * SEG_DOUBLES;
         int *pi = (int *)(pf + SEG_F64 * WAVE);
-        if (seg > 0 && lane < n) {
+        if (seg > 0 && has_cand) {
             pf[0 * WAVE + lane] = g.Jp; pf[1 * WAVE + lane] = g.d_last; pf[2 * WAVE + lane] = g.v_last;
             pf[3 * WAVE + lane] = g.acc.max_step2; ((uint64_t *)pf)[4 * WAVE + lane] = hit_mask;
             pi[0 * WAVE + lane] = (int)g.acc.fl; pi[1 * WAVE + lane] = g.first_nan;
@@ -644,7 +654,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         }
         __syncthreads();
         if (seg != 0) return;
-        if (lane < n) {
+        if (has_cand) {
             for (int sg = 1; sg < n_seg; ++sg) {
                 if (sg * seg_len >= L.n_t) break;                // that segment held no sample of this candidate
                 const double *qf = s_part + (sg - 1) * SEG_DOUBLES;
@@ -662,7 +672,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
             hit |= __popcll(hit_mask) > D.max_viol;
         }
     }
-    if (lane < n) {
+    if (has_cand) {
         CandResult r;
         finish_candidate(P, D, L, tab, g, hit, r);
         const EvalKernArgs &KA = eval_kernargs();
@@ -689,10 +699,15 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 // so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
 // ladder run longest), so the long tiles start early and the short ones fill the end of the launch.  The waves of a
 // workgroup share nothing but the staged spline: each has its own slice of LDS.
+// One wave per tile.  The grid deals the tiles out position-major and XCD-aligned: workgroup b serves the instances
+// x, x + 8, ... with x = b mod 8 -- the XCD that, under round-robin placement, also ran k_cull's workgroups for them,
+// so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
+// ladder run longest), so the long tiles start early and the short ones fill the end of the launch.  The waves of a
+// workgroup share nothing but the staged spline: each has its own slice of LDS.
 __global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
            const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
-           const uint32_t *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
+           const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
 {
     // (eval_kernargs() addresses the struct's fields in the argument segment, behind the EVAL_LEAD_PTRS pointers)
     const int waves_per_wg = (int)blockDim.x / WAVE;
@@ -719,7 +734,7 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
 __global__ void __launch_bounds__(SEG_MAX * WAVE)
 k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
                  const InstState *__restrict__ state, const int32_t *__restrict__ tile_cand0,
-                 const int32_t *__restrict__ tile_n, const uint32_t *__restrict__ wave_rng,
+                 const int32_t *__restrict__ tile_n, const TileStep *__restrict__ wave_rng,
                  const f2 *__restrict__ ent32, const EvalKernArgs a)
 {
     const int n_seg = (int)blockDim.x / WAVE;
@@ -762,7 +777,7 @@ __global__ void __launch_bounds__(CULL_KG * WAVE)
 k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
        int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
-       uint32_t *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+       TileStep *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
        int ablate)
 {
     __shared__ int s_cnt[CULL_KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
@@ -792,6 +807,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const int n_prof = S.c2f_ok ? n_grid_lon + S.n_brake : 0;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
     const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
+    const FilterConst fc = filter_const(sq_max, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
     const float slack = box_footprint_slack(P);
 
     const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
@@ -893,7 +909,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const float mk = s_margin[kk];
     const bool live_k = bk.x0 <= bk.x1;
     const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
-    uint32_t *rng = wave_rng + (int64_t)D.tile0 * P.n_total + k;                   // + tile * n_total
+    TileStep *rng = wave_rng + (int64_t)D.tile0 * P.n_total + k;                   // + tile * n_total
     const int count = s_start[kk][CULL_BINS];
     const int row = k < D.T - 1 ? k : D.T - 1;
     auto point = [&](int i, d2 &o, int &sid) {                                      // obstacle i at step k
@@ -946,7 +962,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     if (lane == 0) ent_cnt[(int64_t)inst * P.n_total + k] = padded;
     // chunk range of every tile of the instance
     for (int w = lane; w < D.n_tiles; w += WAVE) {
-        uint32_t r = 0u;
+        TileStep r = { 0u, 0.0f, 0.0f, 0u };
         const int idx0 = tile_cand0[D.shape_off + w];
         if (live_k && idx0 < S.n_cand && !(ablate & 1)) {
             const int last = idx0 + tile_n[D.shape_off + w] - 1;
@@ -960,7 +976,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
                 box_merge(wb, profile_box_at(P, D, S.frenet0, sp, sl, k, s_ext[kk][e][0], s_ext[kk][e][1]));
             }
             const float wm = cull_margin(sq_max, wb) + slack;
-            r = strip_range(bmk, wb, wm, [&](int bb) { return s_start[kk][bb]; });
+            r.rng = strip_range(bmk, wb, wm, [&](int bb) { return s_start[kk][bb]; });
+            box_thresholds(fc, wb, wm, r.thr, r.thr_sure);
         }
         rng[(int64_t)w * P.n_total] = r;
     }
@@ -1418,7 +1435,9 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     // Fewer tiles than a quarter of the GPU's SIMDs: every tile is cut into time segments (k_evaluate_split).
     int n_seg = tiles.n_tiles <= 256 ? SEG_MAX : tiles.n_tiles <= 512 ? 2 : 1;
     if (tiles.eval_segments >= 1 && tiles.eval_segments <= SEG_MAX) n_seg = tiles.eval_segments;
-    const int wpw = n_seg > 1 ? 1 : tiles.n_tiles >= 1024 ? EVAL_WG / WAVE : 1;
+    static const int force_wpw = getenv("FOT_EVAL_WPW") ? atoi(getenv("FOT_EVAL_WPW")) : 0;      // diagnostics
+    int wpw = n_seg > 1 ? 1 : tiles.n_tiles >= 1024 ? EVAL_WG / WAVE : 1;
+    if (n_seg == 1 && force_wpw >= 1 && force_wpw <= EVAL_WG / WAVE) wpw = force_wpw;
     const int64_t per_queue = (int64_t)((n_inst + N_XCD - 1) / N_XCD) * tiles.max_tiles;
     const int64_t n_blocks = (per_queue + wpw - 1) / wpw * N_XCD;
     if (n_blocks > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;

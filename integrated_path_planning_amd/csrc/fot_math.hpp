@@ -1013,6 +1013,18 @@ FOT_HD float filter_threshold_sure(const FilterConst &f, float px, float py)
     return (f.sq_lo - 4.0f * f.r * e) * 0.999998f - 1e-30f;
 }
 
+// Both thresholds for EVERY point of a float32 box (instance-local frame) grown by m: filter_threshold grows and
+// filter_threshold_sure shrinks with |px| + |py|, so their values at the box's bound of |x| + |y| hold for each point
+// inside.  k_cull evaluates this once per (tile, time step) for the box of the tile's profiles grown by the cull
+// margin (collision radius + rounding slack + footprint offsets: the collision points of the tile's candidates lie
+// inside); k_evaluate then compares against two wave-uniform values instead of deriving them per sample.
+FOT_HD void box_thresholds(const FilterConst &f, const Box32 &b, float m, float &thr, float &thr_sure)
+{
+    const float bx = fmaxf(fabsf(b.x0), fabsf(b.x1)) + m, by = fmaxf(fabsf(b.y0), fabsf(b.y1)) + m;
+    thr = filter_threshold(f, bx, by);
+    thr_sure = filter_threshold_sure(f, bx, by);
+}
+
 // exact float64 test of one chunk (the reference's test); updates the per-sample hit state
 FOT_HD void exact_chunk(const d2 *e64, const uint8_t *sid, double px, double py, double sq_static, double sq_dyn,
                         int max_viol, uint64_t &hit_mask, int &viol, bool &collided)
@@ -1061,6 +1073,8 @@ FOT_HD void exact_chunk_f32first(const f2x8 &c32, const d2 *e64, const uint8_t *
 // the chunk walk on scalar loads.
 struct EntryCollider {
     const uint32_t *rng;                 // [n_total] strip ranges of this candidate's wave, nullptr: no obstacles
+    const float *thr_k = nullptr, *thr_sure_k = nullptr;   // [n_total] the tile's thresholds per step (box_thresholds),
+                                                           // nullptr: derived from the point itself
     const f2 *e32; const d2 *e64; const uint8_t *sid;                       // of this instance
     int ent_cap, max_viol;
     double ox, oy, sq_static, sq_dyn, sq_max;
@@ -1085,7 +1099,8 @@ struct EntryCollider {
         const int64_t base = (int64_t)k * ent_cap;
         const float fx = (float)(px - ox), fy = (float)(py - oy);
         const FilterConst fc = filter_const(sq_max, sq_dyn < sq_static ? sq_dyn : sq_static);
-        const float thr = filter_threshold(fc, fx, fy), thr_sure = filter_threshold_sure(fc, fx, fy);
+        const float thr = thr_k ? thr_k[k] : filter_threshold(fc, fx, fy);
+        const float thr_sure = thr_sure_k ? thr_sure_k[k] : filter_threshold_sure(fc, fx, fy);
         for (int c = c_lo * ENT_CHUNK; c < c_hi * ENT_CHUNK && !hit; c += ENT_CHUNK) {
             const float m = min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy);
             if (m > thr) continue;

@@ -161,6 +161,8 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         if ((int)tile_c0.size() != D.n_tiles) return -105;                // what build_batch_layout counted
         const int n_tiles_inst = (int)tile_c0.size();
         std::vector<uint32_t> rng((size_t)std::max(n_tiles_inst, 1) * P.n_total, 0u);
+        // k_cull's per (tile, step) thresholds (TileStep) and the bound of |x| + |y| they were taken at
+        std::vector<float> thr_t(rng.size(), 0.0f), thr_sure_t(rng.size(), 0.0f), bound_t(rng.size(), -1.0f);
         if (D.ent_cap > 0) {
             const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
             const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
@@ -204,6 +206,11 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     const uint32_t r = strip_range(bm, wb, wm, [&](int b) { return bin_start[b]; });
                     if ((int)(r & 0xffffu) * ENT_CHUNK > cnt[k]) return -101;          // range must stay inside the padded list
                     rng[(size_t)w * P.n_total + k] = r;
+                    const double sq_dyn_ = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
+                    const FilterConst fc = filter_const(sq_max, sq_dyn_ < P.sq_r ? sq_dyn_ : P.sq_r);
+                    const size_t at = (size_t)w * P.n_total + k;
+                    box_thresholds(fc, wb, wm, thr_t[at], thr_sure_t[at]);
+                    bound_t[at] = std::fmax(std::fabs(wb.x0), std::fabs(wb.x1)) + std::fmax(std::fabs(wb.y0), std::fabs(wb.y1));
                 }
             }
         }
@@ -223,6 +230,10 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             ec.init(P, D);
             ec.rng = D.ent_cap > 0 ? rng.data() + (size_t)tile_of[(size_t)idx] * P.n_total : nullptr;
             ec.e32 = e32.data(); ec.e64 = e64.data(); ec.sid = sid.data();
+            if (D.ent_cap > 0) {
+                ec.thr_k = thr_t.data() + (size_t)tile_of[(size_t)idx] * P.n_total;
+                ec.thr_sure_k = thr_sure_t.data() + (size_t)tile_of[(size_t)idx] * P.n_total;
+            }
             CandResult r;
             evaluate_candidate(P, D, loop_const(P, D), Li, GlobalTab{ tab }, q, P.n_total, ec, r);
             {   // broad phase + in-loop test vs the definition on the recorded points
@@ -235,6 +246,17 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     if (collide_candidate(P, D, obs, rk.keep, src)) want = FOT_ST_COLLISION;
                 }
                 if (want != r.status || rk.keep != r.keep) return -100;
+                // the tile's box bounds |x| + |y| of every collision point of its candidates (box_thresholds)
+                const int n_circ = P.has_footprint ? P.n_circ : 1;
+                for (int k = 0; k < rk.keep && D.ent_cap > 0; ++k) {
+                    const float bound = bound_t[(size_t)tile_of[(size_t)idx] * P.n_total + k];
+                    if (bound < 0.0f) continue;                              // (no live box at this step)
+                    for (int ci = 0; ci < n_circ; ++ci) {
+                        const d2 &v = pts[(size_t)ci * P.n_total + k];
+                        const float fx = (float)(v.x - D.ego.x), fy = (float)(v.y - D.ego.y);
+                        if (!(std::fabs(fx) + std::fabs(fy) <= bound + 2.0f * box_footprint_slack(P) + 2e-3f)) return -113;
+                    }
+                }
             }
             for (int n_seg = 2; n_seg <= 4; ++n_seg) {   // k_evaluate_split: time segments merged == the single walk
                 const int n_loop = P.n_total, seg_len = (n_loop + n_seg - 1) / n_seg;
