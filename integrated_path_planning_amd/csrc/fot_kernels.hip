@@ -492,6 +492,12 @@ struct StagedTab {
 __device__ uint64_t g_timeline[4 * 16384];
 __device__ uint64_t g_shader_clock[2 * 16384];     // s_memtime at loop start / end: shader cycles (in-kernel clock)
 __device__ uint64_t g_row_wait[16384];             // shader cycles lane 0 spent between issuing and having its LDS rows
+__device__ uint64_t g_phase[4 * 16384];            // kernel entry, spline staged, profile summaries ready, loop done
+__shared__ uint64_t s_tl_entry[2];                 // kernel entry / spline staged, of this workgroup
+extern "C" int fot_timeline_read_phase(uint64_t *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(uint64_t) * (size_t)n_words);
+}
 extern "C" int fot_timeline_read_rows(uint64_t *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_wait), sizeof(uint64_t) * (size_t)n_words);
@@ -552,6 +558,9 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     }
     if (lane < n_stage && seg == 0) s_info[lane] = profile_info(P, D, S.frenet0, slot_lo + lane, true);
     lds_fence();
+#ifdef FOT_TIMELINE
+    const uint64_t t_info = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int p = 0; p < n_stage; ++p) { const int nt = s_info[p].n_t; n_loop = nt > n_loop ? nt : n_loop; }
     n_loop = __builtin_amdgcn_readfirstlane(n_loop);
     for (int i = seg * WAVE + lane; i < total_rows; i += n_seg * WAVE) {
@@ -642,6 +651,9 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         tl_rows = tab.t_rows;
 #endif
     }
+#ifdef FOT_TIMELINE
+    const uint64_t t_loop_end = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (SPLIT) {
         // segments 1.. leave their state in LDS, the wave of segment 0 folds them in, in time order
         double *pf = s_part + (seg - 1) * SEG_DOUBLES;
@@ -690,6 +702,8 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         g_timeline[tl_wave * 4 + 3] = (uint64_t)(uint32_t)tl_chunks | ((uint64_t)(uint32_t)tl_tag << 32);
         g_shader_clock[tl_wave * 2 + 0] = c_wave; g_shader_clock[tl_wave * 2 + 1] = __builtin_amdgcn_s_memtime();
         g_row_wait[tl_wave] = tl_rows;
+        g_phase[tl_wave * 4 + 0] = s_tl_entry[0]; g_phase[tl_wave * 4 + 1] = s_tl_entry[1];
+        g_phase[tl_wave * 4 + 2] = t_info; g_phase[tl_wave * 4 + 3] = t_loop_end;
     }
 #endif
 }
@@ -704,7 +718,8 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 // so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
 // ladder run longest), so the long tiles start early and the short ones fill the end of the launch.  The waves of a
 // workgroup share nothing but the staged spline: each has its own slice of LDS.
-__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
+template <int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
 k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
            const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
            const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
@@ -712,8 +727,15 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     // (eval_kernargs() addresses the struct's fields in the argument segment, behind the EVAL_LEAD_PTRS pointers)
     const int waves_per_wg = (int)blockDim.x / WAVE;
     const int wave_doubles = eval_wave_doubles(a.row_budget);
+#ifdef FOT_TIMELINE
+    if (threadIdx.x == 0) s_tl_entry[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     // LDS: per wave [rows | summaries | row offsets], then the spline (shared by the workgroup's waves)
     const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_lon + waves_per_wg * wave_doubles);
+#ifdef FOT_TIMELINE
+    if (threadIdx.x == 0) s_tl_entry[1] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+#endif
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int lane = threadIdx.x & (WAVE - 1);
     double *my_rows = s_lon + wv * wave_doubles;
@@ -1453,8 +1475,10 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     if (n_seg > 1)
         k_evaluate_split<<<(unsigned)n_blocks, n_seg * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng,
                                                                         e.e32, a);
+    else if (tiles.row_budget <= TILE_ROWS_4WAVES)                            // 16 waves share a CU's LDS (and 128 VGPRs do)
+        k_evaluate<4><<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     else
-        k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
+        k_evaluate<3><<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     FOT_LAUNCH_CHECK();
     return 0;
 }

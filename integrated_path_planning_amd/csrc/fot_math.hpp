@@ -325,11 +325,15 @@ FOT_HD int profile_rows(const DevParams &P, const InstDesc &D, int slot)
     return ne < P.n_total ? ne + 1 : ne;
 }
 
-// rows one wave of k_evaluate may stage: three full-length profiles and a little more (the seven brake-ladder entries of
-// the default lattice then share one tile); 12 waves per CU x (rows x 72 B + summaries) stay below the 160 KB of LDS
-FOT_HD int tile_row_budget(int n_total)
+// Rows one wave of k_evaluate may stage.  Two cuts: three full-length profiles and a little more (the seven
+// brake-ladder entries of the default lattice then share one tile) -- 12 waves per CU x (rows x 72 B + summaries) stay
+// below the 160 KB of LDS, three waves per SIMD; or at most TILE_ROWS_4WAVES rows (two full-length profiles), which lets
+// 16 waves share the CU's LDS: four waves per SIMD (k_evaluate then has to make do with 128 vector registers, which it
+// does).  The handle picks the cut by the number of tiles either one makes of its lattice (build_tile_shapes).
+constexpr int TILE_ROWS_4WAVES = 126;
+FOT_HD int tile_row_budget(int n_total, int profiles)
 {
-    const int want = 3 * n_total + 8, cap = 176;
+    const int want = profiles * n_total + 8, cap = profiles >= 3 ? 176 : TILE_ROWS_4WAVES;
     return want < cap ? want : (cap > n_total ? cap : n_total);
 }
 

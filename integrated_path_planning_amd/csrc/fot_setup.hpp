@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "fot_types.h"
@@ -175,10 +176,10 @@ struct TileShapes {
     int tiles_of(int n_tv) const { return off[n_tv + 1] - off[n_tv]; }
 };
 
-inline void build_tile_shapes(const DevParams &P, TileShapes &T)
+inline void build_tile_shapes(const DevParams &P, TileShapes &T, int row_budget)
 {
     T = TileShapes();
-    T.row_budget = tile_row_budget(P.n_total);
+    T.row_budget = row_budget;
     for (int n_tv = 0; n_tv <= FOT_MAX_TV; ++n_tv) {
         T.off[n_tv] = (int32_t)T.cand0.size();
         InstDesc D = InstDesc();
@@ -193,6 +194,20 @@ inline void build_tile_shapes(const DevParams &P, TileShapes &T)
         }
     }
     T.off[FOT_MAX_TV + 1] = (int32_t)T.cand0.size();
+}
+
+// The cut of the handle's lattice: two-profile tiles (four waves per SIMD in k_evaluate) unless they make over 15 %
+// more tiles than three-profile ones -- a lattice with few lateral offsets fills the 64 lanes of a tile badly either
+// way, and worse with two profiles (measured on the 29-offset lattice: 11 % more tiles, 6 % less time).
+// FOT_TILE_PROFILES=2|3 in the environment forces the cut (diagnostics).
+inline void build_tile_shapes(const DevParams &P, TileShapes &T)
+{
+    TileShapes two, three;
+    build_tile_shapes(P, two, tile_row_budget(P.n_total, 2));
+    build_tile_shapes(P, three, tile_row_budget(P.n_total, 3));
+    bool use_two = two.row_budget <= TILE_ROWS_4WAVES && (double)two.cand0.size() <= 1.15 * (double)three.cand0.size();
+    if (const char *e = getenv("FOT_TILE_PROFILES")) use_two = atoi(e) == 2 && two.row_budget <= TILE_ROWS_4WAVES;
+    T = use_two ? two : three;
 }
 
 struct BatchLayout {

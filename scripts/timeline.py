@@ -67,6 +67,16 @@ def main():
             ghz = (ck[okc, 1] - ck[okc, 0]) / ((t[okc, 2] - t[okc, 1]) * 10.0)          # cycles per ns (100 MHz ticks)
             print(f"in-kernel shader clock over the wave loops: median {np.median(ghz):.3f} GHz "
                   f"(p5 {np.percentile(ghz, 5):.3f}, p95 {np.percentile(ghz, 95):.3f})")
+    if hasattr(L, "fot_timeline_read_phase"):                              # where a tile's time goes before its loop
+        ph = np.zeros(4 * 16384, dtype=np.uint64)
+        L.fot_timeline_read_phase.argtypes = [C.c_void_p, C.c_int]
+        if L.fot_timeline_read_phase(ph.ctypes.data, ph.size) == 0:
+            ph = ph.reshape(-1, 4).astype(np.int64)
+            okp = (t[:, 2] > t[:, 1]) & (ph[:, 0] > 0)
+            us = lambda a: "median %.2f p95 %.2f" % (np.median(a) / 100.0, np.percentile(a, 95) / 100.0)
+            print("per tile [us]: entry -> spline staged " + us((ph[:, 1] - ph[:, 0])[okp]) + "; -> tile start " + us((t[:, 0] - ph[:, 1])[okp])
+                  + "; -> summaries " + us((ph[:, 2] - t[:, 0])[okp]) + "; -> rows built " + us((t[:, 1] - ph[:, 2])[okp])
+                  + "; loop " + us((ph[:, 3] - t[:, 1])[okp]) + "; epilogue " + us((t[:, 2] - ph[:, 3])[okp]))
     n_waves = int(np.nonzero(t[:, 2])[0].max()) + 1
     n_waves = (n_waves + WPB - 1) // WPB * WPB
     t = t[:n_waves]
