@@ -273,6 +273,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     tt.n = h->dShapes.as<int32_t>() + h->shapes.cand0.size();
     tt.n_tiles = L.n_tiles; tt.max_tiles = L.max_tiles; tt.row_budget = L.row_budget;
     tt.eval_segments = h->eval_segments;
+    tt.grouped = L.grouped;
     const DevParams *dP = h->dP.as<DevParams>();
     const SplineView sv = spline_view(h);
     CandArrays ca;

@@ -41,6 +41,7 @@ struct MetaImport {
 struct TileTable {
     const int32_t *cand0 = nullptr, *n = nullptr;
     int n_tiles = 0, max_tiles = 0, row_budget = 0;
+    int grouped = 0;                    // groups of GROUP_TILES tiles share a row table (TileShapes::grouped)
     int eval_segments = 0;              // time segments per tile in k_evaluate: 0 = by batch size, 1..4 forced (tests)
 };
 

@@ -446,9 +446,14 @@ __host__ __device__ constexpr int eval_wave_doubles(int row_budget)
 {
     return row_budget * ROW_FIELDS + TILE_MAX_PROFILES * LONINFO_DOUBLES + TILE_MAX_PROFILES / 2;
 }
+// doubles of LDS of a group's shared table (k_evaluate_group)
+__host__ __device__ constexpr int eval_group_doubles()
+{
+    return GROUP_ROWS * ROW_FIELDS + GROUP_MAX_PROFILES * LONINFO_DOUBLES + GROUP_MAX_PROFILES / 2;
+}
 // A tile cut into time segments (k_evaluate_split): what a later segment hands to the wave of segment 0, per lane
 constexpr int SEG_MAX = 4;
-constexpr int SEG_F64 = 5, SEG_I32 = 4;  // Jp, d_last, v_last, max_step2, hit_mask | flags, first_nan, k_last, hit
+constexpr int SEG_F64 = 4, SEG_I32 = 4;  // d_last, v_last, max_step2, hit_mask | flags, first_nan, k_last, hit
 constexpr int SEG_DOUBLES = (SEG_F64 + SEG_I32 / 2) * WAVE;
 
 struct StagedTab {
@@ -519,51 +524,66 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
-// One tile: rows of its profiles into LDS, then one candidate per lane.  SPLIT == false: the wave owns the tile and
-// its slice of LDS (my_rows).  SPLIT == true: the workgroup's n_seg waves share the tile -- they build the rows
-// together, wave `seg` walks the time steps [seg, seg + 1) * ceil(n_loop / n_seg) of every candidate, and wave 0 merges
-// the segments (seg_merge) through `s_part`.
-template <bool SPLIT>
+// One tile: rows of its profiles into LDS, then one candidate per lane.
+//   TILE_WAVE   the wave owns the tile and its slice of LDS (rows_base).
+//   TILE_SPLIT  the workgroup's n_sub waves share the tile -- they build the rows together, wave `sub` walks the time
+//               steps [sub, sub + 1) * ceil(n_loop / n_sub) of every candidate, and wave 0 merges the segments
+//               (seg_merge) through `s_part`.
+//   TILE_GROUP  the workgroup's GROUP_TILES waves take the tiles grp_tile0 + sub of one group (fot_math.hpp): they
+//               build the rows of ALL the group's profiles together, each walks its own tile.
+enum { TILE_WAVE = 0, TILE_SPLIT = 1, TILE_GROUP = 2 };
+template <int MODE>
 __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
                                               const InstState *__restrict__ state,
                                               const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
                                               const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32,
                                               const EvalKernArgs &a, const SplineView &sp_lds,
                                               double *my_rows, int inst, int tile, int lane, int tl_tag,
-                                              int seg = 0, int n_seg = 1, double *s_part = nullptr)
+                                              int sub = 0, int n_sub = 1, double *s_part = nullptr, int grp_tile0 = 0)
 {
+    constexpr bool SPLIT = MODE == TILE_SPLIT, GROUP = MODE == TILE_GROUP;
+    const int seg = SPLIT ? sub : 0, n_seg = SPLIT ? n_sub : 1;
     const DevParams &P = *Pp;
     const InstDesc &D = desc[inst];
     const InstState &S = state[inst];
     const int n_total = P.n_total;
     const int cand0 = tile_cand0[D.shape_off + tile];
     int n = tile_n[D.shape_off + tile];
-    if (!S.c2f_ok || cand0 >= S.n_cand) return;                 // (the brake ladder of a standing ego)
-    if (cand0 + n > S.n_cand) n = S.n_cand - cand0;
+    // candidates whose profiles are staged in this slice: the tile's own, or the whole group's
+    int stage_c0 = cand0, stage_c1 = cand0 + n;                  // [first, one past the last)
+    if constexpr (GROUP) {
+        stage_c0 = tile_cand0[D.shape_off + grp_tile0];
+        stage_c1 = tile_cand0[D.shape_off + grp_tile0 + GROUP_TILES - 1] + tile_n[D.shape_off + grp_tile0 + GROUP_TILES - 1];
+    }
+    if constexpr (!GROUP) { if (n <= 0) return; }               // (a padding tile of the grouped cut)
+    if (!S.c2f_ok || stage_c0 >= S.n_cand) return;              // (the brake ladder of a standing ego) -- the whole workgroup
+    if (stage_c1 > S.n_cand) stage_c1 = S.n_cand;
+    if (cand0 + n > S.n_cand) n = S.n_cand - cand0 > 0 ? S.n_cand - cand0 : 0;
 #ifdef FOT_TIMELINE
     const uint64_t t_blk = __builtin_amdgcn_s_memrealtime();
 #endif
-    LonInfo *s_info = (LonInfo *)(my_rows + a.row_budget * ROW_FIELDS);
-    int *s_row0 = (int *)(s_info + TILE_MAX_PROFILES);
-    // profiles of the tile's first .. last candidate (slots grow with the candidate index)
-    const int slot_lo = decode_candidate(P, D, S.frenet0, cand0).lon_slot;
-    const int n_stage = decode_candidate(P, D, S.frenet0, cand0 + n - 1).lon_slot - slot_lo + 1;
-    const auto lds_fence = [] { if constexpr (SPLIT) __syncthreads(); else wave_lds_fence(); };
-    if constexpr (!SPLIT) wave_lds_fence();                     // the previous tile's rows are no longer read
+    constexpr int PROF_CAP = GROUP ? GROUP_MAX_PROFILES : TILE_MAX_PROFILES;
+    LonInfo *s_info = (LonInfo *)(my_rows + (GROUP ? GROUP_ROWS : a.row_budget) * ROW_FIELDS);
+    int *s_row0 = (int *)(s_info + PROF_CAP);
+    // staged profiles: of the first .. last staged candidate (slots grow with the candidate index)
+    const int slot_lo = decode_candidate(P, D, S.frenet0, stage_c0).lon_slot;
+    const int n_stage = decode_candidate(P, D, S.frenet0, stage_c1 - 1).lon_slot - slot_lo + 1;
+    const auto lds_fence = [] { if constexpr (MODE != TILE_WAVE) __syncthreads(); else wave_lds_fence(); };
+    if constexpr (MODE == TILE_WAVE) wave_lds_fence();           // the previous tile's rows are no longer read
+    // who builds: the wave itself, or all waves of the workgroup together
+    const int bld_id = (MODE == TILE_WAVE ? 0 : sub * WAVE) + lane, bld_n = (MODE == TILE_WAVE ? 1 : n_sub) * WAVE;
     int total_rows = 0, n_loop = 0;
     for (int p = 0; p < n_stage; ++p) {                         // wave-uniform: a handful of scalar operations
         const int r = profile_rows(P, D, slot_lo + p);
-        if (lane == p && seg == 0) s_row0[p] = total_rows;
+        if (bld_id == p) s_row0[p] = total_rows;
         total_rows += r;
     }
-    if (lane < n_stage && seg == 0) s_info[lane] = profile_info(P, D, S.frenet0, slot_lo + lane, true);
+    if (bld_id < n_stage) s_info[bld_id] = profile_info(P, D, S.frenet0, slot_lo + bld_id, true);
     lds_fence();
 #ifdef FOT_TIMELINE
     const uint64_t t_info = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int p = 0; p < n_stage; ++p) { const int nt = s_info[p].n_t; n_loop = nt > n_loop ? nt : n_loop; }
-    n_loop = __builtin_amdgcn_readfirstlane(n_loop);
-    for (int i = seg * WAVE + lane; i < total_rows; i += n_seg * WAVE) {
+    for (int i = bld_id; i < total_rows; i += bld_n) {
         int p = 0;
         for (int pp = 1; pp < n_stage; ++pp) p = i >= s_row0[pp] ? pp : p;
         const int k = i - s_row0[p];
@@ -576,6 +596,14 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
     }
     lds_fence();
+    if constexpr (GROUP) { if (n <= 0) return; }                // (a padding tile, or one past a standing ego's lattice)
+    // the time steps this tile needs: the longest of its OWN profiles
+    {
+        const int own_lo = decode_candidate(P, D, S.frenet0, cand0).lon_slot - slot_lo;
+        const int own_hi = decode_candidate(P, D, S.frenet0, cand0 + n - 1).lon_slot - slot_lo;
+        for (int p = own_lo; p <= own_hi; ++p) { const int nt = s_info[p].n_t; n_loop = nt > n_loop ? nt : n_loop; }
+        n_loop = __builtin_amdgcn_readfirstlane(n_loop);
+    }
     // this wave's time steps
     const int seg_len = (n_loop + n_seg - 1) / n_seg;
     const int k0 = SPLIT ? seg * seg_len : 0;
@@ -604,6 +632,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     uint64_t hit_mask = 0;
     bool hit = false;
     int64_t slot = 0;
+    double q[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };              // lateral quintic of the lane's candidate
     // Lanes 0 .. n_total-1 hold the per-step values of the tile (my_step) that the time-step loop reads ACROSS lanes
     // (v_readlane of lane k): they must be active wherever the compiler may place a copy of those registers, so they
     // all enter the region below -- a lane without a candidate walks an empty path (n_t = 0).
@@ -619,7 +648,6 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         tab.k_max = profile_rows(P, D, cd.lon_slot) - 1;
         tab.info = s_info + p;
         tab.dt = P.dt;
-        double q[6];
         lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
         // q[0..2] are the instance's lateral state (wave-uniform): as scalar values they end up in spilled SGPRs and
         // come back through v_readlane in every time step -- three vector registers are cheaper
@@ -659,8 +687,8 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         double *pf = s_part + (seg - 1) * SEG_DOUBLES;
         int *pi = (int *)(pf + SEG_F64 * WAVE);
         if (seg > 0 && has_cand) {
-            pf[0 * WAVE + lane] = g.Jp; pf[1 * WAVE + lane] = g.d_last; pf[2 * WAVE + lane] = g.v_last;
-            pf[3 * WAVE + lane] = g.acc.max_step2; ((uint64_t *)pf)[4 * WAVE + lane] = hit_mask;
+            pf[0 * WAVE + lane] = g.d_last; pf[1 * WAVE + lane] = g.v_last;
+            pf[2 * WAVE + lane] = g.acc.max_step2; ((uint64_t *)pf)[3 * WAVE + lane] = hit_mask;
             pi[0 * WAVE + lane] = (int)g.acc.fl; pi[1 * WAVE + lane] = g.first_nan;
             pi[2 * WAVE + lane] = g.k_last; pi[3 * WAVE + lane] = hit ? 1 : 0;
         }
@@ -672,12 +700,12 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
                 const double *qf = s_part + (sg - 1) * SEG_DOUBLES;
                 const int *qi = (const int *)(qf + SEG_F64 * WAVE);
                 SegState nx;
-                nx.Jp = qf[0 * WAVE + lane]; nx.d_last = qf[1 * WAVE + lane]; nx.v_last = qf[2 * WAVE + lane];
-                nx.acc.max_step2 = qf[3 * WAVE + lane];
+                nx.d_last = qf[0 * WAVE + lane]; nx.v_last = qf[1 * WAVE + lane];
+                nx.acc.max_step2 = qf[2 * WAVE + lane];
                 nx.acc.fl = (uint32_t)qi[0 * WAVE + lane]; nx.first_nan = qi[1 * WAVE + lane];
                 nx.k_last = qi[2 * WAVE + lane];
                 if (seg_merge(g, nx)) {
-                    hit_mask |= ((const uint64_t *)qf)[4 * WAVE + lane];
+                    hit_mask |= ((const uint64_t *)qf)[3 * WAVE + lane];
                     hit |= qi[3 * WAVE + lane] != 0;
                 }
             }
@@ -686,7 +714,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     }
     if (has_cand) {
         CandResult r;
-        finish_candidate(P, D, L, tab, g, hit, r);
+        finish_candidate(P, D, L, tab, q, g, hit, r);
         const EvalKernArgs &KA = eval_kernargs();
         KA.cand_cost[slot] = r.cost;
         KA.cand_vlast[slot] = r.v_last;
@@ -718,8 +746,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 // so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
 // ladder run longest), so the long tiles start early and the short ones fill the end of the launch.  The waves of a
 // workgroup share nothing but the staged spline: each has its own slice of LDS.
-template <int WAVES_PER_SIMD>
-__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
+__global__ void __launch_bounds__(EVAL_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
            const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
            const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
@@ -746,7 +773,7 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int inst = x + N_XCD * j;
     const int n_tiles = desc[inst].n_tiles;
     if (pos >= n_tiles) return;                                  // a shorter lattice than the batch's longest
-    evaluate_tile<false>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst,
+    evaluate_tile<TILE_WAVE>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst,
                          n_tiles - 1 - pos, lane, x);
 }
 
@@ -768,13 +795,48 @@ k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
     const int lane = threadIdx.x & (WAVE - 1);
     const int x = (int)blockIdx.x & (N_XCD - 1), q = (int)blockIdx.x >> 3;
     const int m_x = (a.n_inst - x + N_XCD - 1) / N_XCD;
-    if (m_x <= 0 || q >= m_x * a.max_tiles) return;
+    if (m_x <= 0) return;
+    if (q >= m_x * a.max_tiles) return;
     const int pos = q / m_x, j = q - pos * m_x;
     const int inst = x + N_XCD * j;
     const int n_tiles = desc[inst].n_tiles;
     if (pos >= n_tiles) return;
-    evaluate_tile<true>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst,
-                        n_tiles - 1 - pos, lane, x, seg, n_seg, s_part);
+    const int tile = n_tiles - 1 - pos;
+    evaluate_tile<TILE_SPLIT>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile, lane, x,
+                              seg, n_seg, s_part);
+}
+
+// The grouped cut (fot_math.hpp): one workgroup per group of GROUP_TILES tiles, one shared row table, four such
+// workgroups per CU -- four waves per SIMD.  Same order as above with groups in the place of tiles: queue x holds the
+// groups of the instances x, x + 8, ... position-major, an instance's last group first.
+__global__ void __launch_bounds__(GROUP_TILES * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
+                 const InstState *__restrict__ state, const int32_t *__restrict__ tile_cand0,
+                 const int32_t *__restrict__ tile_n, const TileStep *__restrict__ wave_rng,
+                 const f2 *__restrict__ ent32, const EvalKernArgs a)
+{
+    // LDS: [rows | summaries | row offsets] of the group, then the spline
+#ifdef FOT_TIMELINE
+    if (threadIdx.x == 0) s_tl_entry[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_lon + eval_group_doubles());
+#ifdef FOT_TIMELINE
+    if (threadIdx.x == 0) s_tl_entry[1] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+#endif
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int x = (int)blockIdx.x & (N_XCD - 1), q = (int)blockIdx.x >> 3;
+    const int m_x = (a.n_inst - x + N_XCD - 1) / N_XCD;
+    const int n_entries = m_x * (a.max_tiles / GROUP_TILES);      // groups in this queue
+    if (m_x <= 0 || q >= n_entries) return;
+    const int pos = q / m_x, j = q - pos * m_x;
+    const int inst = x + N_XCD * j;
+    const int n_groups = desc[inst].n_tiles / GROUP_TILES;
+    if (pos >= n_groups) return;                                 // a shorter lattice than the batch's longest
+    const int tile0 = (n_groups - 1 - pos) * GROUP_TILES;
+    evaluate_tile<TILE_GROUP>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile0 + wv,
+                              lane, x, wv, GROUP_TILES, nullptr, tile0);
 }
 
 // ---------------------------------------------------------------------------
@@ -986,7 +1048,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     for (int w = lane; w < D.n_tiles; w += WAVE) {
         TileStep r = { 0u, 0.0f, 0.0f, 0u };
         const int idx0 = tile_cand0[D.shape_off + w];
-        if (live_k && idx0 < S.n_cand && !(ablate & 1)) {
+        if (live_k && idx0 < S.n_cand && tile_n[D.shape_off + w] > 0 && !(ablate & 1)) {   // (not a padding tile)
             const int last = idx0 + tile_n[D.shape_off + w] - 1;
             const int idx1 = last < S.n_cand - 1 ? last : S.n_cand - 1;
             int s0, s1;
@@ -1455,7 +1517,7 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     // four waves per workgroup for batches, one for a handful of egos (a single lattice then spreads over as many CUs
     // as it has tiles); 8 queues of ceil(n_inst / 8) * max_tiles tiles, `wpw` of them per workgroup
     // Fewer tiles than a quarter of the GPU's SIMDs: every tile is cut into time segments (k_evaluate_split).
-    int n_seg = tiles.n_tiles <= 256 ? SEG_MAX : tiles.n_tiles <= 512 ? 2 : 1;
+    int n_seg = tiles.n_tiles <= 2304 ? SEG_MAX : 1;       // (scripts/segment_sweep.py: four segments win up to ~64 egos)
     if (tiles.eval_segments >= 1 && tiles.eval_segments <= SEG_MAX) n_seg = tiles.eval_segments;
     static const int force_wpw = getenv("FOT_EVAL_WPW") ? atoi(getenv("FOT_EVAL_WPW")) : 0;      // diagnostics
     int wpw = n_seg > 1 ? 1 : tiles.n_tiles >= 1024 ? EVAL_WG / WAVE : 1;
@@ -1472,13 +1534,17 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_vlast = c.v_last; a.cand_travel = c.travel; a.cand_status = c.status; a.cand_keep = c.keep;
-    if (n_seg > 1)
+    if (n_seg > 1) {
         k_evaluate_split<<<(unsigned)n_blocks, n_seg * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng,
                                                                         e.e32, a);
-    else if (tiles.row_budget <= TILE_ROWS_4WAVES)                            // 16 waves share a CU's LDS (and 128 VGPRs do)
-        k_evaluate<4><<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
-    else
-        k_evaluate<3><<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
+    } else if (tiles.grouped) {                                            // one workgroup per group of tiles
+        const int per_q = (n_inst + N_XCD - 1) / N_XCD * (tiles.max_tiles / GROUP_TILES);
+        const size_t g_lds = sizeof(double) * ((size_t)eval_group_doubles() + 9 * (size_t)lds_knots);
+        k_evaluate_group<<<(unsigned)(per_q * N_XCD), GROUP_TILES * WAVE, g_lds, st>>>(P, desc, state, tiles.cand0,
+                                                                                      tiles.n, e.rng, e.e32, a);
+    } else {
+        k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
+    }
     FOT_LAUNCH_CHECK();
     return 0;
 }

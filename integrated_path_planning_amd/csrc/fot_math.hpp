@@ -325,15 +325,19 @@ FOT_HD int profile_rows(const DevParams &P, const InstDesc &D, int slot)
     return ne < P.n_total ? ne + 1 : ne;
 }
 
-// Rows one wave of k_evaluate may stage.  Two cuts: three full-length profiles and a little more (the seven
-// brake-ladder entries of the default lattice then share one tile) -- 12 waves per CU x (rows x 72 B + summaries) stay
-// below the 160 KB of LDS, three waves per SIMD; or at most TILE_ROWS_4WAVES rows (two full-length profiles), which lets
-// 16 waves share the CU's LDS: four waves per SIMD (k_evaluate then has to make do with 128 vector registers, which it
-// does).  The handle picks the cut by the number of tiles either one makes of its lattice (build_tile_shapes).
-constexpr int TILE_ROWS_4WAVES = 126;
-FOT_HD int tile_row_budget(int n_total, int profiles)
+// Two cuts of a lattice into tiles.
+//  * per-wave rows: a tile's profiles must fit the rows ONE wave stages for itself -- three full-length profiles and a
+//    little more (the seven brake-ladder entries of the default lattice then share one tile); 12 waves per CU x
+//    (rows x 72 B + summaries) stay below the 160 KB of LDS: three waves per SIMD.
+//  * groups: four consecutive tiles (one workgroup of k_evaluate) share ONE row table of GROUP_ROWS rows and
+//    GROUP_MAX_PROFILES profiles, so a tile is 64 candidates wherever the lattice has them, and four such workgroups
+//    share the CU's LDS: four waves per SIMD (k_evaluate then has to make do with 128 vector registers, which it
+//    does).  A shape's tile list is padded with empty tiles (n = 0) so that group g is tiles [4g, 4g + 4).
+// The handle picks the cut by the number of tiles either one makes of its lattice (build_tile_shapes).
+constexpr int GROUP_TILES = 4, GROUP_ROWS = 512, GROUP_MAX_PROFILES = 16;
+FOT_HD int tile_row_budget(int n_total)
 {
-    const int want = profiles * n_total + 8, cap = profiles >= 3 ? 176 : TILE_ROWS_4WAVES;
+    const int want = 3 * n_total + 8, cap = 176;
     return want < cap ? want : (cap > n_total ? cap : n_total);
 }
 
@@ -568,6 +572,18 @@ FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d,
     }
 }
 
+// sum over the polynomial samples k = 0..n_eval-1 of the squared lateral jerk, jerk(t) = 6 q3 + 24 q4 t + 60 q5 t^2,
+// t_k = k dt, in closed form (the jerk is zero on the brake padding): with c0 + c1 k + c2 k^2 it is
+// c0^2 S0 + 2 c0 c1 S1 + (c1^2 + 2 c0 c2) S2 + 2 c1 c2 S3 + c2^2 S4, S_j = sum k^j (exact integers in double).
+// The same value however the time range of a candidate is walked (one piece, or segments by different waves).
+FOT_HD double lateral_jerk_sum(const double *q, int n_eval, double dt)
+{
+    const double n = (double)n_eval, c0 = 6.0 * q[3], c1 = 24.0 * q[4] * dt, c2 = 60.0 * q[5] * dt * dt;
+    const double s1 = n * (n - 1.0) * 0.5, s2 = (n - 1.0) * n * (2.0 * n - 1.0) / 6.0, s3 = s1 * s1;
+    const double s4 = (n - 1.0) * n * (2.0 * n - 1.0) * (3.0 * n * n - 3.0 * n - 1.0) / 30.0;
+    return c0 * c0 * n + 2.0 * c0 * c1 * s1 + (c1 * c1 + 2.0 * c0 * c2) * s2 + 2.0 * c1 * c2 * s3 + c2 * c2 * s4;
+}
+
 // Sink protocol (every call site is reached with a wave-uniform k):
 //   row_begin(k), row_end(k)      once per time step, by every lane of the wave (n_loop is wave-uniform, >= n_t)
 //   put(k, circle, x, y, alive)   collision point of sample k of the kept prefix; alive == false when the candidate
@@ -606,14 +622,14 @@ struct ComputeTab {
 // (seg_merge), and a segment that starts at k0 > 0 first rebuilds sample k0 - 1 as its predecessor.
 struct SegState {
     CheckAcc acc;
-    double Jp, d_last, v_last;
+    double d_last, v_last;
     int first_nan, k_last;
 };
 
 FOT_HD void seg_init(SegState &g)
 {
     check_init(g.acc);
-    g.Jp = 0.0; g.d_last = 0.0; g.v_last = 0.0;
+    g.d_last = 0.0; g.v_last = 0.0;
     g.first_nan = -1; g.k_last = -1;
 }
 
@@ -646,7 +662,6 @@ FOT_HD void evaluate_segment(const DevParams &P, const LoopConst &C, const LonIn
       if (k < n_t) {
         double d, d_d, d_dd, d_ddd;
         lat_sample(q, k, L.n_eval, C.dt, d, d_d, d_dd, d_ddd);
-        g.Jp += d_ddd * d_ddd;
         g.d_last = d;
         CartSample c;
         frenet_to_cart(ls, d, d_d, d_dd, c);
@@ -675,7 +690,6 @@ FOT_HD void evaluate_segment(const DevParams &P, const LoopConst &C, const LonIn
 // false when g already ended the kept prefix (a NaN sample): n's checks and collision points then do not count.
 FOT_HD bool seg_merge(SegState &g, const SegState &n)
 {
-    g.Jp += n.Jp;
     g.d_last = n.d_last;
     g.acc.fl |= n.acc.fl & CK_SINGULAR;
     if (g.acc.fl & CK_SEEN_NAN) return false;
@@ -688,7 +702,7 @@ FOT_HD bool seg_merge(SegState &g, const SegState &n)
 
 template <class Tab>
 FOT_HD void finish_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
-                             const SegState &g, bool collided, CandResult &out)
+                             const double *q, const SegState &g, bool collided, CandResult &out)
 {
     const int n_t = L.n_t;
     int keep = n_t;
@@ -698,7 +712,7 @@ FOT_HD void finish_candidate(const DevParams &P, const InstDesc &D, const LonInf
     const double Jd = g.d_last * g.d_last;
     const double dv = D.target_speed - L.sd_last;
     const double Jt = (double)(n_t - 1) * P.dt;
-    const double lat = P.k_j * g.Jp + P.k_t * Jt + P.k_d * Jd;
+    const double lat = P.k_j * lateral_jerk_sum(q, L.n_eval, P.dt) + P.k_t * Jt + P.k_d * Jd;
     const double lon = P.k_j * L.Js + P.k_t * Jt + P.k_s_dot * (dv * dv);
     out.cost = P.k_lat * lat + P.k_lon * lon;
 
@@ -717,7 +731,7 @@ FOT_HD void evaluate_candidate(const DevParams &P, const InstDesc &D, const Loop
     SegState g;
     seg_init(g);
     evaluate_segment(P, C, L, lon_tab, q, 0, n_loop, sink, g);
-    finish_candidate(P, D, L, lon_tab, g, sink.collided(), out);
+    finish_candidate(P, D, L, lon_tab, q, g, sink.collided(), out);
 }
 
 // ---------------------------------------------------------------------------

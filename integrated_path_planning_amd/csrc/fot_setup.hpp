@@ -168,46 +168,94 @@ inline int build_spline(int n, const double *wx, const double *wy, HostSpline &s
 // ---------------------------------------------------------------------------
 
 // Tile table of a handle: for every terminal-speed grid size n_tv (the one thing besides the planner constants that
-// shapes an instance's lattice) the tiles tile_extent() cuts it into.  Built once per handle, resident in HBM.
+// shapes an instance's lattice) the tiles it is cut into.  Built once per handle, resident in HBM.
 struct TileShapes {
-    int row_budget = 0;
+    int row_budget = 0;                            // rows a wave that stages one tile on its own needs at most
+    int grouped = 0;                               // 1: groups of GROUP_TILES tiles share a row table (fot_math.hpp)
+    int64_t n_real = 0;                            // tiles with candidates, over all shapes (cost of the cut)
     std::vector<int32_t> cand0, n;                 // all shapes back to back
     int32_t off[FOT_MAX_TV + 2] = { 0 };           // shape of n_tv: entries [off[n_tv], off[n_tv + 1])
     int tiles_of(int n_tv) const { return off[n_tv + 1] - off[n_tv]; }
 };
 
-inline void build_tile_shapes(const DevParams &P, TileShapes &T, int row_budget)
+inline InstDesc shape_desc(const DevParams &P, int n_tv)
+{
+    InstDesc D = InstDesc();
+    D.n_tv = n_tv;
+    D.n_grid = P.n_ti * n_tv * P.n_di;
+    D.n_cand_max = D.n_grid + P.n_brake;
+    return D;
+}
+
+// per-wave rows: every tile fits row_budget rows
+inline void build_tile_shapes_wave(const DevParams &P, TileShapes &T)
 {
     T = TileShapes();
-    T.row_budget = row_budget;
+    T.row_budget = tile_row_budget(P.n_total);
     for (int n_tv = 0; n_tv <= FOT_MAX_TV; ++n_tv) {
         T.off[n_tv] = (int32_t)T.cand0.size();
-        InstDesc D = InstDesc();
-        D.n_tv = n_tv;
-        D.n_grid = P.n_ti * n_tv * P.n_di;
-        D.n_cand_max = D.n_grid + P.n_brake;
         if (n_tv == 0) continue;
+        const InstDesc D = shape_desc(P, n_tv);
         for (int c = 0; c < D.n_cand_max;) {
             const int n = tile_extent(P, D, c, T.row_budget);
             T.cand0.push_back(c); T.n.push_back(n);
-            c += n;
+            c += n; ++T.n_real;
         }
     }
     T.off[FOT_MAX_TV + 1] = (int32_t)T.cand0.size();
 }
 
-// The cut of the handle's lattice: two-profile tiles (four waves per SIMD in k_evaluate) unless they make over 15 %
-// more tiles than three-profile ones -- a lattice with few lateral offsets fills the 64 lanes of a tile badly either
-// way, and worse with two profiles (measured on the 29-offset lattice: 11 % more tiles, 6 % less time).
-// FOT_TILE_PROFILES=2|3 in the environment forces the cut (diagnostics).
+// groups: greedy -- a group takes profiles while their rows fit GROUP_ROWS (and GROUP_MAX_PROFILES), its tiles take 64
+// candidates each out of those profiles (at most TILE_MAX_PROFILES per tile: k_cull merges that many boxes per tile)
+inline void build_tile_shapes_grouped(const DevParams &P, TileShapes &T)
+{
+    T = TileShapes();
+    T.grouped = 1;
+    for (int n_tv = 0; n_tv <= FOT_MAX_TV; ++n_tv) {
+        T.off[n_tv] = (int32_t)T.cand0.size();
+        if (n_tv == 0) continue;
+        const InstDesc D = shape_desc(P, n_tv);
+        const int n_grid_lon = P.n_ti * D.n_tv;
+        int c = 0;
+        while (c < D.n_cand_max) {
+            int rows = 0, profs = 0, last_slot = -1;          // of the group so far
+            for (int t = 0; t < GROUP_TILES; ++t) {
+                const int c0 = c;
+                int n = 0, tile_profs = 0, tile_rows = 0;
+                while (n < WAVE && c < D.n_cand_max && tile_profs < TILE_MAX_PROFILES) {
+                    int slot, left;                           // profile of candidate c, candidates of it from c on
+                    if (c < D.n_grid) { slot = c / P.n_di; left = (slot + 1) * P.n_di - c; }
+                    else { slot = n_grid_lon + (c - D.n_grid); left = 1; }
+                    const int r = profile_rows(P, D, slot);
+                    if (slot != last_slot) {                  // a profile the group does not hold yet
+                        if (profs > 0 && (rows + r > GROUP_ROWS || profs + 1 > GROUP_MAX_PROFILES)) break;
+                        rows += r; ++profs; last_slot = slot;
+                    }
+                    ++tile_profs; tile_rows += r;
+                    const int take = left < WAVE - n ? left : WAVE - n;
+                    n += take; c += take;
+                }
+                T.cand0.push_back(c0); T.n.push_back(n);
+                if (n > 0) ++T.n_real;
+                if (tile_rows > T.row_budget) T.row_budget = tile_rows;
+            }
+        }
+    }
+    T.off[FOT_MAX_TV + 1] = (int32_t)T.cand0.size();
+}
+
+// The cut of the handle's lattice: groups (four waves per SIMD in k_evaluate) unless they make over 15 % more tiles
+// than the per-wave cut -- with few lateral offsets per profile a tile fills its 64 lanes badly either way, and a
+// group's sixteen profiles may then hold fewer candidates than four per-wave tiles.  FOT_TILE_CUT=wave|group in the
+// environment forces the cut (diagnostics).
 inline void build_tile_shapes(const DevParams &P, TileShapes &T)
 {
-    TileShapes two, three;
-    build_tile_shapes(P, two, tile_row_budget(P.n_total, 2));
-    build_tile_shapes(P, three, tile_row_budget(P.n_total, 3));
-    bool use_two = two.row_budget <= TILE_ROWS_4WAVES && (double)two.cand0.size() <= 1.15 * (double)three.cand0.size();
-    if (const char *e = getenv("FOT_TILE_PROFILES")) use_two = atoi(e) == 2 && two.row_budget <= TILE_ROWS_4WAVES;
-    T = use_two ? two : three;
+    TileShapes wave, grouped;
+    build_tile_shapes_wave(P, wave);
+    build_tile_shapes_grouped(P, grouped);
+    bool use_groups = (double)grouped.n_real <= 1.15 * (double)wave.n_real;
+    if (const char *e = getenv("FOT_TILE_CUT")) use_groups = e[0] == 'g';
+    T = use_groups ? grouped : wave;
 }
 
 struct BatchLayout {
@@ -216,6 +264,7 @@ struct BatchLayout {
     int n_tiles = 0;              // tiles of the whole batch (k_evaluate's units of work: one wave each)
     int max_tiles = 0;            // most tiles of one instance
     int row_budget = 0;           // LDS rows per k_evaluate wave the tiles were cut for
+    int grouped = 0;              // the tile table's cut (TileShapes::grouped)
     int64_t n_slots = 0;          // candidate slots (instances padded to multiples of 64)
     int64_t n_lon = 0;            // longitudinal profile slots
     int max_lon = 0;              // max profiles of one instance
@@ -235,6 +284,7 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const Ti
     L.n_inst = b.n_inst;
     L.desc.resize(b.n_inst);
     L.row_budget = shapes.row_budget;
+    L.grouped = shapes.grouped;
     for (int i = 0; i < b.n_inst; ++i) {
         InstDesc &D = L.desc[i];
         D = InstDesc();

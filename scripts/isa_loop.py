@@ -14,7 +14,8 @@ def children(i):
     return n
 # the time-step loop: the innermost loop header that still has five or more child loops (chunk walks, re-checks)
 heads = [(int(re.search(r'Depth=(\d+)', l).group(1)), i) for i, l in enumerate(body) if 'Loop Header: Depth=' in l and children(i) >= 5]
-start = max(heads)[1]
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -1           # several time-step loops in one kernel: which one
+start = sorted(h for h in heads if h[0] == max(heads)[0])[which][1]
 while not re.match(r'\.LBB\d+_\d+:', body[start]):       # (the label sits a few comment lines above a nested header)
     start -= 1
 label = body[start].split(':')[0]

@@ -16,7 +16,7 @@ from integrated_path_planning_amd import _abi, synthetic as syn            # noq
 from integrated_path_planning_amd.batch import PackedBatch                 # noqa: E402
 from integrated_path_planning_amd.planner import BatchPlanner              # noqa: E402
 
-N_INST, WPB, SLOTS = 256, int(os.environ.get("FOT_TIMELINE_WPB", "4")), 3072                       # 256 CUs x 4 SIMDs x 3 waves (VGPR-limited)
+N_INST, WPB, SLOTS = 256, int(os.environ.get("FOT_TIMELINE_WPB", "4")), int(os.environ.get("FOT_TIMELINE_SLOTS", "4096"))                       # 256 CUs x 4 SIMDs x 3 waves (VGPR-limited)
 
 
 def list_schedule(durations, slots):

@@ -144,19 +144,34 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         std::vector<uint8_t> sid(cap * P.n_total + 16, SID_STATIC);
         // tiles of the instance (k_evaluate's units of work): the walk the host and k_frenet_state do
         std::vector<int> tile_c0, tile_n, tile_of((size_t)std::max(D.n_cand_max, 1), -1);
-        for (int c = 0; c < D.n_cand_max;) {
-            const int n = tile_extent(P, D, c, L.row_budget);
-            if (n < 1 || n > WAVE) return -102;
-            int s0, s1, rows = 0;                                         // the tile's profiles fit the wave's LDS rows
-            wave_profile_span(P, D, n_grid_lon, c, c + n - 1, s0, s1);
-            if (s1 - s0 + 1 > TILE_MAX_PROFILES) return -103;
-            for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
-            if (rows > L.row_budget && s1 > s0) return -104;
-            for (int i = c; i < c + n; ++i) tile_of[(size_t)i] = (int)tile_c0.size();
-            if (shapes.cand0[(size_t)D.shape_off + tile_c0.size()] != c || shapes.n[(size_t)D.shape_off + tile_c0.size()] != n)
-                return -106;                                              // the handle's table holds this very walk
+        // the handle's table (either cut, padding tiles of the grouped cut included): consecutive, complete, within
+        // the limits the kernels rely on
+        for (int t = 0, c = 0; t < shapes.tiles_of(D.n_tv); ++t) {
+            const int c0 = shapes.cand0[(size_t)D.shape_off + t], n = shapes.n[(size_t)D.shape_off + t];
+            if (c0 != c || n < 0 || n > WAVE || (n == 0 && !shapes.grouped)) return -102;
+            if (n > 0) {
+                int s0, s1, rows = 0;
+                wave_profile_span(P, D, n_grid_lon, c, c + n - 1, s0, s1);
+                if (s1 - s0 + 1 > TILE_MAX_PROFILES) return -103;
+                for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
+                if (rows > L.row_budget && s1 > s0) return -104;          // what a wave staging the tile alone needs
+                if (!shapes.grouped && tile_extent(P, D, c, L.row_budget) != n) return -106;
+                for (int i = c; i < c + n; ++i) tile_of[(size_t)i] = t;
+            }
             tile_c0.push_back(c); tile_n.push_back(n);
             c += n;
+            if (t == shapes.tiles_of(D.n_tv) - 1 && c != D.n_cand_max) return -108;    // every candidate in some tile
+        }
+        if (shapes.grouped) {                                             // a group's profiles fit its shared table
+            if (shapes.tiles_of(D.n_tv) % GROUP_TILES) return -109;
+            for (int g0 = 0; g0 < (int)tile_c0.size(); g0 += GROUP_TILES) {
+                const int c0 = tile_c0[(size_t)g0], c1 = tile_c0[(size_t)g0 + GROUP_TILES - 1] + tile_n[(size_t)g0 + GROUP_TILES - 1];
+                if (c1 <= c0) return -109;
+                int s0, s1, rows = 0;
+                wave_profile_span(P, D, n_grid_lon, c0, c1 - 1, s0, s1);
+                for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
+                if (s1 - s0 + 1 > GROUP_MAX_PROFILES || (rows > GROUP_ROWS && s1 > s0)) return -109;
+            }
         }
         if ((int)tile_c0.size() != D.n_tiles) return -105;                // what build_batch_layout counted
         const int n_tiles_inst = (int)tile_c0.size();
@@ -197,7 +212,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 const int count = (int)ents.size();
                 cnt[k] = (count + 2 * ENT_CHUNK - 1) & ~(2 * ENT_CHUNK - 1);
                 for (int w = 0; w < n_tiles_inst; ++w) {
-                    if (tile_c0[w] >= S.n_cand) continue;
+                    if (tile_c0[w] >= S.n_cand || tile_n[w] == 0) continue;
                     int s0, s1;
                     wave_profile_span(P, D, n_grid_lon, tile_c0[w], std::min(tile_c0[w] + tile_n[w] - 1, S.n_cand - 1), s0, s1);
                     Box32 wb = box_empty();
@@ -281,13 +296,11 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 for (uint64_t m = hit_mask; m; m &= m - 1) ++pc;
                 hit |= pc > D.max_viol;
                 CandResult rs;
-                finish_candidate(P, D, Li, GlobalTab{ tab }, g, hit, rs);
+                finish_candidate(P, D, Li, GlobalTab{ tab }, q, g, hit, rs);
                 if (rs.status != r.status || rs.keep != r.keep) return -110;
                 if (std::memcmp(&rs.v_last, &r.v_last, sizeof(double)) || std::memcmp(&rs.travel, &r.travel, sizeof(double)))
                     return -111;
-                if (!(std::fabs(rs.cost - r.cost) <= 1e-12 * std::fabs(r.cost)) && !(std::isnan(rs.cost) && std::isnan(r.cost))
-                    && rs.cost != r.cost)
-                    return -112;
+                if (std::memcmp(&rs.cost, &r.cost, sizeof(double))) return -112;     // (the jerk sums are closed forms)
             }
             int st = r.status;
             st = final_status(st, r.v_last, r.travel, D.max_stop);
