@@ -816,14 +816,7 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
                  const f2 *__restrict__ ent32, const EvalKernArgs a)
 {
     // LDS: [rows | summaries | row offsets] of the group, then the spline
-#ifdef FOT_TIMELINE
-    if (threadIdx.x == 0) s_tl_entry[0] = __builtin_amdgcn_s_memrealtime();
-#endif
     const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_lon + eval_group_doubles());
-#ifdef FOT_TIMELINE
-    if (threadIdx.x == 0) s_tl_entry[1] = __builtin_amdgcn_s_memrealtime();
-    __syncthreads();
-#endif
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int lane = threadIdx.x & (WAVE - 1);
     const int x = (int)blockIdx.x & (N_XCD - 1), q = (int)blockIdx.x >> 3;
