@@ -94,10 +94,15 @@ typedef struct fot_ego {
     int32_t has_prev_s;          /* 0: first call (global nearest-point search); 1: prev_s valid;
                                     2 (FOT_PREV_S_CHAINED): prev_s := new_prev_s of the PREVIOUS instance of the
                                     batch, i.e. this instance is the next plan() call on the same planner object
-                                    (the escalation retries of integrated_simulator.py:602-644 in one launch) */
+                                    (the escalation retries of integrated_simulator.py:602-644 in one launch);
+                                    3 (FOT_EGO_IS_FRENET): the record IS a Frenet state -- x, y, yaw, v, a, last_kappa
+                                    hold s, s_d, s_dd, d, d_d, d_dd -- and the lattice is generated from it as given
+                                    (what the reference's tests do through _generate_frenet_paths(FrenetState, ...),
+                                    frenet_planner.py:376); no nearest-point search, new_prev_s comes back NaN */
     int32_t _pad;
 } fot_ego;
 #define FOT_PREV_S_CHAINED 2
+#define FOT_EGO_IS_FRENET 3
 
 /* replaces constraint_overrides (frenet_planner.py:921-930); NaN = key absent */
 typedef struct fot_overrides {

@@ -27,6 +27,7 @@ class PlanRequest:
     last_kappa: float = 0.0
     prev_s: Optional[float] = None
     chain_prev_s: bool = False                   # prev_s := new_prev_s of the previous request (next call on the same planner)
+    is_frenet: bool = False                      # x, y, yaw, v, a, last_kappa hold s, s_d, s_dd, d, d_d, d_dd (FOT_EGO_IS_FRENET)
     overrides: Optional[dict] = None
     max_stop_distance: Optional[float] = None
     static: Optional[np.ndarray] = None          # [Ns, 2]
@@ -94,7 +95,9 @@ class PackedBatch:
             e = self.ego[i]
             e.x, e.y, e.yaw, e.v, e.a = float(r.x), float(r.y), float(r.yaw), float(r.v), float(r.a)
             e.last_kappa = float(r.last_kappa)
-            if r.chain_prev_s:
+            if r.is_frenet:
+                e.has_prev_s, e.prev_s = _abi.EGO_IS_FRENET, 0.0
+            elif r.chain_prev_s:
                 if i == 0:
                     raise ValueError("the first request of a batch cannot chain its nearest-point cache")
                 e.has_prev_s, e.prev_s = 2, 0.0

@@ -203,7 +203,9 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
 
         double best_s = 0.0;
         bool need_global = true;
-        if (has_prev) {                                        // cached window +-10 m, 100 samples
+        const bool given = D.ego.has_prev_s == FOT_EGO_IS_FRENET;  // the Frenet state itself: nothing to search
+        if (given) need_global = false;
+        if (has_prev && !given) {                              // cached window +-10 m, 100 samples
             const double s_min = fmax(0.0, prev_s - 10.0);
             const double s_max = fmin(s_end, prev_s + 10.0);
             ScanBest b = block_argmin(scan_samples(sp, x, y, s_min, s_max, 100, tid, FRENET_WG, false), s_best);
@@ -216,12 +218,12 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
             ScanBest b = block_argmin(scan_samples(sp, x, y, 0.0, s_end, n_glob, tid, FRENET_WG, true), s_best);
             best_s = linspace_at(0.0, s_end, n_glob, b.idx >= 0 ? b.idx : 0);
         }
-        best_s = refine_nearest_wave(sp, x, y, best_s, lane);
-        const double new_prev_s = best_s;
+        if (!given) best_s = refine_nearest_wave(sp, x, y, best_s, lane);
+        const double new_prev_s = given ? NAN : best_s;
 
         double fr[6], ref[6];
-        bool ok = frenet_state_at(sp, D.ego, best_s, fr, ref);
-        if (!ok) {
+        bool ok = given ? frenet_state_given(sp, D.ego, fr, ref) : frenet_state_at(sp, D.ego, best_s, fr, ref);
+        if (!ok && !given) {
             double px, py;
             spline_xy(sp, best_s, px, py);
             if (isnan(px) || isnan(py)) {                     // coordinate_converter.py:289-295

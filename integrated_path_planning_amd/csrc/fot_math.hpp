@@ -218,6 +218,19 @@ FOT_HD bool frenet_state_at(const SplineView &sp, const fot_ego &ego, double rs,
     return true;
 }
 
+// FOT_EGO_IS_FRENET: the record holds s, s_d, s_dd, d, d_d, d_dd; the reference point is the spline frame at s
+FOT_HD bool frenet_state_given(const SplineView &sp, const fot_ego &ego, double *fr, double *ref)
+{
+    fr[0] = ego.x; fr[1] = ego.y; fr[2] = ego.yaw; fr[3] = ego.v; fr[4] = ego.a; fr[5] = ego.last_kappa;
+    SplinePt p;
+    spline_point(sp, fr[0], p);
+    if (isnan(p.x) || isnan(p.y)) return false;
+    double cos_r, sin_r, rkappa, rdkappa;
+    spline_frame(p, cos_r, sin_r, rkappa, rdkappa);
+    ref[0] = fr[0]; ref[1] = p.x; ref[2] = p.y; ref[3] = atan2(p.dy, p.dx); ref[4] = rkappa; ref[5] = rdkappa;
+    return !(isnan(ref[3]) || isnan(rkappa) || isnan(rdkappa));
+}
+
 // ---------------------------------------------------------------------------
 // lattice polynomials (reference: frenet_planner.py:586-701)
 // ---------------------------------------------------------------------------

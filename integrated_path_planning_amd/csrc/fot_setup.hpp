@@ -289,7 +289,7 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const Ti
         InstDesc &D = L.desc[i];
         D = InstDesc();
         D.ego = b.ego[i];
-        if (D.ego.has_prev_s < 0 || D.ego.has_prev_s > FOT_PREV_S_CHAINED) { err = "has_prev_s must be 0, 1 or 2"; return FOT_ERR_INVALID; }
+        if (D.ego.has_prev_s < 0 || D.ego.has_prev_s > FOT_EGO_IS_FRENET) { err = "has_prev_s must be 0 .. 3"; return FOT_ERR_INVALID; }
         if (i == 0 && D.ego.has_prev_s == FOT_PREV_S_CHAINED) { err = "the first instance cannot be chained"; return FOT_ERR_INVALID; }
         const double target = b.target_speed[i];
         D.target_speed = target;

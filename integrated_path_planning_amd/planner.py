@@ -567,6 +567,98 @@ class FrenetPlanner:
                 out[_abi.STATUS_NAMES[st]].append(fp)
         return out
 
+    # The generation / conversion stages as separate calls (frenet_planner.py:376-503, 736-889).  libfot generates,
+    # converts and checks a candidate in one pass over registers; these views re-run the lattice from the GIVEN Frenet
+    # state (FOT_EGO_IS_FRENET) and read the candidates back through the debug entries -- what the reference's tests
+    # look at, not a path plan() takes.
+    _FRENET_FIELDS = ("t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd")
+    _CART_FIELDS = ("x", "y", "yaw", "v", "a", "c")
+
+    def _lattice_from(self, frenet_state, target_speed):
+        fs = frenet_state
+        req = PlanRequest(float(fs.s), float(fs.s_d), float(fs.s_dd), float(fs.d), float(fs.d_d),
+                          target_speed=float(target_speed), last_kappa=float(fs.d_dd), is_frenet=True)
+        self._engine.plan_batch([req])
+        cost, _status, keep, _nt = self._engine.candidates(0)
+        return cost, keep
+
+    def _generate_frenet_paths(self, frenet_state, target_speed: float) -> List[FrenetPath]:
+        """Every candidate of the lattice (grid, then the brake ladder) with its Frenet arrays and cost
+        (frenet_planner.py:376-451); the Cartesian arrays are filled in by ``_calc_global_paths``."""
+        cost, keep = self._lattice_from(frenet_state, target_speed)
+        paths = []
+        for i in range(len(cost)):
+            full = self._engine.candidate_path(i)
+            fp = FrenetPath(**{f: getattr(full, f) for f in self._FRENET_FIELDS})
+            fp.cost = float(cost[i])
+            fp.__dict__["_fot_global"] = ({f: getattr(full, f) for f in self._CART_FIELDS}, int(keep[i]))
+            paths.append(fp)
+        return paths
+
+    def _generate_brake_candidates(self, frenet_state, target_speed: float) -> List[FrenetPath]:
+        """The brake-ladder candidates alone (frenet_planner.py:453-503): the tail of the generation order; none
+        below BRAKE_MIN_SPEED."""
+        standing = FrenetState(frenet_state.s, 0.0, frenet_state.s_dd, frenet_state.d, frenet_state.d_d,
+                               frenet_state.d_dd)
+        n_grid = len(self._lattice_from(standing, target_speed)[0])          # (no ladder from a standing start)
+        return self._generate_frenet_paths(frenet_state, target_speed)[n_grid:]
+
+    def _calc_global_paths(self, fp_list: List[FrenetPath]) -> List[FrenetPath]:
+        """Cartesian arrays of candidates made by ``_generate_frenet_paths``, cut to the valid prefix in lockstep
+        with the Frenet arrays (frenet_planner.py:736-889: out-of-domain tail dropped, fewer than two samples or a
+        singular point empty the path)."""
+        for fp in fp_list:
+            cart, keep = fp.__dict__["_fot_global"]
+            for f in self._CART_FIELDS:
+                setattr(fp, f, list(cart[f][:keep]))
+            for f in self._FRENET_FIELDS:
+                setattr(fp, f, list(getattr(fp, f)[:keep]))
+        return fp_list
+
+    def _path_collision_geometry(self, fp, dynamic_margin_inflation: float = 1.0):
+        """(path_points, path_t, path_min, path_max, sq_rubicon, sq_rubicon_dyn) as the reference's tests read them
+        (frenet_planner.py:1126-1179): one point per footprint circle and sample, the squared radii, the box.  A view
+        for tests -- the kernels derive these points in registers."""
+        n = min(len(fp.x), len(fp.t))
+        if len(fp.x) == 0:
+            return None
+        pts = np.stack([np.asarray(fp.x[:n], float), np.asarray(fp.y[:n], float)], axis=1)
+        t = np.asarray(fp.t[:n], float)
+        radius = self.robot_radius
+        if self.footprint is not None:
+            radius = self.footprint.radius
+            yaw = np.asarray(fp.yaw[:n], float)
+            if len(yaw) < n:
+                yaw = np.concatenate([yaw, np.full(n - len(yaw), yaw[-1] if len(yaw) else 0.0)])
+            heading = np.stack([np.cos(yaw), np.sin(yaw)], axis=1)
+            off = np.asarray(self.footprint.offsets, float)
+            pts = (pts[None] + off[:, None, None] * heading[None]).reshape(-1, 2)
+            t = np.tile(t, len(off))
+        r_static = max(radius + self.obstacle_radius, 1e-6)
+        r_dyn = r_static * dynamic_margin_inflation
+        grow = max(r_static, r_dyn)
+        return pts, t, pts.min(axis=0) - grow, pts.max(axis=0) + grow, r_static ** 2, r_dyn ** 2
+
+    @staticmethod
+    def _apply_stop_distance_filter(fp_dict: dict, max_stop_distance: float) -> None:
+        """frenet_planner.py:307-324 on a categorised dict: 'ok' paths that do not come to rest within the travel
+        move to 'stop_distance_error'."""
+        ok, late = [], []
+        for fp in fp_dict["ok"]:
+            at_rest = len(fp.v) > 0 and abs(fp.v[-1]) <= 0.15                # STOP_SPEED_EPS
+            travel = float(fp.s[-1] - fp.s[0]) if len(fp.s) > 0 else 0.0
+            (ok if at_rest and travel <= max_stop_distance + 1e-6 else late).append(fp)
+        fp_dict["ok"], fp_dict["stop_distance_error"] = ok, late
+
+    @staticmethod
+    def _select_best_path(path_dict: dict) -> Optional[FrenetPath]:
+        """First minimum-cost entry of 'ok' (frenet_planner.py:1235-1259)."""
+        best, best_cost = None, float("inf")
+        for fp in path_dict["ok"]:
+            if fp.cost < best_cost:
+                best, best_cost = fp, fp.cost
+        return best
+
     def candidate_table(self):
         """(cost, status, keep, n_t) per candidate of the last plan() call (diagnostic)."""
         return self._engine.candidates(0)

@@ -64,7 +64,9 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         bool need_global = true;
         const bool chained = D.ego.has_prev_s == FOT_PREV_S_CHAINED;
         const double prev_s_in = chained ? out[inst - 1].new_prev_s : D.ego.prev_s;
-        if (D.ego.has_prev_s) {
+        const bool given = D.ego.has_prev_s == FOT_EGO_IS_FRENET;
+        if (given) need_global = false;
+        if (D.ego.has_prev_s && !given) {
             const double s_min = fmax(0.0, prev_s_in - 10.0), s_max = fmin(s_end, prev_s_in + 10.0);
             ScanBest bb = scan_samples(sp, x, y, s_min, s_max, 100, 0, 1, false);
             best_s = bb.idx >= 0 ? linspace_at(s_min, s_max, 100, bb.idx) : 0.0;
@@ -75,9 +77,9 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
             ScanBest bb = scan_samples(sp, x, y, 0.0, s_end, n_glob, 0, 1, true);
             best_s = linspace_at(0.0, s_end, n_glob, bb.idx >= 0 ? bb.idx : 0);
         }
-        best_s = refine_nearest(sp, x, y, best_s);
-        S.new_prev_s = best_s;
-        bool ok = frenet_state_at(sp, D.ego, best_s, S.frenet0, S.ref0);
+        if (!given) best_s = refine_nearest(sp, x, y, best_s);
+        S.new_prev_s = given ? NAN : best_s;
+        bool ok = given ? frenet_state_given(sp, D.ego, S.frenet0, S.ref0) : frenet_state_at(sp, D.ego, best_s, S.frenet0, S.ref0);
         S.c2f_ok = ok;
         S.n_brake = (ok && S.frenet0[1] > 0.1) ? P.n_brake : 0;
         S.n_cand = ok ? D.n_grid + S.n_brake : 0;

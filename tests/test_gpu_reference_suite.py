@@ -504,3 +504,66 @@ def test_spline_domain_and_nearest_point_at_ends():                          # t
     assert fs is not None and abs(fs.s) < 1e-6
     fs = pl._cartesian_to_frenet_state(EgoVehicleState(x=25.0, y=-1.0, yaw=0.0, v=1.0, a=0.0))
     assert fs is not None and abs(fs.s - 20.0) < 1e-6
+
+
+# ---------------------------------------------------------------- the stages as separate calls
+# (what the reference's tests do with FrenetState(...) objects: frenet_planner.py:376, :453, :736, :1126, :1235)
+
+def test_stage_views_reproduce_the_plan_call():
+    """_generate_frenet_paths(FrenetState) + _calc_global_paths from the Frenet state of a plan() call give that
+    call's candidates: same arrays (generated from the given state, no nearest-point search in between), same valid
+    prefixes."""
+    pl = make_brake_planner()
+    ego = EgoVehicleState(x=62.0, y=0.4, yaw=0.03, v=6.0, a=0.2)                # some candidates run past the 80 m path
+    pl.plan(ego, NO_OBS, target_speed=5.0)
+    cost, _status, keep, nt = pl.candidate_table()
+    ref = [pl.engine.candidate_path(i) for i in (0, 7, len(cost) // 2, len(cost) - 8, len(cost) - 1)]
+    pick = (0, 7, len(cost) // 2, len(cost) - 8, len(cost) - 1)
+    fs = make_brake_planner()._cartesian_to_frenet_state(ego)                  # (a fresh planner: no curvature / nearest-point cache, like the plan() above)
+    paths = pl._generate_frenet_paths(fs, 5.0)
+    assert len(paths) == len(cost)
+    np.testing.assert_allclose([p.cost for p in paths], cost, rtol=1e-12)
+    assert all(len(p.x) == 0 for p in paths)                                    # Frenet arrays only, so far
+    for i, want in zip(pick, ref):
+        for f in ("t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd"):
+            np.testing.assert_allclose(getattr(paths[i], f), getattr(want, f), rtol=0, atol=1e-12, err_msg=f"{i} {f}")
+    pl._calc_global_paths(paths)
+    assert [len(p.x) for p in paths] == keep.tolist()
+    assert (keep < nt).any() and (keep == nt).any()                             # truncated ones among them
+    for p in paths:                                                             # every array in lockstep (:853-871)
+        assert len({len(getattr(p, f)) for f in ("t", "s", "d", "x", "y", "yaw", "v", "a", "c")}) == 1
+    for i, want in zip(pick, ref):
+        k = int(keep[i])
+        for f in ("x", "y", "yaw", "v", "a", "c"):
+            np.testing.assert_allclose(getattr(paths[i], f), getattr(want, f)[:k], rtol=0, atol=1e-9, err_msg=f"{i} {f}")
+
+
+def test_stage_view_brake_candidates():                                      # tests/test_smooth_braking.py:33-62
+    from integrated_path_planning_amd.data_structures import FrenetState
+    pl = make_brake_planner()
+    ladder = pl._generate_brake_candidates(FrenetState(5.0, 5.0, 0.0, 0.5, 0.0, 0.0), 5.0)
+    assert len(ladder) == len(np.arange(0.5, pl.min_t - 1e-9, 0.5))
+    for fp in ladder:
+        assert fp.t[-1] == pytest.approx(pl.max_t) and fp.s_d[-1] == pytest.approx(0.0, abs=1e-9)
+        assert fp.d[-1] == pytest.approx(0.5, abs=1e-9)
+    assert pl._generate_brake_candidates(FrenetState(5.0, 0.05, 0.0, 0.5, 0.0, 0.0), 5.0) == []
+
+
+def test_stage_view_collision_geometry_and_selection():                     # tests/test_footprint.py:105-119
+    fp3 = EgoFootprint.multi_circle(4.5, 1.8, 3)
+    pl = make_straight_planner(footprint=fp3, collision_margin_inflation=1.2)
+    path = FrenetPath(t=[0.0, 0.1, 0.2], x=[0.0, 1.0, 2.0], y=[0.0, 0.0, 0.0], yaw=[0.0, 0.0])   # yaw one short: padded
+    pts, t, lo, hi, sq, sq_dyn = pl._path_collision_geometry(path, dynamic_margin_inflation=1.2)
+    assert pts.shape == (9, 2) and t.shape == (9,)
+    np.testing.assert_allclose(sorted(set(np.round(pts[:, 0] - np.tile([0.0, 1.0, 2.0], 3), 9))), sorted(fp3.offsets))
+    assert sq == pytest.approx((fp3.radius + pl.obstacle_radius) ** 2) and sq_dyn == pytest.approx(sq * 1.44)
+    assert lo[0] == pytest.approx(pts[:, 0].min() - 1.2 * (fp3.radius + pl.obstacle_radius))
+    assert pl._path_collision_geometry(FrenetPath()) is None
+    a, b, c = FrenetPath(cost=3.0), FrenetPath(cost=1.0), FrenetPath(cost=1.0)
+    assert pl._select_best_path({"ok": [a, b, c]}) is b and pl._select_best_path({"ok": []}) is None
+    stop = FrenetPath(s=[0.0, 1.0, 2.0], v=[2.0, 1.0, 0.0], cost=5.0)
+    roll = FrenetPath(s=[0.0, 2.0, 4.0], v=[2.0, 2.0, 2.0], cost=1.0)
+    far = FrenetPath(s=[0.0, 4.0, 9.0], v=[3.0, 1.0, 0.0], cost=2.0)
+    d = {"ok": [roll, stop, far]}
+    pl._apply_stop_distance_filter(d, 3.0)
+    assert d["ok"] == [stop] and d["stop_distance_error"] == [roll, far]
