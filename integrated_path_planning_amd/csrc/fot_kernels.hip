@@ -903,17 +903,16 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     constexpr int STRIDE = WAVE;                                  // obstacles between two of a lane's loads
     const int row_l = k0 + kl < D.T - 1 ? k0 + kl : D.T - 1;
     struct Raw { T x, y; };                                       // as stored: widened only when it is classified
+    // Branch-free: an index past the end is clamped (classify() ignores its value) and static / dynamic is a select
+    // between two addresses, so the UNROLL loads of a lane are issued back to back -- behind a branch each one would
+    // wait for the one before it, one gather in flight per lane, and the pass would crawl along at memory latency.
     auto fetch = [&](int i, Raw &o) {
-        o.x = (T)0; o.y = (T)0;
-        if (i >= total) return;
-        if (i < D.n_static) {
-            const int64_t in = D.static_off + i;
-            o.x = static_xy[2 * in]; o.y = static_xy[2 * in + 1];
-        } else {
-            const int j = i - D.n_static;                         // = s * P + p
-            const int64_t in = D.dyn_off + (tmajor ? (int64_t)row_l * n_dyn + j : (int64_t)j * D.T + row_l);
-            o.x = dyn_xy[2 * in]; o.y = dyn_xy[2 * in + 1];
-        }
+        const int ic = i < total ? i : total - 1;                 // (total > 0 inside the loop)
+        const int j = ic - D.n_static;                            // = s * P + p when dynamic
+        const T *ps = static_xy + 2 * ((int64_t)D.static_off + ic);
+        const T *pd = dyn_xy + 2 * (D.dyn_off + (tmajor ? (int64_t)row_l * n_dyn + j : (int64_t)j * D.T + row_l));
+        const Raw *src = (const Raw *)(ic < D.n_static ? ps : pd);
+        o = *src;
     };
     // wave wv: box of time step k0 + wv over all longitudinal profiles of the instance
     {
