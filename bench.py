@@ -354,8 +354,17 @@ def main():
             return None, False
         return d, d.get("_meta", {}).get("source_hash") == src_hash
 
+    def of_kernel(d, name):
+        """entry of the profiled kernel that ran in slot `name` (the evaluation slot has variants: k_evaluate,
+        k_evaluate_group, k_evaluate_split -- the profile of this very workload holds the one that ran)"""
+        if not d:
+            return {}, None
+        keys = [name] + sorted(k for k in d if k.startswith(name + "_"))
+        hit = max((k for k in keys if k in d), key=lambda k: float(d[k].get("SQ_INSTS_VALU", d[k].get("hbm_bytes_gfx950_corrected", 0.0))), default=None)
+        return (d[hit], hit) if hit else ({}, None)
+
     traffic_d, traffic_fresh = committed("traffic.json")
-    traffic = (traffic_d or {}).get(dom, {}).get("hbm_bytes_gfx950_corrected") if traffic_fresh else None
+    traffic = of_kernel(traffic_d, dom)[0].get("hbm_bytes_gfx950_corrected") if traffic_fresh else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
                 "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -373,12 +382,14 @@ def main():
     # alone would take at one wave64 instruction per 4 cycles per SIMD, against the measured launch time
     issue = None
     pmc_d, pmc_fresh = committed("pmc.json")
-    if pmc_d and dom in pmc_d and "SQ_INSTS_VALU" in pmc_d[dom]:
-        n_valu = float(pmc_d[dom]["SQ_INSTS_VALU"])
+    pmc_k, pmc_name = of_kernel(pmc_d, dom)
+    if "SQ_INSTS_VALU" in pmc_k:
+        n_valu = float(pmc_k["SQ_INSTS_VALU"])
         issue_ms = n_valu * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
         issue = {"kernel": dom, "bound": "valu_issue", "unit": "ms", "achieved": issue_ms, "peak": dom_ms,
                  "frac": issue_ms / dom_ms, "valu_instructions_per_launch": n_valu, "cycles_per_instruction": 4,
                  "simds": N_SIMD, "clock_ghz": CLOCK_HZ / 1e9,
+                 "profiled_kernel": pmc_name,
                  "source": "profiles/pmc.json" + (" (%s)" % pmc_d.get("_meta", {}).get("tag", "?")),
                  "source_matches_build": pmc_fresh,
                  "note": "executed VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over the measured launch "

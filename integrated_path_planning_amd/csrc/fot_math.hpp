@@ -524,6 +524,20 @@ FOT_HD void check_init(CheckAcc &c)
 
 FOT_HD void check_flag(CheckAcc &c, bool cond, uint32_t bit) { c.fl |= cond ? bit : 0u; }
 
+// |atan2(sn, cs)| > max(lim_curv * sqrt(step2), 0.1): the yaw-step cap of the low-speed rule (:1013-1022), for the few
+// steps that turn by more than 0.09 rad.  A real function on the device, on purpose: inlined into k_evaluate's loop
+// the arc tangent's and the square root's nineteen-odd constants are hoisted out of the loop into vector registers
+// (or, at 128 registers, into scratch memory: 60 MB of spill traffic per launch) for a branch that almost never runs.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline))
+#else
+inline
+#endif
+bool yaw_step_over_cap(double sn, double cs, double lim_curv, double step2)
+{
+    return fabs(atan2(sn, cs)) > fmax(lim_curv * sqrt(step2), 0.1);
+}
+
 // k = index of the sample inside the path; has_geo / has_d: the low-speed rules and the road test
 // only apply when the caller's path carries the arrays they read (:1013-1022, :982).  arc_step() returns
 // |s_k - s_{k-1}|; it is only asked for in the low-speed branch.
@@ -549,10 +563,7 @@ FOT_HD void check_sample(const LoopConst &C, CheckAcc &c, int k, const PathSampl
             const double cs = p.cos_t * c.prev.cos_t + p.sin_t * c.prev.sin_t;
             // yaw-step cap: the cap is at least 0.1 rad and |atan2(sn, cs)| <= |sn| / cs for cs > 0, so a step with
             // |sn| <= 0.09 cs can never exceed it -- the arc tangent (and the square root) only for the others
-            if (!(cs > 0.0 && fabs(sn) <= 0.09 * cs)) {
-                const double dyaw = fabs(atan2(sn, cs));
-                check_flag(c, dyaw > fmax(C.lim_curv * sqrt(step2), 0.1), CK_CURV);
-            }
+            if (!(cs > 0.0 && fabs(sn) <= 0.09 * cs)) check_flag(c, yaw_step_over_cap(sn, cs, C.lim_curv, step2), CK_CURV);
         }
         check_flag(c, p.v * p.v * fabs(p.kappa) > C.lim_lat, CK_LAT);                         // :975
         check_flag(c, has_d && fabs(p.d) > C.road_lim, CK_ROAD);                 // :982
