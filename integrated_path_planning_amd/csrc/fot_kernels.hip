@@ -378,7 +378,7 @@ struct FusedSink {
         bool sure = false;                                        // some obstacle is certainly within its radius
         const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
         for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
-            const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // even: lists are padded to chunk pairs
+            const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // (may be odd: the last pair then tests one chunk)
             const f2x8 *cp = row + c0;
             uint32_t near_bits = 0;                               // chunk c0+i within the threshold -> bit nb-1-i
             // Branch-free loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns out of
@@ -396,9 +396,11 @@ struct FusedSink {
                 sure |= ma <= thr_fatal;
                 swait_chunk(cb);
                 sload_chunk_ahead<128>(ca, cp, fx);
-                const float mb = min_sqdist32_f16(cb, fx, fy);
-                near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
-                sure |= mb <= thr_fatal;
+                if (c + 1 < nb) {                                     // wave-uniform
+                    const float mb = min_sqdist32_f16(cb, fx, fy);
+                    near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
+                    sure |= mb <= thr_fatal;
+                }
                 swait_chunk(ca);
                 cp += 2;
             }

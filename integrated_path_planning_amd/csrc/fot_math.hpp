@@ -972,8 +972,8 @@ FOT_HD int bin_of_value(const BinMap &m, float v)
 FOT_HD int bin_of(const BinMap &m, float x, float y) { return bin_of_value(m, m.axis ? y : x); }
 
 // Chunk range [c_lo, c_hi) of a list ordered by bin (bin_start[b] = first entry of bin b, bin_start[CULL_BINS] =
-// entries) that holds every entry a point of box `wb` could touch; both ends even (k_evaluate walks chunk pairs)
-// and within the pair-padded list.  Packed as c_lo << 16 | c_hi; 0 = nothing to test.
+// entries) that holds every entry a point of box `wb` could touch, within the pair-padded list (k_evaluate loads
+// chunks in pairs and may fetch -- not test -- one chunk past an odd range).  Packed as c_lo << 16 | c_hi; 0 = nothing.
 template <class StartFn>
 FOT_HD uint32_t strip_range(const BinMap &m, const Box32 &wb, float margin, const StartFn &bin_start)
 {
@@ -982,7 +982,7 @@ FOT_HD uint32_t strip_range(const BinMap &m, const Box32 &wb, float margin, cons
     const int b_lo = bin_of_value(m, lo), b_hi = bin_of_value(m, hi);
     const int e_lo = bin_start(b_lo), e_hi = bin_start(b_hi + 1);
     if (e_hi <= e_lo) return 0u;
-    const int c_lo = (e_lo / ENT_CHUNK_) & ~1, c_hi = ((e_hi + ENT_CHUNK_ - 1) / ENT_CHUNK_ + 1) & ~1;
+    const int c_lo = e_lo / ENT_CHUNK_, c_hi = (e_hi + ENT_CHUNK_ - 1) / ENT_CHUNK_;
     return ((uint32_t)c_lo << 16) | (uint32_t)c_hi;
 }
 
