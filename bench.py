@@ -384,7 +384,8 @@ def main():
     pmc_d, pmc_fresh = committed("pmc.json")
     pmc_k, pmc_name = of_kernel(pmc_d, dom)
     if "SQ_INSTS_VALU" in pmc_k:
-        n_valu = float(pmc_k["SQ_INSTS_VALU"])
+        prof_inst = int(pmc_d.get("_meta", {}).get("instances_per_launch", 256))
+        n_valu = float(pmc_k["SQ_INSTS_VALU"]) * (n_inst / launches_per_step) / prof_inst    # (the work is per instance)
         issue_ms = n_valu * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
         issue = {"kernel": dom, "bound": "valu_issue", "unit": "ms", "achieved": issue_ms, "peak": dom_ms,
                  "frac": issue_ms / dom_ms, "valu_instructions_per_launch": n_valu, "cycles_per_instruction": 4,
@@ -393,8 +394,8 @@ def main():
                  "source": "profiles/pmc.json" + (" (%s)" % pmc_d.get("_meta", {}).get("tag", "?")),
                  "source_matches_build": pmc_fresh,
                  "note": "executed VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over the measured launch "
-                         "time of the serial leg; valid for %d instances per launch" %
-                         int(pmc_d.get("_meta", {}).get("instances_per_launch", 256))}
+                         "time of the serial leg; counted on %d instances per launch, scaled to this launch's %d" %
+                         (prof_inst, int(n_inst / launches_per_step))}
     kernels = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items() if v["launches"]}
 
     # ---- parity spot check against the oracle (checker only, outside the timed region)
