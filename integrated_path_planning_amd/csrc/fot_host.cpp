@@ -103,7 +103,7 @@ struct fot_handle {
     HostSpline spline;
     DevBuf dSpline;
     TileShapes shapes;                       // tile table (host copy) ...
-    DevBuf dShapes;                          // ... and in HBM: cand0[] | n[]
+    DevBuf dShapes;                          // ... and in HBM: cand0[] | n[] | span[]
     bool has_path = false;
     Workspace ws[FOT_LANES];
     int lanes_cfg = 1;                       // sub-batches a large batch is split into
@@ -271,6 +271,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     TileTable tt;
     tt.cand0 = h->dShapes.as<int32_t>();
     tt.n = h->dShapes.as<int32_t>() + h->shapes.cand0.size();
+    tt.span = h->dShapes.as<int32_t>() + 2 * h->shapes.cand0.size();
     tt.n_tiles = L.n_tiles; tt.max_tiles = L.max_tiles; tt.row_budget = L.row_budget;
     tt.eval_segments = h->eval_segments;
     tt.grouped = L.grouped;
@@ -434,11 +435,13 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     build_tile_shapes(h->P, h->shapes);
     {
         const size_t nt = h->shapes.cand0.size();
-        if ((e = h->dShapes.ensure(sizeof(int32_t) * 2 * std::max<size_t>(nt, 1))) != hipSuccess) return bail(e, "hipMalloc");
+        if ((e = h->dShapes.ensure(sizeof(int32_t) * 3 * std::max<size_t>(nt, 1))) != hipSuccess) return bail(e, "hipMalloc");
         if (nt) {
             if ((e = hipMemcpy(h->dShapes.p, h->shapes.cand0.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
                 return bail(e, "hipMemcpy");
             if ((e = hipMemcpy(h->dShapes.as<int32_t>() + nt, h->shapes.n.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
+                return bail(e, "hipMemcpy");
+            if ((e = hipMemcpy(h->dShapes.as<int32_t>() + 2 * nt, h->shapes.span.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
                 return bail(e, "hipMemcpy");
         }
     }

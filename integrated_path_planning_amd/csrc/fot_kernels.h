@@ -40,6 +40,7 @@ struct MetaImport {
 // tile t of an instance = candidates [cand0[shape_off + t], + n[shape_off + t]).  n_tiles / max_tiles: of the batch.
 struct TileTable {
     const int32_t *cand0 = nullptr, *n = nullptr;
+    const int32_t *span = nullptr;      // first << 16 | last profile of each tile
     int n_tiles = 0, max_tiles = 0, row_budget = 0;
     int grouped = 0;                    // groups of GROUP_TILES tiles share a row table (TileShapes::grouped)
     int eval_segments = 0;              // time segments per tile in k_evaluate: 0 = by batch size, 1..4 forced (tests)

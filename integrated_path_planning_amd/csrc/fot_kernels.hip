@@ -859,6 +859,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
        int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
        TileStep *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+       const int32_t *__restrict__ tile_span,
        int ablate)
 {
     __shared__ int s_cnt[CULL_KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
@@ -870,6 +871,11 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __shared__ float s_margin[CULL_KG];
     __shared__ Box32 s_pbox[CULL_KG][CULL_PBOX];                 // boxes of the instance's profiles at the group's steps
     __shared__ double s_ext[CULL_KG][FOT_MAX_TI + FOT_MAX_BRAKE][2];   // lateral extent per horizon / brake entry and step
+    // what the boxes need of the instance that does not depend on the step, solved once per workgroup: the quartic of
+    // every profile (and its horizon's index), the quintics of the two extreme lateral targets of every horizon
+    __shared__ LonQuartic s_linfo[CULL_PBOX];
+    __shared__ uint8_t s_lext[CULL_PBOX];
+    __shared__ double s_latq[FOT_MAX_TI + FOT_MAX_BRAKE][9];
     const DevParams &P = *Pp;
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
     const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
@@ -890,6 +896,16 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
     const FilterConst fc = filter_const(sq_max, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
     const float slack = box_footprint_slack(P);
+    const int n_ext = P.n_ti + (S.c2f_ok ? S.n_brake : 0);
+    for (int w = tid; w < n_prof && w < CULL_PBOX; w += CULL_KG * WAVE) {
+        s_linfo[w] = lon_quartic(profile_info(P, D, S.frenet0, w, false));
+        s_lext[w] = (uint8_t)extent_index(P, D, w);
+    }
+    if (S.c2f_ok && tid < n_ext) {
+        const bool brake = tid >= P.n_ti;
+        lateral_extent_coeffs(P, S.frenet0, brake, brake ? P.brake[tid - P.n_ti] : P.ti[tid], s_latq[tid]);
+    }
+    __syncthreads();
 
     const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
     const int n_dyn = dyn_on ? D.S * D.P : 0;
@@ -921,18 +937,23 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         Box32 bw = box_empty();
         if (wv < nk && !(ablate & 8)) {
             // lateral extents first: one per horizon (shared by its terminal speeds) and per brake-ladder entry
-            const int n_ext = P.n_ti + (S.c2f_ok ? S.n_brake : 0);
             if (lane < n_ext) {
                 const bool brake = lane >= P.n_ti;
-                const TimeInfo &ti = brake ? P.brake[lane - P.n_ti] : P.ti[lane];
-                lateral_extent(P, S.frenet0, brake, ti, k0 + wv, brake ? ti.n_t : ti.n_t, s_ext[wv][lane][0], s_ext[wv][lane][1]);
+                const int n_eval = brake ? P.brake[lane - P.n_ti].n_t : P.ti[lane].n_t;
+                lateral_extent_q(s_latq[lane], brake, k0 + wv, n_eval, P.dt, s_ext[wv][lane][0], s_ext[wv][lane][1]);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int w = lane; w < n_prof; w += WAVE) {
-                const int e = extent_index(P, D, w);
-                const Box32 o = profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, s_ext[wv][e][0], s_ext[wv][e][1]);
-                if (w < CULL_PBOX) s_pbox[wv][w] = o;               // read again below, per tile
+                Box32 o;
+                if (w < CULL_PBOX) {
+                    const int e = s_lext[w];
+                    o = profile_box_from(s_linfo[w], D, sp, k0 + wv, P.dt, s_ext[wv][e][0], s_ext[wv][e][1]);
+                    s_pbox[wv][w] = o;                              // read again below, per tile
+                } else {                                            // (more profiles than the table holds: on the spot)
+                    const int e = extent_index(P, D, w);
+                    o = profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, s_ext[wv][e][0], s_ext[wv][e][1]);
+                }
                 box_merge(bw, o);
             }
         }
@@ -960,12 +981,31 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             }
         };
         constexpr int UNROLL = 4;                                 // gathers in flight per lane
-        for (int ib = i_first; ib < total; ib += UNROLL * STRIDE) {
-            Raw o[UNROLL];
+        if (D.n_static == 0) {
+            // only the prediction tensor (the usual case): a lane's obstacles are a fixed number of bytes apart, so the
+            // address is a running pointer instead of two 64-bit multiply-adds and a select per gather
+            const char *p0 = (const char *)(dyn_xy + 2 * (D.dyn_off + (tmajor ? (int64_t)row_l * n_dyn + i_first
+                                                                              : (int64_t)i_first * D.T + row_l)));
+            const int64_t step = (int64_t)(tmajor ? STRIDE : STRIDE * D.T) * (int64_t)(2 * sizeof(T));
+            const char *p = p0;
+            for (int ib = i_first; ib < total; ib += UNROLL * STRIDE) {
+                Raw o[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) fetch(ib + u * STRIDE, o[u]);
+                for (int u = 0; u < UNROLL; ++u) {                // (past the end: the lane's first obstacle again, ignored)
+                    o[u] = *(const Raw *)(ib + u * STRIDE < total ? p : p0);
+                    p += step;
+                }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) classify(ib + u * STRIDE, o[u]);
+                for (int u = 0; u < UNROLL; ++u) classify(ib + u * STRIDE, o[u]);
+            }
+        } else {
+            for (int ib = i_first; ib < total; ib += UNROLL * STRIDE) {
+                Raw o[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) fetch(ib + u * STRIDE, o[u]);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) classify(ib + u * STRIDE, o[u]);
+            }
         }
     }
     __syncthreads();
@@ -1045,10 +1085,9 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         TileStep r = { 0u, 0.0f, 0.0f, 0u };
         const int idx0 = tile_cand0[D.shape_off + w];
         if (live_k && idx0 < S.n_cand && tile_n[D.shape_off + w] > 0 && !(ablate & 1)) {   // (not a padding tile)
-            const int last = idx0 + tile_n[D.shape_off + w] - 1;
-            const int idx1 = last < S.n_cand - 1 ? last : S.n_cand - 1;
-            int s0, s1;
-            wave_profile_span(P, D, n_grid_lon, idx0, idx1, s0, s1);
+            // its profiles, from the table (a standing ego has no brake ladder: the span ends with its last profile)
+            const uint32_t sp01 = (uint32_t)tile_span[D.shape_off + w];
+            const int s0 = (int)(sp01 >> 16), s1 = (int)(sp01 & 0xffffu) < n_prof - 1 ? (int)(sp01 & 0xffffu) : n_prof - 1;
             Box32 wb = box_empty();
             for (int sl = s0; sl <= s1; ++sl) {
                 if (sl < CULL_PBOX) { box_merge(wb, s_pbox[kk][sl]); continue; }
@@ -1494,12 +1533,12 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
     const size_t lds = sizeof(double) * 9 * (size_t)lds_knots;
     if (dtype == FOT_F32)
         k_cull<float><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const float *)static_xy,
-                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0, tiles.n,
+                                             (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0, tiles.n, tiles.span,
                                              ablate);
     else
         k_cull<double><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const double *)static_xy,
                                               (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0,
-                                              tiles.n, ablate);
+                                              tiles.n, tiles.span, ablate);
     FOT_LAUNCH_CHECK();
     return 0;
 }

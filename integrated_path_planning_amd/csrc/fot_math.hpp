@@ -893,6 +893,27 @@ FOT_HD void lateral_extent(const DevParams &P, const double *fr, bool brake, con
     }
 }
 
+// the same from the two extreme targets' coefficients, solved once (they do not depend on the step)
+// (q9: the low target's six coefficients, then the high target's q3..q5 -- q0..q2 are the start state, shared)
+FOT_HD void lateral_extent_q(const double *q9, bool brake, int k, int n_eval, double dt, double &d0, double &d1)
+{
+    double u0, u1, u2;
+    lat_sample(q9, k, n_eval, dt, d0, u0, u1, u2);
+    d1 = d0;
+    if (!brake) {
+        const double q_hi[6] = { q9[0], q9[1], q9[2], q9[6], q9[7], q9[8] };
+        lat_sample(q_hi, k, n_eval, dt, d1, u0, u1, u2);
+    }
+}
+
+FOT_HD void lateral_extent_coeffs(const DevParams &P, const double *fr, bool brake, const TimeInfo &ti, double *q9)
+{
+    double q_hi[6];
+    lat_coeffs(fr, brake ? fr[3] : -(double)P.n_side * P.d_road_w, ti, q9);
+    lat_coeffs(fr, brake ? fr[3] : (double)(P.n_di - 1 - P.n_side) * P.d_road_w, ti, q_hi);
+    q9[6] = q_hi[3]; q9[7] = q_hi[4]; q9[8] = q_hi[5];
+}
+
 // box of the two end points of the segment (rx, ry) + d * normal, d in {d0, d1}
 FOT_HD Box32 segment_box(double rx, double ry, double cos_r, double sin_r, double d0, double d1, double ox, double oy)
 {
@@ -921,6 +942,35 @@ FOT_HD Box32 profile_box_at(const DevParams &P, const InstDesc &D, const double 
     if (k >= L.n_t) return box_empty();
     double s_, u0, u1, u2;
     lon_sample(L, k, P.dt, s_, u0, u1, u2);
+    SplinePt p;
+    spline_point(sp, s_, p);
+    const double inv = fast_rsqrt(p.dx * p.dx + p.dy * p.dy);
+    return segment_box(p.x, p.y, p.dx * inv, p.dy * inv, d0, d1, D.ego.x, D.ego.y);
+}
+
+// ... and from a profile whose quartic is already solved (k_cull keeps the instance's profiles in LDS: they do not
+// depend on the step either)
+struct LonQuartic {                      // what a box needs of a profile: 48 bytes instead of LonInfo's 72 (LDS)
+    double a0, a1, a2, a3, a4;
+    int32_t n_t, n_eval;
+};
+
+FOT_HD LonQuartic lon_quartic(const LonInfo &L)
+{
+    LonQuartic q;
+    q.a0 = L.a0; q.a1 = L.a1; q.a2 = L.a2; q.a3 = L.a3; q.a4 = L.a4; q.n_t = L.n_t; q.n_eval = L.n_eval;
+    return q;
+}
+
+FOT_HD Box32 profile_box_from(const LonQuartic &Q, const InstDesc &D, const SplineView &sp, int k, double dt, double d0,
+                              double d1)
+{
+    if (k >= Q.n_t) return box_empty();
+    LonInfo L;
+    L.a0 = Q.a0; L.a1 = Q.a1; L.a2 = Q.a2; L.a3 = Q.a3; L.a4 = Q.a4; L.n_t = Q.n_t; L.n_eval = Q.n_eval;
+    L.Js = 0.0; L.sd_last = 0.0; L.T = 0.0;
+    double s_, u0, u1, u2;
+    lon_sample(L, k, dt, s_, u0, u1, u2);
     SplinePt p;
     spline_point(sp, s_, p);
     const double inv = fast_rsqrt(p.dx * p.dx + p.dy * p.dy);

@@ -174,6 +174,7 @@ struct TileShapes {
     int grouped = 0;                               // 1: groups of GROUP_TILES tiles share a row table (fot_math.hpp)
     int64_t n_real = 0;                            // tiles with candidates, over all shapes (cost of the cut)
     std::vector<int32_t> cand0, n;                 // all shapes back to back
+    std::vector<int32_t> span;                     // first << 16 | last longitudinal profile of each tile (0 for padding)
     int32_t off[FOT_MAX_TV + 2] = { 0 };           // shape of n_tv: entries [off[n_tv], off[n_tv + 1])
     int tiles_of(int n_tv) const { return off[n_tv + 1] - off[n_tv]; }
 };
@@ -244,6 +245,21 @@ inline void build_tile_shapes_grouped(const DevParams &P, TileShapes &T)
     T.off[FOT_MAX_TV + 1] = (int32_t)T.cand0.size();
 }
 
+// profiles each tile's candidates come from (k_cull merges their boxes per tile and step)
+inline void fill_tile_spans(const DevParams &P, TileShapes &T)
+{
+    T.span.assign(T.cand0.size(), 0);
+    for (int n_tv = 1; n_tv <= FOT_MAX_TV; ++n_tv) {
+        const InstDesc D = shape_desc(P, n_tv);
+        for (int t = T.off[n_tv]; t < T.off[n_tv + 1]; ++t) {
+            if (T.n[(size_t)t] <= 0) continue;
+            int s0, s1;
+            wave_profile_span(P, D, P.n_ti * n_tv, T.cand0[(size_t)t], T.cand0[(size_t)t] + T.n[(size_t)t] - 1, s0, s1);
+            T.span[(size_t)t] = (int32_t)(((uint32_t)s0 << 16) | (uint32_t)s1);
+        }
+    }
+}
+
 // The cut of the handle's lattice: groups (four waves per SIMD in k_evaluate) unless they make over 15 % more tiles
 // than the per-wave cut -- with few lateral offsets per profile a tile fills its 64 lanes badly either way, and a
 // group's sixteen profiles may then hold fewer candidates than four per-wave tiles.  FOT_TILE_CUT=wave|group in the
@@ -256,6 +272,7 @@ inline void build_tile_shapes(const DevParams &P, TileShapes &T)
     bool use_groups = (double)grouped.n_real <= 1.15 * (double)wave.n_real;
     if (const char *e = getenv("FOT_TILE_CUT")) use_groups = e[0] == 'g';
     T = use_groups ? grouped : wave;
+    fill_tile_spans(P, T);
 }
 
 struct BatchLayout {

@@ -114,6 +114,14 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     double d0, d1;
                     lateral_extent(P, S.frenet0, brake, lat_ti, k, Li.n_eval, d0, d1);
                     pbox[(size_t)slot * P.n_total + k] = profile_box_at(P, D, S.frenet0, sp, slot, k, d0, d1);
+                    {   // k_cull's form: quartic and extreme lateral quintics solved once per instance, kept in LDS
+                        double q9[9], e0, e1;
+                        lateral_extent_coeffs(P, S.frenet0, brake, lat_ti, q9);
+                        lateral_extent_q(q9, brake, k, Li.n_eval, P.dt, e0, e1);
+                        const Box32 viaq = profile_box_from(lon_quartic(Li), D, sp, k, P.dt, e0, e1);
+                        if (std::memcmp(&e0, &d0, sizeof(double)) || std::memcmp(&e1, &d1, sizeof(double)) ||
+                            std::memcmp(&viaq, &pbox[(size_t)slot * P.n_total + k], sizeof(Box32))) return -114;
+                    }
                     // ... agrees with the one built from the full row
                     const Box32 ref = profile_box(P, S.frenet0, brake, lat_ti, ls, k, Li.n_eval, D.ego.x, D.ego.y);
                     const Box32 &got = pbox[(size_t)slot * P.n_total + k];
@@ -155,6 +163,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                 int s0, s1, rows = 0;
                 wave_profile_span(P, D, n_grid_lon, c, c + n - 1, s0, s1);
                 if (s1 - s0 + 1 > TILE_MAX_PROFILES) return -103;
+                if ((uint32_t)shapes.span[(size_t)D.shape_off + t] != (((uint32_t)s0 << 16) | (uint32_t)s1)) return -115;
                 for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
                 if (rows > L.row_budget && s1 > s0) return -104;          // what a wave staging the tile alone needs
                 if (!shapes.grouped && tile_extent(P, D, c, L.row_budget) != n) return -106;
