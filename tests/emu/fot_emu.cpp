@@ -357,3 +357,58 @@ extern "C" int emu_spline(int n, const double *wx, const double *wy, double *out
     for (int f = 0; f < 9; ++f) for (int i = 0; i < n; ++i) out9n[f * n + i] = (*src[f])[i];
     return 0;
 }
+
+// Both cuts of a planner's lattice, every terminal-speed grid size: the invariants the kernels rely on.
+// 0 = fine; otherwise -(1000 * cut + 10 * check + ...) style codes: -1xx wave cut, -2xx grouped cut.
+extern "C" int emu_check_tile_tables(const fot_params *params, int32_t *n_tiles_wave, int32_t *n_tiles_grouped, int32_t *chosen)
+{
+    std::string err;
+    DevParams P;
+    if (build_dev_params(*params, P, err) != FOT_OK) return -1;
+    TileShapes cuts[2], picked;
+    build_tile_shapes_wave(P, cuts[0]);
+    build_tile_shapes_grouped(P, cuts[1]);
+    build_tile_shapes(P, picked);
+    *n_tiles_wave = (int32_t)cuts[0].n_real; *n_tiles_grouped = (int32_t)cuts[1].n_real; *chosen = picked.grouped;
+    if (picked.cand0 != cuts[picked.grouped].cand0 || picked.n != cuts[picked.grouped].n) return -2;
+    if (picked.span.size() != picked.cand0.size()) return -3;
+    for (int c = 0; c < 2; ++c) {
+        TileShapes &T = cuts[c];
+        fill_tile_spans(P, T);
+        const int base = -100 * (c + 1);
+        for (int n_tv = 1; n_tv <= FOT_MAX_TV; ++n_tv) {
+            const InstDesc D = shape_desc(P, n_tv);
+            const int n_grid_lon = P.n_ti * n_tv, nt = T.tiles_of(n_tv);
+            if (nt <= 0) return base - 1;
+            if (T.grouped && nt % GROUP_TILES) return base - 2;
+            int cnext = 0;
+            for (int t = 0; t < nt; ++t) {
+                const int c0 = T.cand0[(size_t)T.off[n_tv] + t], n = T.n[(size_t)T.off[n_tv] + t];
+                if (c0 != cnext || n < 0 || n > WAVE || (n == 0 && !T.grouped)) return base - 3;
+                cnext += n;
+                if (n == 0) { if (T.span[(size_t)T.off[n_tv] + t] != 0) return base - 4; continue; }
+                int s0, s1, rows = 0;
+                wave_profile_span(P, D, n_grid_lon, c0, c0 + n - 1, s0, s1);
+                if (s1 - s0 + 1 > TILE_MAX_PROFILES) return base - 5;
+                for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
+                if (rows > T.row_budget && s1 > s0) return base - 6;
+                if ((uint32_t)T.span[(size_t)T.off[n_tv] + t] != (((uint32_t)s0 << 16) | (uint32_t)s1)) return base - 7;
+            }
+            if (cnext != D.n_cand_max) return base - 8;                     // every candidate in exactly one tile
+            if (T.grouped) {
+                for (int g0 = 0; g0 < nt; g0 += GROUP_TILES) {
+                    const size_t o = (size_t)T.off[n_tv] + g0;
+                    const int c0 = T.cand0[o], c1 = T.cand0[o + GROUP_TILES - 1] + T.n[o + GROUP_TILES - 1];
+                    if (c1 <= c0 || T.n[o] == 0) return base - 9;           // no empty group, padding only at a group's end
+                    int s0, s1, rows = 0;
+                    wave_profile_span(P, D, n_grid_lon, c0, c1 - 1, s0, s1);
+                    for (int sl = s0; sl <= s1; ++sl) rows += profile_rows(P, D, sl);
+                    if (s1 - s0 + 1 > GROUP_MAX_PROFILES || (rows > GROUP_ROWS && s1 > s0)) return base - 10;
+                    for (int t = 1; t < GROUP_TILES; ++t)
+                        if (T.n[o + t] > 0 && T.n[o + t - 1] == 0) return base - 11;
+                }
+            }
+        }
+    }
+    return 0;
+}

@@ -103,3 +103,30 @@ def test_kernel_logic_matches_reference(emu, golden):
         else:
             np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8, err_msg=f)
     np.testing.assert_allclose(r.new_last_kappa, float(g["last_kappa_after"]), rtol=1e-8, atol=1e-9)
+
+
+def test_tile_tables_of_random_lattices(emu):
+    """Both cuts of the lattice (per-wave rows / groups of four tiles) for random planner parameters and every
+    terminal-speed grid size: consecutive, complete, within the limits the kernels rely on; the handle's choice is one
+    of the two with its profile spans filled in."""
+    emu.emu_check_tile_tables.argtypes = [C.POINTER(_abi.Params)] + [C.POINTER(C.c_int32)] * 3
+    rng = np.random.default_rng(11)
+    chosen = []
+    for case in range(300):
+        dt = float(rng.choice([0.05, 0.1, 0.125, 0.2, 0.25]))
+        min_t = float(rng.choice([1.0, 2.0, 3.0, 4.0]))
+        max_t = min(min_t + float(rng.choice([0.0, 0.5, 1.0, 2.0])), 63 * dt)
+        min_t = min(min_t, max_t)
+        kw = dict(dt=dt, min_t=min_t, max_t=max_t, d_road_w=float(rng.choice([0.2, 0.25, 0.5, 1.0, 3.5])),
+                  max_road_width=float(rng.uniform(0.5, 7.5)), d_t_s=float(rng.uniform(0.5, 3.0)))
+        try:
+            params = make_params(**kw)
+        except Exception:
+            continue
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        rc = emu.emu_check_tile_tables(C.byref(params), C.byref(a), C.byref(b), C.byref(c))
+        if rc == -1:                                     # beyond a FOT_MAX_* limit: not a lattice libfot accepts
+            continue
+        assert rc == 0, (rc, kw)
+        chosen.append(c.value)
+    assert len(chosen) > 150 and sum(chosen) > 0                      # (the grouped cut wins on every lattice tried so far)
