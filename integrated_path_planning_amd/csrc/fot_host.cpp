@@ -238,8 +238,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     if (rc != FOT_OK) return fail(h, rc, err);
     if (L.n_inst == 0) return FOT_OK;
 
-    // --- staging: the descriptors in a pinned block (k_frenet_state pulls them into HBM; the wave maps behind them in
-    //     dMeta are written on the device)
+    // --- staging: the descriptors in a pinned block (k_frenet_state pulls them into HBM)
     const size_t desc_bytes = align256(sizeof(InstDesc) * (size_t)L.n_inst);
     const size_t meta_bytes = desc_bytes;
     if (w.staging_pending) { HIP_TRY(h, hipEventSynchronize(w.staging_done)); w.staging_pending = false; }

@@ -49,12 +49,6 @@ __device__ __forceinline__ float dpp_f32(float v)
 FOT_WAVE_REDUCE_F32(wave_min_f32, fminf)
 FOT_WAVE_REDUCE_F32(wave_max_f32, fmaxf)
 
-// id (0..7) of the XCD this wave runs on: HW_REG_XCC_ID, bits [3:0]  (speed only: which L2 holds an instance's lists)
-__device__ __forceinline__ int xcc_id()
-{
-    return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u);
-}
-
 // ---------------------------------------------------------------------------
 // ego -> Frenet state
 // ---------------------------------------------------------------------------
@@ -1549,9 +1543,10 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     if (tiles.n_tiles <= 0 || n_inst <= 0) return 0;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
     const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
-    // four waves per workgroup for batches, one for a handful of egos (a single lattice then spreads over as many CUs
-    // as it has tiles); 8 queues of ceil(n_inst / 8) * max_tiles tiles, `wpw` of them per workgroup
-    // Fewer tiles than a quarter of the GPU's SIMDs: every tile is cut into time segments (k_evaluate_split).
+    // Three launch shapes, 8 queues each (workgroup b serves the instances b mod 8):
+    //  * a handful of egos: every tile one workgroup, cut into time segments (k_evaluate_split);
+    //  * the grouped cut: one workgroup per group of four tiles (k_evaluate_group, four waves per SIMD);
+    //  * the per-wave cut: four independent tiles per workgroup (k_evaluate, three waves per SIMD).
     int n_seg = tiles.n_tiles <= 2304 ? SEG_MAX : 1;       // (scripts/segment_sweep.py: four segments win up to ~64 egos)
     if (tiles.eval_segments >= 1 && tiles.eval_segments <= SEG_MAX) n_seg = tiles.eval_segments;
     static const int force_wpw = getenv("FOT_EVAL_WPW") ? atoi(getenv("FOT_EVAL_WPW")) : 0;      // diagnostics
