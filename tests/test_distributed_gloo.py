@@ -83,14 +83,14 @@ def test_all_gather_world2(n_total):
     assert all(ret[r] for r in range(world))
 
 
-def _pipe_worker(rank, world, port, ret):
+def _pipe_worker(rank, world, port, ret, depth=2):
     from integrated_path_planning_amd.distributed import PipelinedAllGather
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         nb = 3 * _abi.RESULT_BYTES
-        pg = PipelinedAllGather(nb, world, torch.device("cpu"))
+        pg = PipelinedAllGather(nb, world, torch.device("cpu"), depth=depth)
         ok = True
         seen = {}
         for step in range(7):                                   # more steps than buffers: every pair is reused
@@ -110,13 +110,15 @@ def _pipe_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_pipelined_all_gather_world2():
-    """Double-buffered asynchronous gather (what bench.py runs at N > 1): buffers rotate, nothing is overwritten early."""
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_all_gather_world2(depth):
+    """Multi-buffered asynchronous gather (what bench.py runs at N > 1, one buffer pair per plan call in flight: three
+    by default): buffers rotate, nothing is overwritten early."""
     world = 2
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, ret, depth)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
