@@ -22,9 +22,13 @@ namespace fot {
 FOT_HD double fast_rcp(double a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // v_rcp_f64 is good to ~2^-26; one Newton step squares that (a few units in the last place -- every consumer is a
+    // product chain that rounds a few times anyway), a second one only buys the last bit
     double x = __builtin_amdgcn_rcp(a);
     x = fma(x, fma(-a, x, 1.0), x);
+#ifdef FOT_NEWTON2
     x = fma(x, fma(-a, x, 1.0), x);
+#endif
     return x;
 #else
     return 1.0 / a;
@@ -37,7 +41,9 @@ FOT_HD double fast_rsqrt(double a)
     double y = __builtin_amdgcn_rsq(a);
     const double h = 0.5 * a;
     y = fma(y, fma(-h * y, y, 0.5), y);
+#ifdef FOT_NEWTON2
     y = fma(y, fma(-h * y, y, 0.5), y);
+#endif
     return y;
 #else
     return 1.0 / sqrt(a);
