@@ -121,3 +121,29 @@ def test_lattice_shapes_across_tile_boundaries():
         res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
         assert len({res.records[i].n_cand for i in range(len(reqs))}) >= 3
         bp.close()
+
+
+def test_debug_hooks_argument_checks_and_frenet_given_state():
+    """fot_debug_set_eval_segments rejects anything but 0..4; a FOT_EGO_IS_FRENET record plans from the state as given
+    (no nearest-point search: new_prev_s is NaN), a state off the reference path gives "no Frenet state", and the
+    records are the same whichever evaluation kernel walks them."""
+    bp = BatchPlanner(waypoints=(WX, WY), dt=0.2)
+    for bad in (-1, 5, 99):
+        with pytest.raises(Exception):
+            bp.set_eval_segments(bad)
+    ego = PlanRequest(20.0, 0.6, 0.05, 5.0, 0.2)
+    rec0 = bp.plan_batch([ego]).records[0]
+    given = PlanRequest(*[float(v) for v in rec0.frenet0[:5]], last_kappa=float(rec0.frenet0[5]), is_frenet=True)
+    outs = []
+    for n_seg in (1, 4):
+        bp.set_eval_segments(n_seg)
+        r = bp.plan_batch([given]).records[0]
+        outs.append(r)
+        assert np.isnan(r.new_prev_s) and r.status == rec0.status and r.best_index == rec0.best_index
+        np.testing.assert_array_equal(np.ctypeslib.as_array(r.frenet0), np.ctypeslib.as_array(rec0.frenet0))
+        np.testing.assert_allclose(np.ctypeslib.as_array(r.x)[: r.n_keep], np.ctypeslib.as_array(rec0.x)[: rec0.n_keep],
+                                   rtol=0, atol=1e-12)
+    assert outs[0].cost == outs[1].cost and list(outs[0].stats) == list(outs[1].stats)
+    bp.set_eval_segments(0)
+    off = PlanRequest(500.0, 1.0, 0.0, 0.0, 0.0, is_frenet=True)                       # s beyond the 120 m path
+    assert bp.plan_batch([off]).records[0].status == _abi.PLAN_C2F_FAILED
