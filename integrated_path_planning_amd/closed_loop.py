@@ -307,6 +307,19 @@ class BatchedClosedLoop:
         self.peds = [ReplayPedestrians(tr, c.dt) for tr in ped_tracks]
         self.n_frames = np.array([p.n_frames for p in self.peds])
         self.ped_off = np.concatenate([[0], np.cumsum([p.n_peds for p in self.peds])]).astype(np.int64)
+        # all episodes' tracks side by side, [T_max, sum P, 2] (a shorter replay holds its last frame, as step() does):
+        # a frame of every running episode is then one row selection instead of a Python loop over the episodes
+        t_max = int(self.n_frames.max()) if len(self.peds) else 0
+
+        def side_by_side(which):
+            out = np.zeros((t_max, int(self.ped_off[-1]), 2))
+            for e, pd_ in enumerate(self.peds):
+                a = getattr(pd_, which)
+                out[: pd_.n_frames, self.ped_off[e]:self.ped_off[e + 1]] = a
+                out[pd_.n_frames:, self.ped_off[e]:self.ped_off[e + 1]] = a[-1]
+            return out
+        self._ped_all = {"trajectories": side_by_side("trajectories"), "velocities": side_by_side("velocities")}
+        self._rows_key, self._rows = None, None
         self.frame, self.ped_time = 0, 0.0
         self.observer = Observer(c.obs_len, c.dt, self.sgan_dt)      # one sampling clock; samples = all episodes' peds
         # ---- ego, state machine and planner caches as arrays
@@ -340,7 +353,17 @@ class BatchedClosedLoop:
     # ------------------------------------------------------------------------------------------------------
     def _ped_frame(self, which: str, sel: np.ndarray) -> np.ndarray:
         """positions / velocities of the episodes ``sel`` at the current frame, concatenated [sum P, 2]."""
-        return np.concatenate([getattr(self.peds[e], which)[min(self.frame, self.n_frames[e] - 1)] for e in sel], axis=0)
+        frame = self._ped_all[which][min(self.frame, len(self._ped_all[which]) - 1)]
+        return frame if len(sel) == len(self.peds) else frame[self._rows_of(sel)]
+
+    def _rows_of(self, sel: np.ndarray) -> np.ndarray:
+        """Pedestrian rows of the episodes ``sel`` (cached: the set of running episodes changes rarely)."""
+        key = sel.tobytes()
+        if key != self._rows_key:
+            self._rows_key = key
+            self._rows = (np.concatenate([np.arange(self.ped_off[e], self.ped_off[e + 1]) for e in sel])
+                          if len(sel) else np.zeros(0, np.int64))
+        return self._rows
 
     def _advance_pedestrians(self) -> None:
         self.frame += 1
@@ -370,7 +393,7 @@ class BatchedClosedLoop:
         t0 = time.perf_counter()
         pred = None
         if self.observer.is_ready:
-            rows = np.concatenate([np.arange(self.ped_off[e], self.ped_off[e + 1]) for e in sel])
+            rows = self._rows_of(sel)
             hist = self.observer.history
             obs = np.stack([hist[-2][rows], hist[-1][rows]], axis=0)          # CV reads the last two samples
             last = self.observer.last_sample_time
