@@ -189,6 +189,27 @@ def build_cases():
     st = np.concatenate([st, [[np.nan, 0.0], [inst.ego[0] + 12.0, np.nan]]])
     add("nan_ped_single", "straight", dict(syn.CONFIG3_PLANNER, collision_margin_inflation=1.2), inst.ego, dyn=dd,
         static=st)
+    # --- round 2: other lattice shapes and option combinations
+    inst = syn.config3_instance(5)
+    add("two_speeds", "straight", syn.CONFIG3_PLANNER, inst.ego, target_speed=1.0,            # terminal speeds 1.0, 0.0 only
+        dist=inst.dist[:8].astype(np.float64))
+    inst = syn.config3_instance(6)
+    add("overrides_tight", "straight", syn.CONFIG3_PLANNER, [22.0, -0.3, 0.02, 5.0, 0.4],
+        overrides={"max_speed": 6.0, "max_accel": 1.2, "max_curvature": 0.15, "max_lat_accel": 1.0},
+        dist=inst.dist[:6].astype(np.float64))
+    inst = syn.config3_instance(7)
+    add("footprint_chance_infl", "straight", dict(syn.CONFIG3_PLANNER, chance_epsilon=0.1, collision_margin_inflation=1.2),
+        inst.ego, dist=inst.dist.astype(np.float64), footprint=dict(length=4.5, width=1.8, n=3))
+    inst = syn.config3_instance(8, S=64, P=10)
+    add("dist_s64", "straight", dict(syn.CONFIG3_PLANNER, chance_epsilon=0.05), inst.ego, dist=inst.dist.astype(np.float64))
+    inst = syn.config3_instance(9)
+    add("stop_directive_dist", "straight", syn.CONFIG3_PLANNER, [30.0, 0.2, 0.0, 3.0, -0.5], max_stop=6.0,
+        target_speed=0.0, dist=inst.dist[:5].astype(np.float64))
+    rng = np.random.default_rng(77)
+    crowd = np.column_stack([rng.uniform(15.0, 75.0, 300), rng.choice([-1.0, 1.0], 300) * rng.uniform(1.5, 9.0, 300)])
+    add("static_crowd", "straight", syn.CONFIG2_PLANNER, [12.0, 0.4, 0.03, 6.5, 0.1], static=crowd)
+    add("curved_slow_turn", "curved", dict(SCEN03, max_curvature=1.0), [-6.0, 2.2, -0.9, 0.6, -0.4], target_speed=1.5,
+        last_kappa=-0.2)
     return cases
 
 
