@@ -218,6 +218,13 @@ int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)
  * of segments for the handle's later plan calls, 0 restores the choice by batch size. */
 int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
 
+/* Test hook.  How the handle cuts a lattice into tiles (the unit of work of the evaluation kernel): 0 = chosen by
+ * the lattice (default), 1 = per-wave rows (k_evaluate: every wave stages the rows of its own tile), 2 = groups
+ * (k_evaluate_group: four tiles share one row table).  Same decisions, byte-identical records either way; the GPU
+ * tests run every reference case under both cuts and under 1..4 time segments.  Rebuilds the handle's tile table
+ * (synchronises the device); applies to the handle's later plan calls. */
+int fot_debug_set_tile_cut(fot_handle *h, int32_t cut);
+
 /* FrenetPlanner._path_is_collision_free (frenet_planner.py:1035-1233) for n_paths externally
  * supplied paths against ONE obstacle set.  x, y, yaw, t: [n_paths][FOT_MAX_NT] host, len[n_paths];
  * static_xy [n_static][2] double host; dyn [S][P][T][2] double host with mode as in dyn_dims.

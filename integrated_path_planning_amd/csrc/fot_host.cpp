@@ -97,6 +97,7 @@ struct fot_handle {
     hipStream_t order_stream = nullptr;
     bool order_valid = false;
     int eval_segments = 0;               // fot_debug_set_eval_segments
+    int tile_cut = 0;                    // fot_debug_set_tile_cut (TILE_CUT_*)
     fot_params params;
     DevParams P;
     DevBuf dP;
@@ -177,6 +178,24 @@ int upload_spline(fot_handle *h)
     HIP_TRY(h, h->dSpline.ensure(flat.size() * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->dSpline.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
     h->has_path = true;
+    h->last_valid = false;
+    return FOT_OK;
+}
+
+// (re)builds the handle's tile table for the given cut and puts it into HBM: cand0[] | n[] | span[]
+int upload_tile_shapes(fot_handle *h, int cut)
+{
+    build_tile_shapes(h->P, h->shapes, cut);
+    h->tile_cut = cut;
+    const size_t nt = h->shapes.cand0.size();
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());                          // nothing may still be reading the old table
+    HIP_TRY(h, h->dShapes.ensure(sizeof(int32_t) * 3 * std::max<size_t>(nt, 1)));
+    if (nt) {
+        HIP_TRY(h, hipMemcpy(h->dShapes.p, h->shapes.cand0.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dShapes.as<int32_t>() + nt, h->shapes.n.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->dShapes.as<int32_t>() + 2 * nt, h->shapes.span.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+    }
     h->last_valid = false;
     return FOT_OK;
 }
@@ -431,18 +450,10 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     }
     if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemcpy(h->dP.p, &h->P, sizeof(DevParams), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
-    build_tile_shapes(h->P, h->shapes);
     {
-        const size_t nt = h->shapes.cand0.size();
-        if ((e = h->dShapes.ensure(sizeof(int32_t) * 3 * std::max<size_t>(nt, 1))) != hipSuccess) return bail(e, "hipMalloc");
-        if (nt) {
-            if ((e = hipMemcpy(h->dShapes.p, h->shapes.cand0.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
-                return bail(e, "hipMemcpy");
-            if ((e = hipMemcpy(h->dShapes.as<int32_t>() + nt, h->shapes.n.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
-                return bail(e, "hipMemcpy");
-            if ((e = hipMemcpy(h->dShapes.as<int32_t>() + 2 * nt, h->shapes.span.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice)) != hipSuccess)
-                return bail(e, "hipMemcpy");
-        }
+        int cut = TILE_CUT_AUTO;                                 // FOT_TILE_CUT=wave|group: diagnostics scripts
+        if (const char *ev = std::getenv("FOT_TILE_CUT")) cut = ev[0] == 'g' ? TILE_CUT_GROUP : ev[0] == 'w' ? TILE_CUT_WAVE : TILE_CUT_AUTO;
+        if (upload_tile_shapes(h, cut) != FOT_OK) { std::string m = h->err; fot_destroy(h); return fail(nullptr, FOT_ERR_HIP, m); }
     }
     *out = h;
     return FOT_OK;
@@ -914,9 +925,12 @@ int fot_pack_records_device(fot_handle *h, int32_t n, const fot_result *records_
     if (!records_dev || !wire_dev) return fail(h, FOT_ERR_INVALID, "NULL buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    // ordered behind the handle's previous enqueue whatever stream that ran on: the records are usually the output of
+    // the plan call just made, and NULL (= the handle's own stream) is also torch's default-stream handle
+    { int r = order_begin(h, st); if (r != FOT_OK) return r; }
     LAUNCH_TRY(h, launch_pack_wire(n, h->P.n_total, fot_wire_record_bytes(h->P.n_total), records_dev,
                                    (unsigned char *)wire_dev, st));
-    return FOT_OK;
+    return order_end(h, st);
 }
 
 static_assert(offsetof(fot_result, s) - offsetof(fot_result, t) == sizeof(double) * FOT_MAX_NT &&
@@ -957,6 +971,8 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
         fot_wire_header H;
         std::memcpy(&H, w, sizeof(H));
         if (H.n_total != n_total) return FOT_ERR_INVALID;
+        if (H.n_keep < 0 || H.n_keep > n_total || H.n_cand < 0 || H.best_index < -1 || H.best_index >= (H.n_cand > 0 ? H.n_cand : 1))
+            return FOT_ERR_INVALID;                              // (a corrupt or foreign record)
         fot_result &R = records[i];
         std::memset(&R, 0, sizeof(R));
         R.status = H.status; R.best_index = H.best_index; R.n_cand = H.n_cand; R.n_keep = H.n_keep;
@@ -980,6 +996,15 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg)
     if (n_seg < 0 || n_seg > 4) return fail(h, FOT_ERR_INVALID, "fot_debug_set_eval_segments: 0 (automatic) .. 4");
     h->eval_segments = n_seg;
     return FOT_OK;
+}
+
+int fot_debug_set_tile_cut(fot_handle *h, int32_t cut)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (cut != TILE_CUT_AUTO && cut != TILE_CUT_WAVE && cut != TILE_CUT_GROUP)
+        return fail(h, FOT_ERR_INVALID, "fot_debug_set_tile_cut: 0 (automatic), 1 (per-wave rows), 2 (groups)");
+    if (cut == h->tile_cut) return FOT_OK;
+    return upload_tile_shapes(h, cut);
 }
 
 int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)

@@ -355,7 +355,7 @@ struct FusedSink {
                          "s_load_dword %0, %1, 0x40\n\t"
                          "s_load_dword %0, %1, 0x80\n\t"
                          "s_load_dword %0, %1, 0xc0"
-                         : "=s"(pf) : "s"(row) : "memory");
+                         : "=&s"(pf) : "s"(row) : "memory");          // (early clobber: four loads read `row`)
         } else {
             pf = 0;
         }
@@ -734,11 +734,6 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 #endif
 }
 
-// One wave per tile.  The grid deals the tiles out position-major and XCD-aligned: workgroup b serves the instances
-// x, x + 8, ... with x = b mod 8 -- the XCD that, under round-robin placement, also ran k_cull's workgroups for them,
-// so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
-// ladder run longest), so the long tiles start early and the short ones fill the end of the launch.  The waves of a
-// workgroup share nothing but the staged spline: each has its own slice of LDS.
 // One wave per tile.  The grid deals the tiles out position-major and XCD-aligned: workgroup b serves the instances
 // x, x + 8, ... with x = b mod 8 -- the XCD that, under round-robin placement, also ran k_cull's workgroups for them,
 // so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake

@@ -262,15 +262,17 @@ inline void fill_tile_spans(const DevParams &P, TileShapes &T)
 
 // The cut of the handle's lattice: groups (four waves per SIMD in k_evaluate) unless they make over 15 % more tiles
 // than the per-wave cut -- with few lateral offsets per profile a tile fills its 64 lanes badly either way, and a
-// group's sixteen profiles may then hold fewer candidates than four per-wave tiles.  FOT_TILE_CUT=wave|group in the
-// environment forces the cut (diagnostics).
-inline void build_tile_shapes(const DevParams &P, TileShapes &T)
+// group's sixteen profiles may then hold fewer candidates than four per-wave tiles.  `cut` forces one
+// (fot_debug_set_tile_cut: the GPU tests run every golden under both).
+enum { TILE_CUT_AUTO = 0, TILE_CUT_WAVE = 1, TILE_CUT_GROUP = 2 };
+inline void build_tile_shapes(const DevParams &P, TileShapes &T, int cut = TILE_CUT_AUTO)
 {
     TileShapes wave, grouped;
     build_tile_shapes_wave(P, wave);
     build_tile_shapes_grouped(P, grouped);
     bool use_groups = (double)grouped.n_real <= 1.15 * (double)wave.n_real;
-    if (const char *e = getenv("FOT_TILE_CUT")) use_groups = e[0] == 'g';
+    if (cut == TILE_CUT_WAVE) use_groups = false;
+    if (cut == TILE_CUT_GROUP) use_groups = true;
     T = use_groups ? grouped : wave;
     fill_tile_spans(P, T);
 }

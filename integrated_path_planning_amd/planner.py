@@ -312,6 +312,12 @@ class BatchPlanner:
         1..4 forced, 0 = chosen by batch size."""
         _abi.check(self._h, self._lib.fot_debug_set_eval_segments(self._h, int(n_seg)))
 
+    def set_tile_cut(self, cut) -> None:
+        """Test hook (``fot_debug_set_tile_cut``): 0 / "auto", 1 / "wave" (k_evaluate, per-wave rows), 2 / "group"
+        (k_evaluate_group, four tiles per row table)."""
+        cut = {"auto": 0, "wave": 1, "group": 2}.get(cut, cut)
+        _abi.check(self._h, self._lib.fot_debug_set_tile_cut(self._h, int(cut)))
+
     def candidate_path(self, index: int, inst: int = 0) -> FrenetPath:
         """Candidate ``index`` of the last plan call as generated + converted, before truncation."""
         arr = np.zeros((15, _abi.MAX_NT))

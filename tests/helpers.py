@@ -15,3 +15,16 @@ def request_from_golden(g) -> PlanRequest:
                        max_stop_distance=m["max_stop"], static=g.static, dyn=g.dyn, dist=g.dist)
 
 
+
+
+# The evaluation kernels a plan call can take (csrc/fot_kernels.hip launch_evaluate).  Every parity test that asserts a
+# per-candidate table runs under each of them: "auto" is what a caller gets (k_evaluate_split for a handful of egos,
+# k_evaluate_group for batches); "group" / "wave" walk every candidate in one piece under the grouped / per-wave cut
+# (k_evaluate_group / k_evaluate); "split-wave" cuts the per-wave tiles into time segments.
+EVAL_PATHS = ("auto", "group", "wave", "split-wave")
+
+
+def set_eval_path(bp, path):
+    cut, seg = {"auto": (0, 0), "group": (2, 1), "wave": (1, 1), "split-wave": (1, 4)}[path]
+    bp.set_tile_cut(cut)
+    bp.set_eval_segments(seg)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import eps_band
-from helpers import TIGHT, assert_record_matches_oracle, oracle_plan_for_request
+from helpers import EVAL_PATHS, TIGHT, assert_record_matches_oracle, oracle_plan_for_request, set_eval_path
 from integrated_path_planning_amd.batch import PlanRequest
 from integrated_path_planning_amd.footprint import EgoFootprint
 from integrated_path_planning_amd.planner import BatchPlanner
@@ -133,21 +133,24 @@ def run_seed(seed, n_inst, dense):
         okw["footprint_offsets"], okw["footprint_radius"] = list(fp.offsets), fp.radius
     params, sp = orc.make_params(**okw), orc.Spline(wx, wy)
     bp = BatchPlanner(waypoints=(wx, wy), **kw)
-    if FORCE_SEGMENTS:
-        bp.set_eval_segments(FORCE_SEGMENTS)
     reqs = [random_request(rng, sp, kw, dense) for _ in range(n_inst)]
-    res = bp.plan_batch(reqs)
-    for i, rq in enumerate(reqs):
-        want = oracle_plan_for_request(orc, params, sp, rq, table=True)
-        label = f"seed {seed} inst {i}"
-        cost, status, keep, nt = bp.candidates(i)
-        assert len(cost) == want.n_cand, label
-        np.testing.assert_array_equal(nt, want.cand_nt, err_msg=label)
-        np.testing.assert_array_equal(keep, want.cand_keep, err_msg=label)
-        eps_band.check_status_table(bp, i, status, want.cand_status, label)
-        np.testing.assert_allclose(cost, want.cand_cost, rtol=TIGHT, atol=TIGHT, err_msg=label)
-        assert_record_matches_oracle(res.records[i], want, label=label)
-
+    wants = [oracle_plan_for_request(orc, params, sp, rq, table=True) for rq in reqs]
+    # the oracle once, the library under every evaluation kernel it ships (FOT_FUZZ_SEGMENTS: that segment count only)
+    for path in (EVAL_PATHS if not FORCE_SEGMENTS else ("forced",)):
+        if FORCE_SEGMENTS:
+            bp.set_eval_segments(FORCE_SEGMENTS)
+        else:
+            set_eval_path(bp, path)
+        res = bp.plan_batch(reqs)
+        for i, want in enumerate(wants):
+            label = f"seed {seed} inst {i} [{path}]"
+            cost, status, keep, nt = bp.candidates(i)
+            assert len(cost) == want.n_cand, label
+            np.testing.assert_array_equal(nt, want.cand_nt, err_msg=label)
+            np.testing.assert_array_equal(keep, want.cand_keep, err_msg=label)
+            eps_band.check_status_table(bp, i, status, want.cand_status, label)
+            np.testing.assert_allclose(cost, want.cand_cost, rtol=TIGHT, atol=TIGHT, err_msg=label)
+            assert_record_matches_oracle(res.records[i], want, label=label)
 
 
 @pytest.mark.parametrize("seed,dense", [(s, False) for s in range(900, 912)] + [(500900 + s, True) for s in range(4)])

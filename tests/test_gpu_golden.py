@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import eps_band
-from helpers import TIGHT, request_from_golden, wrap_angle
+from helpers import EVAL_PATHS, TIGHT, request_from_golden, set_eval_path, wrap_angle
 from integrated_path_planning_amd import _abi
 from integrated_path_planning_amd.planner import BatchPlanner
 
@@ -15,9 +15,12 @@ def _planner(g):
     return BatchPlanner(waypoints=(g["wx"], g["wy"]), **kw)
 
 
-def test_golden_case(golden):
+@pytest.mark.parametrize("eval_path", EVAL_PATHS)
+def test_golden_case(golden, eval_path):
+    """Every reference case under every evaluation kernel the library ships (helpers.EVAL_PATHS)."""
     g = golden
     bp = _planner(g)
+    set_eval_path(bp, eval_path)
     res = bp.plan_batch([request_from_golden(g)])
     r = res.records[0]
     np.testing.assert_allclose(np.array(r.frenet0[:]), g["frenet0"], rtol=TIGHT, atol=TIGHT)
@@ -29,7 +32,7 @@ def test_golden_case(golden):
     np.testing.assert_array_equal(nt, g["cand_nt"])
     np.testing.assert_array_equal(keep, g["cand_keep"])
     np.testing.assert_allclose(cost, g["cand_cost"], rtol=TIGHT, atol=TIGHT)
-    eps_band.check_status_table(bp, 0, status, g["cand_status"], f"golden {g.name}")   # equal + margin bookkeeping
+    eps_band.check_status_table(bp, 0, status, g["cand_status"], f"golden {g.name} [{eval_path}]")   # equal + margin bookkeeping
 
     stats = g["stats"]
     want = {_abi.STATUS_NAMES[i]: int(stats[i]) for i in range(8) if stats[i] >= 0}
