@@ -34,9 +34,9 @@
 extern "C" {
 #endif
 
-#define FOT_MAX_NT 64        /* samples per candidate: round(max_t/dt)+1 must be <= 64 */
+#define FOT_MAX_NT 128       /* samples per candidate: round(max_t/dt)+1 must be <= 128 (dt = 0.05 s at max_t = 5 s: 101) */
 #define FOT_MAX_CIRCLES 8    /* ego footprint circles (footprint.py:26) */
-#define FOT_MAX_TI 32        /* time horizons  int((max_t-min_t)/dt)+1 */
+#define FOT_MAX_TI 64        /* time horizons  int((max_t-min_t)/dt)+1  (min_t = 1 s at max_t = 5 s, dt = 0.1 s: 41) */
 #define FOT_MAX_TV 32        /* terminal speeds per horizon */
 #define FOT_MAX_BRAKE 16     /* brake-ladder entries (frenet_planner.py:475) */
 #define FOT_MAX_SAMPLES 64   /* prediction samples S of a distribution */

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-MAX_NT = 64
+MAX_NT = 128
 MAX_CIRCLES = 8
 MAX_SAMPLES = 64
 

@@ -35,34 +35,20 @@ class PlanRequest:
     dist: Optional[np.ndarray] = None            # [S, P, T, 2]
 
 
-def _drop_nan_tracks(d: np.ndarray) -> np.ndarray:
-    """[S, P, T, 2]: a pedestrian track with a NaN coordinate anywhere becomes all-NaN.
-
-    The reference pre-filters pedestrians by the bounding box of their whole track (np.min / np.max over time,
-    frenet_planner.py:1211-1219); one NaN sample makes that box NaN, the mask False, and the pedestrian is ignored at
-    EVERY time step.  libfot tests time step by time step, where a NaN sample simply never hits -- an all-NaN track is
-    the same statement in its terms.  (Static NaN points never hit on either side.)"""
-    if not np.isnan(d.sum()):                    # no NaN anywhere (the sum is cheap next to the copy that follows)
-        return d
-    bad = np.isnan(d).any(axis=(2, 3))
-    if bad.any():
-        d = np.array(d, dtype=np.float64, copy=True)
-        d[bad] = np.nan
-    return d
-
-
 def _dyn_of(req: PlanRequest):
-    """Which dynamic tensor plan() would use (frenet_planner.py:1043-1047, 1205-1208)."""
+    """Which dynamic tensor plan() would use (frenet_planner.py:1043-1047, 1205-1208).  Passed on as it is: the
+    reference's rule for NaN coordinates (a pedestrian whose track holds one is ignored at every time step,
+    frenet_planner.py:1211-1219) is applied by the library itself, for every producer of the tensor."""
     if req.dist is not None and np.size(req.dist) > 0:
         d = np.asarray(req.dist)
         if d.ndim != 4 or d.shape[-1] != 2:
             raise ValueError(f"distribution must be [S, P, T, 2], got {d.shape}")
-        return _abi.DYN_DISTRIBUTION, _drop_nan_tracks(d)
+        return _abi.DYN_DISTRIBUTION, d
     if req.dyn is not None and np.size(req.dyn) > 0 and np.shape(req.dyn)[-1] == 2:
         d = np.asarray(req.dyn)
         if d.ndim != 3:
             raise ValueError(f"dynamic obstacles must be [P, T, 2], got {d.shape}")
-        return _abi.DYN_SINGLE, _drop_nan_tracks(d[None])
+        return _abi.DYN_SINGLE, d[None]
     return _abi.DYN_NONE, None
 
 

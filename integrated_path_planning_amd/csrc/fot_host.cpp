@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -69,12 +70,13 @@ struct Workspace {
     DevBuf dState;
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
     DevBuf dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: culled entry lists + per-wave chunk ranges
+    DevBuf dNanFlag;                         // one flag per pedestrian track (NanScan)
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
         DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
-                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid };
+                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag };
         for (DevBuf *b : bufs) b->release();
         staging.release();
         if (staging_done) (void)hipEventDestroy(staging_done);
@@ -281,6 +283,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dEnt64.ensure(sizeof(d2) * n_ent));
     HIP_TRY(h, w.dEntSid.ensure(n_ent));
     HIP_TRY(h, w.dWaveRng.ensure(sizeof(TileStep) * (size_t)P.n_total * (size_t)std::max(L.n_tiles, 1)));
+    HIP_TRY(h, w.dNanFlag.ensure((size_t)std::max<int64_t>(L.n_tracks, 16)));
 
     // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
     w.staging_pending = true;
@@ -302,17 +305,25 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
     ea.sid = w.dEntSid.as<uint8_t>(); ea.rng = w.dWaveRng.as<TileStep>();
+    ea.nan_flag = w.dNanFlag.as<uint8_t>();
     {
         ProfScope ps(h, 0, st);
         MetaImport imp;
         imp.h_desc = (const InstDesc *)stg;
         imp.d_desc = (InstDesc *)w.dMeta.p;
-        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, st));
+        // one scan block per 256 KB of an instance's tensor (few, fat blocks: each first reads its descriptor out of the
+        // pinned staging block, a PCIe round trip), at most 64 per instance
+        NanScan scan;
+        if (L.n_tracks > 0) {
+            scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
+            scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
+        }
+        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, scan, st));
         HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
     if (L.any_obstacles) {
         ProfScope ps(h, 1, st);
-        LAUNCH_TRY(h, launch_cull(dP, d_desc, w.dState.as<InstState>(), L.n_inst, P.n_total, sv,
+        LAUNCH_TRY(h, launch_cull(dP, d_desc, w.dState.as<InstState>(), L.n_inst, P.n_total, P.n_ti + P.n_brake, sv,
                                   d_static, d_dyn, b.obstacle_dtype, ea, tt, st));
     }
     {
@@ -826,7 +837,7 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
         HIP_TRY(h, h->hSmallOut.ensure(sizeof(InstState) * (size_t)n));
         std::memcpy(h->hSmallIn.p, desc.data(), sizeof(InstDesc) * (size_t)n);
         LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), (const InstDesc *)h->hSmallIn.p,
-                                          (InstState *)h->hSmallOut.p, n, MetaImport(), h->stream));
+                                          (InstState *)h->hSmallOut.p, n, MetaImport(), NanScan(), h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         const InstState *stp = (const InstState *)h->hSmallOut.p;
         for (int i = 0; i < n; ++i) {
@@ -841,7 +852,7 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
     HIP_TRY(h, h->dTmpB.ensure(sizeof(InstState) * (size_t)n));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, desc.data(), sizeof(InstDesc) * (size_t)n, hipMemcpyHostToDevice, h->stream));
     LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), h->dTmpA.as<InstDesc>(),
-                                      h->dTmpB.as<InstState>(), n, MetaImport(), h->stream));
+                                      h->dTmpB.as<InstState>(), n, MetaImport(), NanScan(), h->stream));
     std::vector<InstState> st((size_t)n);
     HIP_TRY(h, hipMemcpyAsync(st.data(), h->dTmpB.p, sizeof(InstState) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1084,7 +1095,22 @@ int check_ext(fot_handle *h, int mode, int32_t n_paths, const int32_t *len, cons
     HIP_TRY(h, h->dTmpC.ensure(sizeof(int32_t) * meta.size()));
     HIP_TRY(h, h->dTmpD.ensure(sizeof(int32_t) * np));
     if (st_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserStatic.p, static_xy, st_bytes, hipMemcpyHostToDevice, st));
-    if (dy_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserDyn.p, dyn, dy_bytes, hipMemcpyHostToDevice, st));
+    // a pedestrian whose track holds a NaN coordinate anywhere is no obstacle at any step (the reference's pre-filter
+    // takes np.min / np.max over the whole track, frenet_planner.py:1211-1219): k_check_ext tests step by step, where an
+    // all-NaN track says the same
+    std::vector<double> dyn_clean;
+    if (dy_bytes && L.desc[0].dyn_mode != FOT_DYN_NONE) {
+        const InstDesc &D0 = L.desc[0];
+        const size_t row = 2 * (size_t)D0.T;
+        for (size_t j = 0; j < (size_t)D0.S * D0.P; ++j) {
+            bool bad = false;
+            for (size_t e = 0; e < row; ++e) bad |= std::isnan(dyn[j * row + e]);
+            if (!bad) continue;
+            if (dyn_clean.empty()) dyn_clean.assign(dyn, dyn + 2 * (size_t)L.dyn_src_points);
+            for (size_t e = 0; e < row; ++e) dyn_clean[j * row + e] = NAN;
+        }
+    }
+    if (dy_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserDyn.p, dyn_clean.empty() ? dyn : dyn_clean.data(), dy_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, L.desc.data(), sizeof(InstDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpB.p, flat.data(), sizeof(double) * flat.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpC.p, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, st));

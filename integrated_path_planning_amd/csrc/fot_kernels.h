@@ -28,6 +28,19 @@ struct EntryArrays {
     d2 *e64;           // exact coordinates
     uint8_t *sid;      // prediction sample of the entry, SID_STATIC for static obstacles
     TileStep *rng;     // [n_tiles][n_total] what a tile needs of time step k: chunk range + float32 thresholds
+    const uint8_t *nan_flag = nullptr;   // [n_tracks] NanScan::flag
+};
+
+// The reference ignores a pedestrian whose track holds a NaN coordinate at ANY time step, at EVERY time step (its
+// pre-filter takes np.min / np.max over the whole track, frenet_planner.py:1211-1219).  The blocks behind the
+// n_inst nearest-point blocks of k_frenet_state's launch scan the caller's dynamic tensors once -- whatever produced
+// them: the host packer, fot_resample_predictions, a PyTorch tensor handed to fot_plan_batch_device -- and leave one
+// flag per (sample, pedestrian) track; k_cull drops flagged tracks.  blocks_per_inst = 0: no dynamic obstacles.
+struct NanScan {
+    const void *dyn_xy = nullptr;
+    int dtype = 0;
+    uint8_t *flag = nullptr;            // [n_tracks] 1: the track holds a NaN
+    int blocks_per_inst = 0;
 };
 
 // descriptors still in pinned host memory, to be moved into HBM by k_frenet_state (h_desc == nullptr: already there)
@@ -48,8 +61,9 @@ struct TileTable {
 
 // every launcher returns 0 or the hipError_t of the launch
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
-                        MetaImport imp, hipStream_t st);
-int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
+                        MetaImport imp, NanScan scan, hipStream_t st);
+// n_ext: horizons + brake-ladder entries of the planner (sizes k_cull's per-horizon tables in LDS)
+int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total, int n_ext,
                 SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, TileTable tiles,
                 hipStream_t st);
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,

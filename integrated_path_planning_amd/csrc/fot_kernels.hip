@@ -133,6 +133,74 @@ __device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, doub
 
 constexpr int FRENET_WG = 256;
 
+// NanScan (fot_kernels.h): block `part` of `parts` of instance D flags the tracks [j0, j1) it owns.  A track is a
+// (sample, pedestrian) pair, T points; the flags of the block's own tracks are cleared, then every NaN coordinate sets
+// its track's flag (plain byte stores of the same value: no ordering between them is needed).
+template <typename T>
+__device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__restrict__ dyn_xy, uint8_t *__restrict__ flag,
+                                                int part, int parts)
+{
+    if (D.dyn_mode == FOT_DYN_NONE) return;
+    const int n_tracks = D.S * D.P;
+    const int per = (n_tracks + parts - 1) / parts;
+    const int j0 = part * per, j1 = j0 + per < n_tracks ? j0 + per : n_tracks;
+    if (j0 >= j1) return;
+    uint8_t *f = flag + D.nan_off;
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += FRENET_WG) f[j] = 0;
+    __syncthreads();
+    struct Pt { T x, y; };
+    const Pt *base = (const Pt *)dyn_xy + D.dyn_off;
+    if (D.dyn_tmajor) {                                          // [T][S][P]: thread = track, rows n_tracks apart
+        for (int j = j0 + (int)threadIdx.x; j < j1; j += FRENET_WG) {
+            bool bad = false;
+            for (int t = 0; t < D.T; ++t) {
+                const Pt p = base[(int64_t)t * n_tracks + j];
+                bad |= (p.x != p.x) | (p.y != p.y);
+            }
+            if (bad) f[j] = 1;
+        }
+    } else {                                                     // [S][P][T]: the block's tracks are one contiguous run
+        // 16-byte loads, sixteen in flight per thread (64 KB per block and round): the run is read once, at memory speed,
+        // while the nearest-point blocks of the same launch wait on their chains of dependent spline evaluations
+        typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int PER = (int)(16 / sizeof(T)) / 2;            // points per load: 2 (float) or 1 (double)
+        constexpr int UNROLL = 16;
+        const int64_t i0 = (int64_t)j0 * D.T, i1 = (int64_t)j1 * D.T;            // points [i0, i1)
+        // head: points in front of the first 16-byte boundary (at most one, float only)
+        int64_t a0 = i0;
+        if (PER == 2 && ((uintptr_t)(base + i0) & 15)) {             // (global loads need dword alignment only; speed)
+            if (threadIdx.x == 0) { const Pt p = base[i0]; if ((p.x != p.x) | (p.y != p.y)) f[(int)(i0 / D.T)] = 1; }
+            a0 = i0 + 1;
+        }
+        const int64_t n_vec = (i1 - a0) / PER;
+        const V *vb = (const V *)(base + a0);
+        for (int64_t vbase = threadIdx.x; vbase < n_vec; vbase += (int64_t)UNROLL * FRENET_WG) {
+            V v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t vi = vbase + (int64_t)u * FRENET_WG;
+                v[u] = vb[vi < n_vec ? vi : n_vec - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t vi = vbase + (int64_t)u * FRENET_WG;
+                if (vi >= n_vec) continue;
+                bool b0 = (v[u][0] != v[u][0]) | (v[u][1] != v[u][1]);
+                if (PER == 2) {
+                    const bool b1 = (v[u][2 % (2 * PER)] != v[u][2 % (2 * PER)]) | (v[u][3 % (2 * PER)] != v[u][3 % (2 * PER)]);
+                    if (b1) f[(int)((a0 + vi * PER + 1) / D.T)] = 1;
+                }
+                if (b0) f[(int)((a0 + vi * PER) / D.T)] = 1;
+            }
+        }
+        // tail: the last point when an odd number is left (float only)
+        if (PER == 2 && threadIdx.x == 0 && a0 + n_vec * PER < i1) {
+            const Pt p = base[i1 - 1];
+            if ((p.x != p.x) | (p.y != p.y)) f[(int)((i1 - 1) / D.T)] = 1;
+        }
+    }
+}
+
 // arg-min of a sample scan over the whole workgroup (lowest index wins ties); every thread gets the result
 __device__ __forceinline__ ScanBest block_argmin(ScanBest b, ScanBest *s_best)
 {
@@ -149,12 +217,21 @@ __device__ __forceinline__ ScanBest block_argmin(ScanBest b, ScanBest *s_best)
 // state are uniform values every wave computes alike.
 __global__ void __launch_bounds__(FRENET_WG)
 k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *desc,
-               InstState *__restrict__ state, int n_inst, MetaImport imp)
+               InstState *__restrict__ state, int n_inst, MetaImport imp, NanScan scan)
 {
     __shared__ ScanBest s_best[FRENET_WG / WAVE];
     __shared__ InstDesc s_desc;                                   // the descriptor being worked on, read once
     int inst = blockIdx.x;
-    if (inst >= n_inst) return;
+    if (inst >= n_inst) {
+        // the blocks behind the nearest-point blocks: NaN scan of the dynamic tensors (memory-bound, on CUs whose
+        // nearest-point block is a chain of dependent spline evaluations)
+        const int b = inst - n_inst, si = b / scan.blocks_per_inst, part = b - si * scan.blocks_per_inst;
+        if (si >= n_inst) return;
+        const InstDesc &D = (imp.h_desc ? imp.h_desc : desc)[si];
+        if (scan.dtype == FOT_F32) scan_nan_tracks(D, (const float *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst);
+        else scan_nan_tracks(D, (const double *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst);
+        return;
+    }
     constexpr int DESC_WORDS = (int)(sizeof(InstDesc) / sizeof(unsigned long long));
     static_assert(sizeof(InstDesc) % sizeof(unsigned long long) == 0, "InstDesc is copied in 8-byte words");
     if (imp.h_desc) {
@@ -323,10 +400,15 @@ __device__ __forceinline__ const EvalKernArgs &eval_kernargs()
 struct FusedSink {
     const DevParams *Pp;
     const InstDesc *Dp;
-    uint32_t my_rng;                     // lane k: strip range of time step k of this wave (0: nothing to test)
-    float my_thr, my_thr_sure;           // lane k: the float32 thresholds of time step k (TileStep)
-    float my_thr_fatal;                  // lane k: my_thr_sure where a certain hit settles the candidate (no chance
+    // The per-step values of the tile (TileStep) sit in lanes: lane l holds time step step_base + l, 64 steps at a time;
+    // a walk that crosses a multiple of 64 (more than 64 samples per candidate) reloads them there (steps_reload).
+    uint32_t my_rng;                     // lane l: strip range of time step step_base + l (0: nothing to test)
+    float my_thr, my_thr_sure;           // lane l: the float32 thresholds of that time step (TileStep)
+    float my_thr_fatal;                  // lane l: my_thr_sure where a certain hit settles the candidate (no chance
                                          // budget), else -1
+    int step_base;                       // multiple of 64 (wave-uniform)
+    int step_row;                        // number of this tile in the batch: its TileSteps start at step_row * n_total
+    int lane_id;
     float thr, thr_fatal;                // of the current time step (wave-uniform)
     const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
     int chunks_per_k;                    // ent_cap / 8
@@ -342,13 +424,29 @@ struct FusedSink {
     // way into the scalar cache while the sample arithmetic runs.  The loads are hand-issued and their (unused)
     // destination register stays tied to the sink until pf_wait(): a scalar load retires at any later time, and
     // must not land in a register the compiler has meanwhile given to something else.
+    // lane l <- TileStep of time step base + l of this tile (every lane of the wave is active here: the region that
+    // calls row_begin holds lanes 0 .. min(n_total, 64) - 1 at least, all 64 once a second block of steps exists)
+    __device__ __forceinline__ void steps_load(int base)
+    {
+        const DevParams &P = *Pp;
+        const EvalKernArgs &KA = eval_kernargs();
+        TileStep st = { 0u, 0.0f, 0.0f, 0u };
+        if (Dp->ent_cap != 0 && base + lane_id < P.n_total && !(KA.ablate & 1))
+            st = KA.wave_rng[(int64_t)step_row * P.n_total + base + lane_id];
+        my_rng = st.rng; my_thr = st.thr; my_thr_sure = st.thr_sure;
+        my_thr_fatal = Dp->max_viol == 0 ? st.thr_sure : -1.0f;
+        step_base = base;
+    }
+
     __device__ __forceinline__ void row_begin(int k)
     {
-        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)my_rng, k);
+        if ((k & ~(WAVE - 1)) != step_base) steps_load(k & ~(WAVE - 1));      // wave-uniform; never taken up to 64 samples
+        const int kl = k & (WAVE - 1);
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)my_rng, kl);
         c_lo = (int)(r >> 16);
         n_chunks = (int)(r & 0xffffu) - c_lo;
-        thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr), k));
-        thr_fatal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_fatal), k));
+        thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr), kl));
+        thr_fatal = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_fatal), kl));
         if (n_chunks > 0 && !no_warm) {
             const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
             asm volatile("s_load_dword %0, %1, 0x0\n\t"
@@ -412,7 +510,7 @@ struct FusedSink {
         const InstDesc &D = *Dp;
         const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
         const EvalKernArgs &KA = eval_kernargs();
-        const float thr_sure = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_sure), k));
+        const float thr_sure = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_sure), k & (WAVE - 1)));
         const d2 *e64 = KA.ent64 + D.ent_off;
         const uint8_t *sid = KA.ent_sid + D.ent_off;
         const int64_t base = ((int64_t)k * chunks_per_k + c_lo) * ENT_CHUNK;
@@ -607,10 +705,12 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     const int k0 = SPLIT ? seg * seg_len : 0;
     const int k1 = SPLIT ? (k0 + seg_len < n_loop ? k0 + seg_len : n_loop) : n_loop;
 
-    // lane k holds the strip range of time step k (read back with v_readlane): loaded while every lane of the
-    // wave is still active, lanes without a candidate included
+    // lane l holds the strip range of time step step_base + l (read back with v_readlane), 64 steps at a time: loaded
+    // while every lane of the wave is still active, lanes without a candidate included
+    const int step_base0 = k0 & ~(WAVE - 1);
     TileStep my_step = { 0u, 0.0f, 0.0f, 0u };
-    if (D.ent_cap != 0 && lane < n_total && !(a.ablate & 1)) my_step = wave_rng[(int64_t)(D.tile0 + tile) * n_total + lane];
+    if (D.ent_cap != 0 && step_base0 + lane < n_total && !(a.ablate & 1))
+        my_step = wave_rng[(int64_t)(D.tile0 + tile) * n_total + step_base0 + lane];
     const uint32_t my_rng = my_step.rng;
     // (while every lane is active: the time-step loop reads lane k of these, candidate or not)
     const float my_thr_fatal = D.max_viol == 0 ? my_step.thr_sure : -1.0f;
@@ -635,7 +735,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     // (v_readlane of lane k): they must be active wherever the compiler may place a copy of those registers, so they
     // all enter the region below -- a lane without a candidate walks an empty path (n_t = 0).
     const bool has_cand = lane < n;
-    if (has_cand || lane < n_total) {
+    if (has_cand || lane < n_total) {                            // (n_total > 64: every lane)
         const int idx = cand0 + (has_cand ? lane : 0);           // candidate index inside the instance
         slot = (int64_t)D.cand_off + idx;
         const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
@@ -656,6 +756,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         sink.my_rng = my_rng;
         sink.my_thr = my_step.thr; sink.my_thr_sure = my_step.thr_sure; sink.thr = 0.0f; sink.thr_fatal = -1.0f;
         sink.my_thr_fatal = my_thr_fatal;
+        sink.step_base = step_base0; sink.step_row = D.tile0 + tile; sink.lane_id = lane;
         sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
         sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
         sink.oxd = D.ego.x; sink.oyd = D.ego.y;
@@ -848,7 +949,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
        int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
        int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
        TileStep *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
-       const int32_t *__restrict__ tile_span,
+       const int32_t *__restrict__ tile_span, const uint8_t *__restrict__ nan_flag,
        int ablate)
 {
     __shared__ int s_cnt[CULL_KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
@@ -859,14 +960,17 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __shared__ BinMap s_bm[CULL_KG];
     __shared__ float s_margin[CULL_KG];
     __shared__ Box32 s_pbox[CULL_KG][CULL_PBOX];                 // boxes of the instance's profiles at the group's steps
-    __shared__ double s_ext[CULL_KG][FOT_MAX_TI + FOT_MAX_BRAKE][2];   // lateral extent per horizon / brake entry and step
     // what the boxes need of the instance that does not depend on the step, solved once per workgroup: the quartic of
     // every profile (and its horizon's index), the quintics of the two extreme lateral targets of every horizon
     __shared__ LonQuartic s_linfo[CULL_PBOX];
     __shared__ uint8_t s_lext[CULL_PBOX];
-    __shared__ double s_latq[FOT_MAX_TI + FOT_MAX_BRAKE][9];
     const DevParams &P = *Pp;
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
+    // dynamic LDS behind the spline, sized by the planner's horizons (launch_cull): the lateral extent per horizon /
+    // brake-ladder entry and step, and the two extreme lateral quintics of every horizon
+    const int n_ext_cap = P.n_ti + P.n_brake;
+    double *s_ext = s_spl + 9 * lds_knots;                       // [CULL_KG][n_ext_cap][2]
+    double *s_latq = s_ext + CULL_KG * n_ext_cap * 2;            // [n_ext_cap][9]
     const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
     // workgroups go round-robin over the 8 XCDs: all groups of instance i run back to back on XCD i mod 8, so the
     // 64-byte runs that neighbouring groups cut out of the same cache lines of the prediction tensor meet in one L2
@@ -890,9 +994,9 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         s_linfo[w] = lon_quartic(profile_info(P, D, S.frenet0, w, false));
         s_lext[w] = (uint8_t)extent_index(P, D, w);
     }
-    if (S.c2f_ok && tid < n_ext) {
+    if (S.c2f_ok && tid < n_ext) {                               // (n_ext <= FOT_MAX_TI + FOT_MAX_BRAKE < the workgroup)
         const bool brake = tid >= P.n_ti;
-        lateral_extent_coeffs(P, S.frenet0, brake, brake ? P.brake[tid - P.n_ti] : P.ti[tid], s_latq[tid]);
+        lateral_extent_coeffs(P, S.frenet0, brake, brake ? P.brake[tid - P.n_ti] : P.ti[tid], s_latq + tid * 9);
     }
     __syncthreads();
 
@@ -926,22 +1030,23 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         Box32 bw = box_empty();
         if (wv < nk && !(ablate & 8)) {
             // lateral extents first: one per horizon (shared by its terminal speeds) and per brake-ladder entry
-            if (lane < n_ext) {
-                const bool brake = lane >= P.n_ti;
-                const int n_eval = brake ? P.brake[lane - P.n_ti].n_t : P.ti[lane].n_t;
-                lateral_extent_q(s_latq[lane], brake, k0 + wv, n_eval, P.dt, s_ext[wv][lane][0], s_ext[wv][lane][1]);
+            for (int e = lane; e < n_ext; e += WAVE) {
+                const bool brake = e >= P.n_ti;
+                const int n_eval = brake ? P.brake[e - P.n_ti].n_t : P.ti[e].n_t;
+                double *ext = s_ext + (wv * n_ext_cap + e) * 2;
+                lateral_extent_q(s_latq + e * 9, brake, k0 + wv, n_eval, P.dt, ext[0], ext[1]);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int w = lane; w < n_prof; w += WAVE) {
                 Box32 o;
                 if (w < CULL_PBOX) {
-                    const int e = s_lext[w];
-                    o = profile_box_from(s_linfo[w], D, sp, k0 + wv, P.dt, s_ext[wv][e][0], s_ext[wv][e][1]);
+                    const double *ext = s_ext + (wv * n_ext_cap + s_lext[w]) * 2;
+                    o = profile_box_from(s_linfo[w], D, sp, k0 + wv, P.dt, ext[0], ext[1]);
                     s_pbox[wv][w] = o;                              // read again below, per tile
                 } else {                                            // (more profiles than the table holds: on the spot)
-                    const int e = extent_index(P, D, w);
-                    o = profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, s_ext[wv][e][0], s_ext[wv][e][1]);
+                    const double *ext = s_ext + (wv * n_ext_cap + extent_index(P, D, w)) * 2;
+                    o = profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, ext[0], ext[1]);
                 }
                 box_merge(bw, o);
             }
@@ -963,6 +1068,9 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         auto classify = [&](int i, const Raw &o) {
             const float fx = (float)((double)o.x - D.ego.x), fy = (float)((double)o.y - D.ego.y);
             if (i < total && live_l && cull_inside(bl, ml, fx, fy)) {
+                // a pedestrian whose track holds a NaN anywhere is no obstacle at any step (NanScan; asked for the few
+                // obstacles inside the box only)
+                if (i >= D.n_static && nan_flag[D.nan_off + (i - D.n_static)]) return;
                 const int bin = bin_of(bml, fx, fy);
                 atomicAdd(&s_cnt[kl][bin], 1);
                 const int j = atomicAdd(&s_nin[kl], 1);
@@ -1052,7 +1160,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             d2 o; int sid;
             point(i, o, sid);
             const float fx = (float)(o.x - D.ego.x), fy = (float)(o.y - D.ego.y);
-            if (live_k && cull_inside(bk, mk, fx, fy)) {
+            if (live_k && cull_inside(bk, mk, fx, fy) && !(i >= D.n_static && nan_flag[D.nan_off + (i - D.n_static)])) {
                 const int bin = bin_of(bmk, fx, fy);
                 const int pos = atomicAdd(&s_cnt[kk][bin], 1);
                 ent32_store(ent32, base + pos, fx, fy);
@@ -1080,8 +1188,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             Box32 wb = box_empty();
             for (int sl = s0; sl <= s1; ++sl) {
                 if (sl < CULL_PBOX) { box_merge(wb, s_pbox[kk][sl]); continue; }
-                const int e = extent_index(P, D, sl);
-                box_merge(wb, profile_box_at(P, D, S.frenet0, sp, sl, k, s_ext[kk][e][0], s_ext[kk][e][1]));
+                const double *ext = s_ext + (kk * n_ext_cap + extent_index(P, D, sl)) * 2;
+                box_merge(wb, profile_box_at(P, D, S.frenet0, sp, sl, k, ext[0], ext[1]));
             }
             const float wm = cull_margin(sq_max, wb) + slack;
             r.rng = strip_range(bmk, wb, wm, [&](int bb) { return s_start[kk][bb]; });
@@ -1179,14 +1287,14 @@ k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, co
     tab.sp = sp; tab.L = L; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
-    if (lane < keep) {
+    for (int k = lane; k < keep; k += WAVE) {                              // (more than 64 samples: two rounds)
         double o[15];
-        final_sample(P, L, tab, q, lane, o);
-        R.t[lane] = o[0]; R.s[lane] = o[1]; R.s_d[lane] = o[2]; R.s_dd[lane] = o[3]; R.s_ddd[lane] = o[4];
-        R.d[lane] = o[5]; R.d_d[lane] = o[6]; R.d_dd[lane] = o[7]; R.d_ddd[lane] = o[8];
-        R.x[lane] = o[9]; R.y[lane] = o[10]; R.yaw[lane] = o[11]; R.v[lane] = o[12]; R.a[lane] = o[13];
-        R.c[lane] = o[14];
-        if (lane == 1) R.new_last_kappa = o[14];                           // frenet_planner.py:301-302
+        final_sample(P, L, tab, q, k, o);
+        R.t[k] = o[0]; R.s[k] = o[1]; R.s_d[k] = o[2]; R.s_dd[k] = o[3]; R.s_ddd[k] = o[4];
+        R.d[k] = o[5]; R.d_d[k] = o[6]; R.d_dd[k] = o[7]; R.d_ddd[k] = o[8];
+        R.x[k] = o[9]; R.y[k] = o[10]; R.yaw[k] = o[11]; R.v[k] = o[12]; R.a[k] = o[13];
+        R.c[k] = o[14];
+        if (k == 1) R.new_last_kappa = o[14];                              // frenet_planner.py:301-302
     }
     if (lane == 0) {
         R.n_keep = keep;
@@ -1214,10 +1322,10 @@ k_debug_path(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc
     tab.sp = sp; tab.L = L; tab.dt = P.dt;
     double q[6];
     lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
-    if (lane < L.n_t) {
+    for (int k = lane; k < L.n_t; k += WAVE) {
         double o[15];
-        final_sample(P, L, tab, q, lane, o);
-        for (int f = 0; f < 15; ++f) out[f * FOT_MAX_NT + lane] = o[f];
+        final_sample(P, L, tab, q, k, o);
+        for (int f = 0; f < 15; ++f) out[f * FOT_MAX_NT + k] = o[f];
     }
     if (lane == 0) { meta[0] = L.n_t; meta[1] = 1; }
 }
@@ -1272,7 +1380,7 @@ k_pack_wire(int n, int n_total, int stride, const fot_result *__restrict__ src, 
     float *path = (float *)(w + sizeof(fot_wire_header));
     const double *arr = R.t;                                  // the 15 arrays are contiguous, FOT_MAX_NT doubles each
     for (int f = 0; f < 15; ++f)
-        if (lane < n_total) path[f * n_total + lane] = (float)arr[f * FOT_MAX_NT + lane];
+        for (int k = lane; k < n_total; k += WAVE) path[f * n_total + k] = (float)arr[f * FOT_MAX_NT + k];
     // padding bytes stay as they are (never read)
 }
 
@@ -1501,17 +1609,19 @@ k_safety(const DevParams *__restrict__ Pp, int n, const double *__restrict__ ego
 #define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
-                        MetaImport imp, hipStream_t st)
+                        MetaImport imp, NanScan scan, hipStream_t st)
 {
     if (n_inst <= 0) return 0;
     const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
-    k_frenet_state<<<n_inst, FRENET_WG, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state, n_inst,
-                                                                                 imp);
+    const int64_t grid = (int64_t)n_inst * (1 + (scan.flag ? scan.blocks_per_inst : 0));
+    if (grid > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
+    k_frenet_state<<<(unsigned)grid, FRENET_WG, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state,
+                                                                                         n_inst, imp, scan);
     FOT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total,
+int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total, int n_ext,
                 SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, TileTable tiles,
                 hipStream_t st)
 {
@@ -1519,15 +1629,16 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
     const unsigned grid = (unsigned)((int64_t)((n_inst + 7) / 8 * 8) * ((n_total + CULL_KG - 1) / CULL_KG));
     static const int ablate = getenv("FOT_CULL_ABLATE") ? atoi(getenv("FOT_CULL_ABLATE")) : 0;   // timing diagnostics
     const int lds_knots = sp.n <= 64 ? sp.n : 0;                           // a short spline rides along in LDS
-    const size_t lds = sizeof(double) * 9 * (size_t)lds_knots;
+    // + per horizon / brake-ladder entry: lateral extents of the group's steps, the two extreme lateral quintics
+    const size_t lds = sizeof(double) * (9 * (size_t)lds_knots + (size_t)n_ext * (CULL_KG * 2 + 9));
     if (dtype == FOT_F32)
         k_cull<float><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const float *)static_xy,
                                              (const float *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0, tiles.n, tiles.span,
-                                             ablate);
+                                             e.nan_flag, ablate);
     else
         k_cull<double><<<grid, CULL_KG * WAVE, lds, st>>>(P, desc, state, n_inst, sp, lds_knots, (const double *)static_xy,
                                               (const double *)dyn_xy, e.cnt, e.e32, e.e64, e.sid, e.rng, tiles.cand0,
-                                              tiles.n, tiles.span, ablate);
+                                              tiles.n, tiles.span, e.nan_flag, ablate);
     FOT_LAUNCH_CHECK();
     return 0;
 }

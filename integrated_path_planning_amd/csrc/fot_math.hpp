@@ -773,6 +773,8 @@ struct ObstacleView {
     const void *stat;
     const void *dyn;
     int dtype;                         // FOT_F32 | FOT_F64
+    const uint8_t *nan_track = nullptr;   // [S * P] 1: the pedestrian's track holds a NaN somewhere -- no obstacle at any
+                                          // step (frenet_planner.py:1211-1219); nullptr: the tensor is already clean
     FOT_HD d2 at(const void *base, int64_t i) const
     {
         d2 o;
@@ -827,8 +829,10 @@ FOT_HD bool collide_candidate(const DevParams &P, const InstDesc &D, const Obsta
             for (int s = 0; s < D.S; ++s) {
                 if ((hit_mask >> s) & 1) continue;
                 bool hit = false;
-                for (int p = 0; p < D.P; ++p)
+                for (int p = 0; p < D.P; ++p) {
+                    if (obs.nan_track && obs.nan_track[s * D.P + p]) continue;
                     if (within(obs.dyn_at(s, p, row, D.P, D.T), px, py, sq)) hit = true;
+                }
                 if (hit) {
                     hit_mask |= (uint64_t)1 << s;
                     if (++viol > D.max_viol) return true;

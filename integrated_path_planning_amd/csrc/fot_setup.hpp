@@ -290,6 +290,8 @@ struct BatchLayout {
     int64_t n_static = 0;         // extent of the caller's static_xy that is referenced (points)
     int64_t dyn_src_points = 0;   // extent of the caller's dyn_xy that is referenced (points)
     int64_t n_entries = 0;        // broad-phase entry slots in the batch (n_total * ent_cap per instance)
+    int64_t n_tracks = 0;         // pedestrian tracks (S * P per instance, rounded up to 16): one NaN flag each
+    int64_t max_dyn_bytes = 0;    // largest dynamic tensor of one instance (sizes the NaN scan)
     bool any_obstacles = false;
 };
 
@@ -377,6 +379,10 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const Ti
                 const int64_t pts = (int64_t)S * Pn * T;
                 if (D.dyn_off + pts > L.dyn_src_points) L.dyn_src_points = D.dyn_off + pts;
                 D.max_viol = mode == FOT_DYN_DISTRIBUTION ? (int)std::floor(hp.chance_epsilon * (double)S) : 0;
+                D.nan_off = L.n_tracks;
+                L.n_tracks += ((int64_t)S * Pn + 15) & ~(int64_t)15;
+                const int64_t bytes = pts * 2 * (b.obstacle_dtype == FOT_F32 ? 4 : 8);
+                if (bytes > L.max_dyn_bytes) L.max_dyn_bytes = bytes;
             }
         }
         const int64_t per_k = (int64_t)D.n_static + (D.dyn_mode != FOT_DYN_NONE ? (int64_t)D.S * D.P : 0);

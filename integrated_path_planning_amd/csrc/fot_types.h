@@ -85,6 +85,7 @@ struct InstDesc {
     int32_t max_viol;                    // floor(eps*S)
     int32_t n_chained;                   // instances right behind this one that continue its nearest-point cache
     int32_t _pad;
+    int64_t nan_off;                     // first of this instance's S * P track flags (fot_kernels.hip scan_nan_tracks)
 };
 
 // device-produced per-instance state

@@ -189,9 +189,17 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         std::vector<uint32_t> rng((size_t)std::max(n_tiles_inst, 1) * P.n_total, 0u);
         // k_cull's per (tile, step) thresholds (TileStep) and the bound of |x| + |y| they were taken at
         std::vector<float> thr_t(rng.size(), 0.0f), thr_sure_t(rng.size(), 0.0f), bound_t(rng.size(), -1.0f);
+        // NanScan (fot_kernels.h): a track with a NaN coordinate at any step is no obstacle at any step
+        std::vector<uint8_t> nan_track((size_t)(D.dyn_mode != FOT_DYN_NONE ? D.S * D.P : 0) + 1, 0);
         if (D.ent_cap > 0) {
             const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
             const double sq_max = sq_dyn > P.sq_r ? sq_dyn : P.sq_r;
+            for (size_t j = 0; j + 1 < nan_track.size(); ++j)
+                for (int t = 0; t < D.T; ++t) {
+                    const d2 o = obs.dyn_at((int)j / D.P, (int)j % D.P, t, D.P, D.T);
+                    if (o.x != o.x || o.y != o.y) nan_track[j] = 1;
+                }
+            obs.nan_track = nan_track.data();                                // (the definition applies the same rule)
             for (int k = 0; k < P.n_total; ++k) {
                 const Box32 &bx = boxes[k];
                 if (!(bx.x0 <= bx.x1)) continue;
@@ -207,6 +215,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     else { const int j = i - D.n_static; e.o = obs.dyn_at(j / D.P, j % D.P, row, D.P, D.T); e.sid = j / D.P; }
                     e.fx = (float)(e.o.x - D.ego.x); e.fy = (float)(e.o.y - D.ego.y);
                     if (!cull_inside(bx, margin, e.fx, e.fy)) continue;
+                    if (i >= D.n_static && nan_track[(size_t)(i - D.n_static)]) continue;
                     e.bin = bin_of(bm, e.fx, e.fy);
                     ents.push_back(e);
                 }

@@ -210,6 +210,19 @@ def build_cases():
     add("static_crowd", "straight", syn.CONFIG2_PLANNER, [12.0, 0.4, 0.03, 6.5, 0.1], static=crowd)
     add("curved_slow_turn", "curved", dict(SCEN03, max_curvature=1.0), [-6.0, 2.2, -0.9, 0.6, -0.4], target_speed=1.5,
         last_kappa=-0.2)
+    # --- round 3: more than 64 samples per candidate / more than 32 horizons (FOT_MAX_NT 128, FOT_MAX_TI 64)
+    inst = syn.config3_instance(12, S=6, P=20, T=101, dt=0.05)
+    add("dt005_dist", "straight", dict(syn.CONFIG3_PLANNER, dt=0.05), inst.ego, dist=inst.dist.astype(np.float64))
+    inst = syn.config3_instance(13, S=4, P=16)
+    add("min_t1_dist", "straight", dict(syn.CONFIG3_PLANNER, min_t=1.0), inst.ego, dist=inst.dist.astype(np.float64),
+        static=np.array([[inst.ego[0] + 9.0, 1.2], [inst.ego[0] + 17.0, -2.1]]))
+    add("dt005_curved", "curved", dict(SCEN03, dt=0.05, max_curvature=1.0), [-20.0, 2.4, 0.0, 3.5, 0.1], target_speed=4.0,
+        static=np.array([[-8.0, 1.5], [-1.0, -1.0], [2.0, -6.0]]), prev_s=9.0)
+    inst = syn.config3_instance(14, S=1, P=8, T=101, dt=0.05)
+    add("dt005_min_t2_single", "straight", dict(syn.CONFIG2_PLANNER, dt=0.05, min_t=2.0, max_road_width=3.0), inst.ego,
+        dyn=inst.dist[0].astype(np.float64), target_speed=6.0)
+    add("dt005_stop", "straight", dict(syn.CONFIG3_PLANNER, dt=0.05, max_road_width=3.0), [30.0, 0.2, 0.0, 3.0, -0.5],
+        max_stop=6.0, target_speed=0.0, overrides=dict(max_accel=6.0, max_lat_accel=6.0))
     return cases
 
 
@@ -279,8 +292,9 @@ def run_case(ref, case, out_dir):
     probes = sorted(set(i for i in [0, 1, n // 3, n // 2, (2 * n) // 3, n - 8, n - 1,
                                     int(out["best_index"])] if 0 <= i < n))
     out["probe_idx"] = np.array(probes, dtype=np.int32)
+    width = 64 if max(len(fp_list[i].t) for i in probes) <= 64 else 128      # (64: the fixtures of rounds 1-2, unchanged)
     for f in FIELDS:
-        arr = np.full((len(probes), 64), np.nan)
+        arr = np.full((len(probes), width), np.nan)
         for r, i in enumerate(probes):
             v = np.asarray(getattr(fp_list[i], f), float)
             arr[r, : len(v)] = v

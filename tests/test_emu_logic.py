@@ -26,6 +26,7 @@ CSRC = os.path.join(ROOT, "integrated_path_planning_amd", "csrc")
 def emu():
     srcs = [os.path.join(EMU_DIR, "fot_emu.cpp")] + [os.path.join(CSRC, f) for f in
                                                       ("fot_math.hpp", "fot_setup.hpp", "fot_types.h")]
+    srcs.append(os.path.join(ROOT, "include", "fot.h"))
     if not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", EMU_SO, srcs[0]],
@@ -52,7 +53,7 @@ def run_emu(emu, g):
     pb = PackedBatch([request_from_golden(g)])
     wx = np.ascontiguousarray(g["wx"]); wy = np.ascontiguousarray(g["wy"])
     out = (_abi.Result * 1)()
-    cap = 4096
+    cap = 16384
     cost = np.zeros(cap); status = np.zeros(cap, np.int32); keep = np.zeros(cap, np.int32)
     err = C.create_string_buffer(256)
     dp = C.POINTER(C.c_double)

@@ -96,6 +96,9 @@ def random_request(rng, sp, kw, dense=False):
         vel = rng.normal(0, 0.3 if dense else 1.2, (S, P, 1, 2))
         t = (np.arange(T) * kw["dt"])[None, None, :, None]
         traj = p0[None, :, None, :] + vel * t + np.cumsum(rng.normal(0, 0.05, (S, P, T, 2)), axis=2)
+        if rng.random() < 0.2:                      # a few NaN coordinates: their whole tracks stop being obstacles
+            for _ in range(int(rng.integers(1, 4))):
+                traj[rng.integers(0, S), rng.integers(0, P), rng.integers(0, T), rng.integers(0, 2)] = np.nan
         if mode == 1:
             req.dyn = traj[0]
         else:

@@ -84,3 +84,48 @@ def test_golden_case_through_adopted_reference_spline(golden):
     np.testing.assert_allclose(cost, g["cand_cost"], rtol=TIGHT, atol=TIGHT)
     if r.best_index >= 0:
         np.testing.assert_allclose(np.array(r.x[: r.n_keep]), g["best_x"], rtol=TIGHT, atol=TIGHT)
+
+
+@pytest.mark.parametrize("name", ["nan_ped_dist", "nan_ped_single"])
+@pytest.mark.parametrize("layout_tsp", [False, True], ids=["spt", "tsp"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_nan_tracks_through_the_device_entry(name, layout_tsp, dtype):
+    """The reference ignores a pedestrian whose track holds ONE NaN coordinate at every time step
+    (frenet_planner.py:1211-1219).  The rule lives in the library: the un-sanitised tensor, resident in HBM the way a
+    PyTorch predictor would hand it over (fot_plan_batch_device), in both layouts and both element types, gives the
+    reference's status table -- and differs from it when the partly-NaN tracks are made finite."""
+    import torch
+    from conftest import Golden
+    from integrated_path_planning_amd.batch import PackedBatch
+    g = Golden(name)
+    bp = _planner(g)
+    rq = request_from_golden(g)
+    tensor = rq.dist if rq.dist is not None else rq.dyn
+    bad = np.isnan(tensor).any(axis=(-1, -2))
+    assert bad.any() and not np.isnan(tensor).all(axis=(-1, -2))[bad].all(), "the case needs a PARTLY NaN track"
+    pb = PackedBatch([rq], dtype, dyn_layout_tsp=layout_tsp)
+    dev = torch.device("cuda", 0)
+    dyn = torch.from_numpy(pb.dyn_xy).to(dev)
+    stat = torch.from_numpy(pb.static_xy).to(dev) if pb.static_xy.size else None
+    out = torch.zeros(_abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    bp.plan_packed_device(pb.with_device_obstacles(stat.data_ptr() if stat is not None else None, dyn.data_ptr()),
+                          out.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    rec = _abi.Result.from_buffer_copy(out.cpu().numpy().tobytes())
+    cost, status, keep, nt = bp.candidates(0)
+    if dtype == np.float64:                              # (float32 obstacle values are not the golden's inputs)
+        np.testing.assert_array_equal(status, g["cand_status"].astype(np.int32))
+        assert rec.best_index == int(g["best_index"])
+    # the oracle on exactly the values the device saw
+    from helpers import oracle_plan_for_request
+    from oracle import oracle as orc
+    okw = g.planner_kwargs()
+    rounded = request_from_golden(g)
+    for f in ("static", "dyn", "dist"):
+        v = getattr(rounded, f)
+        if v is not None:
+            setattr(rounded, f, np.asarray(v).astype(dtype).astype(np.float64))
+    want = oracle_plan_for_request(orc, orc.make_params(**okw), orc.Spline(g["wx"], g["wy"]), rounded, table=True)
+    np.testing.assert_array_equal(status, want.cand_status)
+    assert rec.best_index == want.best_index
