@@ -38,7 +38,7 @@ extern "C" {
 #define FOT_MAX_CIRCLES 8    /* ego footprint circles (footprint.py:26) */
 #define FOT_MAX_TI 64        /* time horizons  int((max_t-min_t)/dt)+1  (min_t = 1 s at max_t = 5 s, dt = 0.1 s: 41) */
 #define FOT_MAX_TV 32        /* terminal speeds per horizon */
-#define FOT_MAX_BRAKE 16     /* brake-ladder entries (frenet_planner.py:475) */
+#define FOT_MAX_BRAKE 32     /* brake-ladder entries 0.5 s, 1.0 s, ... < min_t (frenet_planner.py:475): min_t <= 16.4 s */
 #define FOT_MAX_SAMPLES 64   /* prediction samples S of a distribution */
 
 /* error codes */

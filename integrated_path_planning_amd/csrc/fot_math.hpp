@@ -247,8 +247,14 @@ FOT_HD double tv_value(const DevParams &P, const InstDesc &D, int itv)
     return itv <= D.n_down ? D.target_speed - (double)itv * P.d_t_s : 0.0;
 }
 
+// (The coefficients of both polynomials, like everything that enters a candidate's cost, are formed with every
+// product and sum rounded on its own: whether the compiler contracts a particular a * b + c into a fused multiply-add
+// depends on the code it is inlined into, and the records must not depend on which kernel evaluated a candidate.)
 FOT_HD void lon_coeffs(const double *fr, double tv, const TimeInfo &ti, LonInfo &L)
 {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     L.a0 = fr[0]; L.a1 = fr[1]; L.a2 = fr[2] / 2.0;
     const double b0 = tv - L.a1 - 2.0 * L.a2 * ti.T;
     const double b1 = -2.0 * L.a2;
@@ -259,6 +265,9 @@ FOT_HD void lon_coeffs(const double *fr, double tv, const TimeInfo &ti, LonInfo 
 
 FOT_HD void lat_coeffs(const double *fr, double di, const TimeInfo &ti, double *q)
 {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     const double T = ti.T;
     q[0] = fr[3]; q[1] = fr[4]; q[2] = fr[5] / 2.0;
     const double b0 = di - q[0] - q[1] * T - q[2] * T * T;
@@ -319,13 +328,21 @@ FOT_HD LonInfo profile_info(const DevParams &P, const InstDesc &D, const double 
     }
     L.Js = 0.0; L.sd_last = 0.0;
     if (with_summary) {
+#if defined(__clang__)
+#pragma clang fp contract(off)                           // part of the cost: see lateral_jerk_sum
+#endif
         // sum over the polynomial samples k = 0..n-1 of jerk(t_k)^2 with jerk(t) = 6 a3 + 24 a4 t, t_k = k dt, in closed
         // form (the jerk is zero on the brake padding): n c0^2 + 2 c0 c1 sum(k) + c1^2 sum(k^2), c1 = 24 a4 dt
         const double n = (double)L.n_eval, c0 = 6.0 * L.a3, c1 = 24.0 * L.a4 * P.dt;
         const double sum_k = n * (n - 1.0) * 0.5, sum_k2 = (n - 1.0) * n * (2.0 * n - 1.0) / 6.0;
         L.Js = n * c0 * c0 + 2.0 * c0 * c1 * sum_k + c1 * c1 * sum_k2;
-        double s_, sdd, sddd;
-        lon_sample(L, L.n_t - 1, P.dt, s_, L.sd_last, sdd, sddd);
+        // final speed: the quartic's derivative at the last sample, 0 on a brake profile's padding (lon_sample)
+        if (L.n_t - 1 < L.n_eval) {
+            const double t = (double)(L.n_t - 1) * P.dt, t2 = t * t, t3 = t2 * t;
+            L.sd_last = L.a1 + 2.0 * L.a2 * t + 3.0 * L.a3 * t2 + 4.0 * L.a4 * t3;
+        } else {
+            L.sd_last = 0.0;
+        }
     }
     return L;
 }
@@ -608,6 +625,11 @@ FOT_HD void lat_sample(const double *q, int k, int n_eval, double dt, double &d,
 // The same value however the time range of a candidate is walked (one piece, or segments by different waves).
 FOT_HD double lateral_jerk_sum(const double *q, int n_eval, double dt)
 {
+    // (every product and sum rounded on its own: whether the compiler contracts a particular a * b + c into a fused
+    // multiply-add depends on the code around it, and the cost must not depend on which kernel evaluates it)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     const double n = (double)n_eval, c0 = 6.0 * q[3], c1 = 24.0 * q[4] * dt, c2 = 60.0 * q[5] * dt * dt;
     const double s1 = n * (n - 1.0) * 0.5, s2 = (n - 1.0) * n * (2.0 * n - 1.0) / 6.0, s3 = s1 * s1;
     const double s4 = (n - 1.0) * n * (2.0 * n - 1.0) * (3.0 * n * n - 3.0 * n - 1.0) / 30.0;
@@ -734,6 +756,9 @@ template <class Tab>
 FOT_HD void finish_candidate(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
                              const double *q, const SegState &g, bool collided, CandResult &out)
 {
+#if defined(__clang__)
+#pragma clang fp contract(off)                           // the cost: the same bits from every kernel (lateral_jerk_sum)
+#endif
     const int n_t = L.n_t;
     int keep = n_t;
     if (g.acc.fl & CK_SEEN_NAN) keep = g.first_nan >= 2 ? g.first_nan : 0;
