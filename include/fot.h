@@ -318,7 +318,7 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
  * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the
  * stream it is launched on.  fot_profile_read waits for the recorded work, then returns, per
  * kernel, the number of launches and the summed device time in ms since the last reset. */
-#define FOT_PROFILE_KERNELS 4
+#define FOT_PROFILE_KERNELS 3
 int fot_profile_enable(fot_handle *h, int on);
 int fot_profile_read(fot_handle *h, int reset, int32_t *launches, double *total_ms);
 const char *fot_profile_kernel_name(int index);

@@ -102,7 +102,7 @@ SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_se
            "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
            "fot_predict_cv", "fot_safety_metrics_batch", "fot_wire_n_total", "fot_wire_record_bytes",
            "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
-PROFILE_KERNELS = 4                      # FOT_PROFILE_KERNELS (include/fot.h)
+PROFILE_KERNELS = 3                      # FOT_PROFILE_KERNELS (include/fot.h)
 EGO_IS_FRENET = 3                        # FOT_EGO_IS_FRENET (fot_ego.has_prev_s)
 MARGIN_GROUPS = 8                        # FOT_MARGIN_GROUPS
 MARGIN_NAMES = ["speed", "accel", "curvature", "lat_accel", "road", "collision", "stop_filter", "structural"]

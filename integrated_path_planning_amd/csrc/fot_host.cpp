@@ -71,12 +71,13 @@ struct Workspace {
     DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
     DevBuf dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: culled entry lists + per-wave chunk ranges
     DevBuf dNanFlag;                         // one flag per pedestrian track (NanScan)
+    DevBuf dDone;                            // tiles evaluated so far, per instance (tile_done)
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
         DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
-                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag };
+                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag, &dDone };
         for (DevBuf *b : bufs) b->release();
         staging.release();
         if (staging_done) (void)hipEventDestroy(staging_done);
@@ -208,7 +209,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // memory directly (fot_plan_batch, fot_safety_metrics_batch, fot_frenet_state_batch, the host path of the resampler).
 constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_select" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -284,6 +285,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dEntSid.ensure(n_ent));
     HIP_TRY(h, w.dWaveRng.ensure(sizeof(TileStep) * (size_t)P.n_total * (size_t)std::max(L.n_tiles, 1)));
     HIP_TRY(h, w.dNanFlag.ensure((size_t)std::max<int64_t>(L.n_tracks, 16)));
+    HIP_TRY(h, w.dDone.ensure(sizeof(int32_t) * (size_t)L.n_inst));
 
     // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
     w.staging_pending = true;
@@ -318,7 +320,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
             scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
             scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
         }
-        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, scan, st));
+        LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, scan, w.dDone.as<int32_t>(), st));
         HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
     if (L.any_obstacles) {
@@ -328,12 +330,8 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     }
     {
         ProfScope ps(h, 2, st);
-        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, L.n_inst, tt, ea, ca, st));
-    }
-    {
-        ProfScope ps(h, 3, st);
-        LAUNCH_TRY(h, launch_select(dP, d_desc, w.dState.as<InstState>(),
-                                    sv, ca, d_out, L.n_inst, st));
+        LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, L.n_inst, tt, ea, ca, d_out,
+                                      w.dDone.as<int32_t>(), st));
     }
     return FOT_OK;
 }
@@ -790,9 +788,9 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
     const size_t st_bytes = (size_t)probe.n_static * 2 * elem, dy_bytes = (size_t)probe.dyn_src_points * 2 * elem;
     const size_t out_bytes = sizeof(fot_result) * (size_t)batch->n_inst;
     // A plan step for one or a few egos is latency, not bandwidth: its obstacle points (read once, by k_cull) and its
-    // records (written once, by k_select) then travel straight between the kernels and pinned host memory -- two copy
+    // records (written once, by the selecting wave) then travel straight between the kernels and pinned host memory -- two copy
     // operations and their synchronisation less per call.
-    if (st_bytes + dy_bytes <= 2 * SMALL_CALL_BYTES && out_bytes <= 8 * SMALL_CALL_BYTES) {   // (records stream out while k_select runs)
+    if (st_bytes + dy_bytes <= 2 * SMALL_CALL_BYTES && out_bytes <= 8 * SMALL_CALL_BYTES) {   // (records stream out as instances finish)
         const size_t dy_off = align256(st_bytes);
         HIP_TRY(h, h->hSmallIn.ensure(dy_off + dy_bytes + 256));
         HIP_TRY(h, h->hSmallOut.ensure(out_bytes));
@@ -837,7 +835,7 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
         HIP_TRY(h, h->hSmallOut.ensure(sizeof(InstState) * (size_t)n));
         std::memcpy(h->hSmallIn.p, desc.data(), sizeof(InstDesc) * (size_t)n);
         LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), (const InstDesc *)h->hSmallIn.p,
-                                          (InstState *)h->hSmallOut.p, n, MetaImport(), NanScan(), h->stream));
+                                          (InstState *)h->hSmallOut.p, n, MetaImport(), NanScan(), nullptr, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         const InstState *stp = (const InstState *)h->hSmallOut.p;
         for (int i = 0; i < n; ++i) {
@@ -852,7 +850,7 @@ int fot_frenet_state_batch(fot_handle *h, int32_t n, const fot_ego *ego,
     HIP_TRY(h, h->dTmpB.ensure(sizeof(InstState) * (size_t)n));
     HIP_TRY(h, hipMemcpyAsync(h->dTmpA.p, desc.data(), sizeof(InstDesc) * (size_t)n, hipMemcpyHostToDevice, h->stream));
     LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), h->dTmpA.as<InstDesc>(),
-                                      h->dTmpB.as<InstState>(), n, MetaImport(), NanScan(), h->stream));
+                                      h->dTmpB.as<InstState>(), n, MetaImport(), NanScan(), nullptr, h->stream));
     std::vector<InstState> st((size_t)n);
     HIP_TRY(h, hipMemcpyAsync(st.data(), h->dTmpB.p, sizeof(InstState) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

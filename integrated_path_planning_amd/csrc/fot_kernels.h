@@ -61,15 +61,15 @@ struct TileTable {
 
 // every launcher returns 0 or the hipError_t of the launch
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
-                        MetaImport imp, NanScan scan, hipStream_t st);
+                        MetaImport imp, NanScan scan, int32_t *inst_done, hipStream_t st);
 // n_ext: horizons + brake-ladder entries of the planner (sizes k_cull's per-horizon tables in LDS)
 int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state, int n_inst, int n_total, int n_ext,
                 SplineView sp, const void *static_xy, const void *dyn_xy, int dtype, EntryArrays e, TileTable tiles,
                 hipStream_t st);
+// evaluation + selection: the records land in `out`; inst_done: one counter per instance (zeroed by k_frenet_state)
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,
-                    int n_inst, TileTable tiles, EntryArrays e, CandArrays c, hipStream_t st);
-int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state,
-                  SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st);
+                    int n_inst, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
+                    hipStream_t st);
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state,
                       SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st);
 int launch_debug_margins(const DevParams *P, const InstDesc *desc, const InstState *state, SplineView sp, int inst,

@@ -12,8 +12,9 @@
 //                    truncation, kinematic checks, and -- while the candidate can still pass -- the collision test of
 //                    each sample against the entry list of its time step (wave-uniform chunk walk on scalar loads,
 //                    float32 bounds, float64 only between them).  Candidate points never leave registers.
-//   k_select       : 4 waves / instance: stop-distance filter, rejection histogram, first-minimum argmin (lowest index
-//                    wins ties), selected path rebuilt from its profile and written out
+//   (selection)    : the wave that finishes an instance's last tile: stop-distance filter, rejection histogram,
+//                    first-minimum argmin (lowest index wins ties), selected path rebuilt from its profile and written
+//                    out -- inside the evaluation launch (select_instance_wave)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -217,7 +218,7 @@ __device__ __forceinline__ ScanBest block_argmin(ScanBest b, ScanBest *s_best)
 // state are uniform values every wave computes alike.
 __global__ void __launch_bounds__(FRENET_WG)
 k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *desc,
-               InstState *__restrict__ state, int n_inst, MetaImport imp, NanScan scan)
+               InstState *__restrict__ state, int n_inst, MetaImport imp, NanScan scan, int32_t *__restrict__ inst_done)
 {
     __shared__ ScanBest s_best[FRENET_WG / WAVE];
     __shared__ InstDesc s_desc;                                   // the descriptor being worked on, read once
@@ -304,6 +305,7 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
             }
         }
         if (tid == 0) {
+            if (inst_done) inst_done[inst] = 0;                   // tiles of this instance evaluated so far (tile_done)
             InstState &S = state[inst];
             for (int i = 0; i < 6; ++i) { S.frenet0[i] = ok ? fr[i] : NAN; S.ref0[i] = ok ? ref[i] : NAN; }
             S.new_prev_s = new_prev_s;
@@ -388,6 +390,7 @@ struct EvalKernArgs {
     const int32_t *tile_cand0, *tile_n;
     const TileStep *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
     double *cand_cost, *cand_vlast, *cand_travel; uint8_t *cand_status, *cand_keep;
+    fot_result *out; int32_t *inst_done;             // selection by the wave that finishes an instance's last tile (tile_done)
 };
 // k_evaluate's argument segment: EVAL_LEAD_PTRS read-only pointers (passed on their own so that they carry
 // `__restrict__`: only no-alias inputs are certain to keep their loads on the scalar unit), then this struct
@@ -835,6 +838,114 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// selection + output (reference: frenet_planner.py:294-324, 1235-1259)
+// ---------------------------------------------------------------------------
+
+// One wave selects for one instance: stop-distance filter, rejection histogram, first-minimum arg-min (lowest index
+// wins ties), the selected path rebuilt from its profile, the record written.  Run by the wave that finishes the
+// instance's LAST tile (tile_done below) -- no separate launch behind the evaluation, and the selections of the
+// instances that finish early overlap with the evaluation of the others.  A real function: its registers (final_sample
+// holds an arc tangent) must not count against the time-step loop's.
+__device__ __forceinline__ void select_instance_wave(int inst, int lane)
+{
+    const EvalKernArgs &KA = eval_kernargs();
+    const DevParams &P = *KA.Pp;
+    const InstDesc &D = KA.desc[inst];
+    const InstState &S = KA.state[inst];
+    fot_result &R = KA.out[inst];
+    // the record starts out all zero (this wave alone writes it: program order is enough)
+    for (int i = lane; i < (int)(sizeof(fot_result) / sizeof(unsigned long long)); i += WAVE)
+        ((unsigned long long *)&R)[i] = 0ull;
+    if (!S.c2f_ok) {
+        if (lane == 0) {
+            R.status = FOT_PLAN_C2F_FAILED; R.best_index = -1; R.n_cand = 0; R.n_keep = 0;
+            R.cost = INFINITY; R.stats_valid = 0;
+            R.new_last_kappa = D.ego.last_kappa; R.new_prev_s = S.new_prev_s;
+            for (int i = 0; i < 6; ++i) { R.frenet0[i] = NAN; R.ref0[i] = NAN; }
+        }
+        return;
+    }
+    int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    ScanBest best = { INFINITY, -1 };
+    for (int idx = lane; idx < S.n_cand; idx += WAVE) {
+        const int64_t slot = (int64_t)D.cand_off + idx;
+        int st = KA.cand_status[slot];
+        st = final_status(st, KA.cand_vlast[slot], KA.cand_travel[slot], D.max_stop);
+        KA.cand_status[slot] = (uint8_t)st;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cnt[c] += (st == c) ? 1 : 0;
+        if (st == FOT_ST_OK) {
+            const double cost = KA.cand_cost[slot];
+            if (cost < best.dist) { best.dist = cost; best.idx = idx; }   // first strict minimum of this lane
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        for (int off = 32; off >= 1; off >>= 1) cnt[c] += __shfl_xor(cnt[c], off, WAVE);
+    best = wave_argmin(best);                                              // lowest index wins ties
+    if (lane == 0) {
+        R.status = best.idx >= 0 ? FOT_PLAN_OK : FOT_PLAN_NO_PATH;
+        R.best_index = best.idx;
+        R.n_cand = S.n_cand;
+        R.cost = best.idx >= 0 ? best.dist : INFINITY;
+        for (int c = 0; c < 8; ++c) R.stats[c] = cnt[c];
+        R.stats_valid = 1;
+        R.new_prev_s = S.new_prev_s;
+        for (int i = 0; i < 6; ++i) { R.frenet0[i] = S.frenet0[i]; R.ref0[i] = S.ref0[i]; }
+    }
+    if (best.idx < 0) {
+        if (lane == 0) { R.n_keep = 0; R.new_last_kappa = D.ego.last_kappa; }
+        return;
+    }
+    const int keep = KA.cand_keep[(int64_t)D.cand_off + best.idx];
+    const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
+    const LonInfo L = profile_info(P, D, S.frenet0, cd.lon_slot, false);
+    ComputeTab tab;
+    tab.sp = KA.sp; tab.L = L; tab.dt = P.dt;
+    double q[6];
+    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
+#ifndef FOT_SEL_NO_PATH
+    for (int k = lane; k < keep; k += WAVE) {                              // (more than 64 samples: two rounds)
+        double o[15];
+        final_sample(P, L, tab, q, k, o);
+        R.t[k] = o[0]; R.s[k] = o[1]; R.s_d[k] = o[2]; R.s_dd[k] = o[3]; R.s_ddd[k] = o[4];
+        R.d[k] = o[5]; R.d_d[k] = o[6]; R.d_dd[k] = o[7]; R.d_ddd[k] = o[8];
+        R.x[k] = o[9]; R.y[k] = o[10]; R.yaw[k] = o[11]; R.v[k] = o[12]; R.a[k] = o[13];
+        R.c[k] = o[14];
+        if (k == 1) R.new_last_kappa = o[14];                              // frenet_planner.py:301-302
+    }
+#endif
+    if (lane == 0) {
+        R.n_keep = keep;
+        if (keep <= 1) R.new_last_kappa = D.ego.last_kappa;
+    }
+}
+
+// A wave is done with one tile of instance `inst` (its candidates' results are stored, or the tile was empty).  Every
+// tile of the instance arrives exactly once; the wave that completes the count selects.  k_frenet_state zeroes the
+// counters.  Agent-scope release / acquire around the counter: the other tiles' results may come from other CUs.
+__device__ __forceinline__ void tile_done(int inst, int lane)
+{
+    const EvalKernArgs &KA = eval_kernargs();
+    __threadfence();                                              // this wave's stores, before the count
+    int last = 0;
+    if (lane == 0) last = atomicAdd(&KA.inst_done[inst], 1) == KA.desc[inst].n_tiles - 1 ? 1 : 0;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    __threadfence();                                              // the count, before the other waves' results are read
+    select_instance_wave(inst, lane);
+}
+
+// the degenerate launch: a batch without a single tile (no horizons, no brake ladder) still gets its records
+__global__ void __launch_bounds__(WAVE)
+k_select_only(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+              const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+              const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
+{
+    if ((int)blockIdx.x < a.n_inst) select_instance_wave((int)blockIdx.x, (int)threadIdx.x);
+}
+
 // One wave per tile.  The grid deals the tiles out position-major and XCD-aligned: workgroup b serves the instances
 // x, x + 8, ... with x = b mod 8 -- the XCD that, under round-robin placement, also ran k_cull's workgroups for them,
 // so their lists sit in its L2 (speed only) -- and an instance's LAST tile comes first (late horizons and the brake
@@ -869,6 +980,7 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     if (pos >= n_tiles) return;                                  // a shorter lattice than the batch's longest
     evaluate_tile<TILE_WAVE>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst,
                          n_tiles - 1 - pos, lane, x);
+    tile_done(inst, lane);
 }
 
 // The same for a handful of egos (fewer tiles than the GPU has SIMDs): a tile alone on its SIMD is a chain of
@@ -898,6 +1010,7 @@ k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
     const int tile = n_tiles - 1 - pos;
     evaluate_tile<TILE_SPLIT>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile, lane, x,
                               seg, n_seg, s_part);
+    if (seg == 0) tile_done(inst, lane);                         // (the wave that merged the segments and stored the results)
 }
 
 // The grouped cut (fot_math.hpp): one workgroup per group of GROUP_TILES tiles, one shared row table, four such
@@ -924,6 +1037,7 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
     const int tile0 = (n_groups - 1 - pos) * GROUP_TILES;
     evaluate_tile<TILE_GROUP>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile0 + wv,
                               lane, x, wv, GROUP_TILES, nullptr, tile0);
+    tile_done(inst, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1196,109 +1310,6 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             box_thresholds(fc, wb, wm, r.thr, r.thr_sure);
         }
         rng[(int64_t)w * P.n_total] = r;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// selection + output
-// ---------------------------------------------------------------------------
-
-constexpr int SELECT_WG = 256;
-
-__global__ void __launch_bounds__(SELECT_WG)
-k_select(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-         SplineView sp,
-         const double *__restrict__ cand_cost, const double *__restrict__ cand_vlast,
-         const double *__restrict__ cand_travel, uint8_t *__restrict__ cand_status,
-         const uint8_t *__restrict__ cand_keep, fot_result *__restrict__ out, int n_inst)
-{
-    __shared__ int s_cnt[SELECT_WG / WAVE][8];
-    __shared__ ScanBest s_best[SELECT_WG / WAVE];
-    const int inst = blockIdx.x;
-    if (inst >= n_inst) return;
-    const DevParams &P = *Pp;
-    const InstDesc &D = desc[inst];
-    const InstState &S = state[inst];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    fot_result &R = out[inst];
-    // the record starts out all zero; the fields are written after the barrier below
-    for (int i = tid; i < (int)(sizeof(fot_result) / sizeof(unsigned long long)); i += SELECT_WG)
-        ((unsigned long long *)&R)[i] = 0ull;
-
-    if (!S.c2f_ok) {
-        __syncthreads();
-        if (tid == 0) {
-            R.status = FOT_PLAN_C2F_FAILED; R.best_index = -1; R.n_cand = 0; R.n_keep = 0;
-            R.cost = INFINITY; R.stats_valid = 0;
-            R.new_last_kappa = D.ego.last_kappa; R.new_prev_s = S.new_prev_s;
-            for (int i = 0; i < 6; ++i) { R.frenet0[i] = NAN; R.ref0[i] = NAN; }
-        }
-        return;
-    }
-
-    // four waves over the candidates (a quarter of the dependent load rounds of one wave), merged through LDS
-    int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    ScanBest best = { INFINITY, -1 };
-    for (int idx = tid; idx < S.n_cand; idx += SELECT_WG) {
-        const int64_t slot = (int64_t)D.cand_off + idx;
-        int st = cand_status[slot];
-        st = final_status(st, cand_vlast[slot], cand_travel[slot], D.max_stop);
-        cand_status[slot] = (uint8_t)st;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) cnt[c] += (st == c) ? 1 : 0;
-        if (st == FOT_ST_OK) {
-            const double cost = cand_cost[slot];
-            if (cost < best.dist) { best.dist = cost; best.idx = idx; }   // first strict minimum of this thread
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        for (int off = 32; off >= 1; off >>= 1) cnt[c] += __shfl_xor(cnt[c], off, WAVE);
-    best = wave_argmin(best);                                              // lowest index wins ties
-    if (lane == 0) {
-        for (int c = 0; c < 8; ++c) s_cnt[wv][c] = cnt[c];
-        s_best[wv] = best;
-    }
-    __syncthreads();                                                       // also orders the zero fill before the fields
-    if (wv != 0) return;
-    for (int w = 1; w < SELECT_WG / WAVE; ++w) {
-        for (int c = 0; c < 8; ++c) cnt[c] += s_cnt[w][c];
-        scan_merge(best, s_best[w]);
-    }
-
-    if (lane == 0) {
-        R.status = best.idx >= 0 ? FOT_PLAN_OK : FOT_PLAN_NO_PATH;
-        R.best_index = best.idx;
-        R.n_cand = S.n_cand;
-        R.cost = best.idx >= 0 ? best.dist : INFINITY;
-        for (int c = 0; c < 8; ++c) R.stats[c] = cnt[c];
-        R.stats_valid = 1;
-        R.new_prev_s = S.new_prev_s;
-        for (int i = 0; i < 6; ++i) { R.frenet0[i] = S.frenet0[i]; R.ref0[i] = S.ref0[i]; }
-    }
-    if (best.idx < 0) {
-        if (lane == 0) { R.n_keep = 0; R.new_last_kappa = D.ego.last_kappa; }
-        return;
-    }
-    const int keep = cand_keep[(int64_t)D.cand_off + best.idx];
-    const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
-    const LonInfo L = profile_info(P, D, S.frenet0, cd.lon_slot, false);
-    ComputeTab tab;
-    tab.sp = sp; tab.L = L; tab.dt = P.dt;
-    double q[6];
-    lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
-    for (int k = lane; k < keep; k += WAVE) {                              // (more than 64 samples: two rounds)
-        double o[15];
-        final_sample(P, L, tab, q, k, o);
-        R.t[k] = o[0]; R.s[k] = o[1]; R.s_d[k] = o[2]; R.s_dd[k] = o[3]; R.s_ddd[k] = o[4];
-        R.d[k] = o[5]; R.d_d[k] = o[6]; R.d_dd[k] = o[7]; R.d_ddd[k] = o[8];
-        R.x[k] = o[9]; R.y[k] = o[10]; R.yaw[k] = o[11]; R.v[k] = o[12]; R.a[k] = o[13];
-        R.c[k] = o[14];
-        if (k == 1) R.new_last_kappa = o[14];                              // frenet_planner.py:301-302
-    }
-    if (lane == 0) {
-        R.n_keep = keep;
-        if (keep <= 1) R.new_last_kappa = D.ego.last_kappa;
     }
 }
 
@@ -1609,14 +1620,14 @@ k_safety(const DevParams *__restrict__ Pp, int n, const double *__restrict__ ego
 #define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
-                        MetaImport imp, NanScan scan, hipStream_t st)
+                        MetaImport imp, NanScan scan, int32_t *inst_done, hipStream_t st)
 {
     if (n_inst <= 0) return 0;
     const int lds_knots = sp.n <= SPLINE_LDS_KNOTS ? sp.n : 0;
     const int64_t grid = (int64_t)n_inst * (1 + (scan.flag ? scan.blocks_per_inst : 0));
     if (grid > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
     k_frenet_state<<<(unsigned)grid, FRENET_WG, sizeof(double) * 9 * (size_t)lds_knots, st>>>(P, sp, lds_knots, desc, state,
-                                                                                         n_inst, imp, scan);
+                                                                                         n_inst, imp, scan, inst_done);
     FOT_LAUNCH_CHECK();
     return 0;
 }
@@ -1644,9 +1655,10 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
 }
 
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,
-                    int n_inst, TileTable tiles, EntryArrays e, CandArrays c, hipStream_t st)
+                    int n_inst, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
+                    hipStream_t st)
 {
-    if (tiles.n_tiles <= 0 || n_inst <= 0) return 0;
+    if (n_inst <= 0) return 0;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
     const int lds_knots = sp.n <= 28 ? sp.n : 0;                           // a short spline rides along (2 KB at most)
     // Three launch shapes, 8 queues each (workgroup b serves the instances b mod 8):
@@ -1670,7 +1682,10 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_vlast = c.v_last; a.cand_travel = c.travel; a.cand_status = c.status; a.cand_keep = c.keep;
-    if (n_seg > 1) {
+    a.out = out; a.inst_done = inst_done;
+    if (tiles.n_tiles <= 0) {
+        k_select_only<<<(unsigned)n_inst, WAVE, 0, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
+    } else if (n_seg > 1) {
         k_evaluate_split<<<(unsigned)n_blocks, n_seg * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng,
                                                                         e.e32, a);
     } else if (tiles.grouped) {                                            // one workgroup per group of tiles
@@ -1681,16 +1696,6 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     } else {
         k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     }
-    FOT_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_select(const DevParams *P, const InstDesc *desc, const InstState *state,
-                  SplineView sp, CandArrays c, fot_result *out, int n_inst, hipStream_t st)
-{
-    if (n_inst <= 0) return 0;
-    k_select<<<n_inst, SELECT_WG, 0, st>>>(P, desc, state, sp, c.cost, c.v_last, c.travel, c.status,
-                                     c.keep, out, n_inst);
     FOT_LAUNCH_CHECK();
     return 0;
 }

@@ -1279,6 +1279,16 @@ FOT_HD CandDecode decode_candidate(const DevParams &P, const InstDesc &D, const 
     return c;
 }
 
+// yaw of the selected path's samples.  A real function on the device, like yaw_step_over_cap and for the same reason:
+// inlined behind the evaluation kernels' time-step loop (the selection runs there), the arc tangent's constants are
+// hoisted in front of the loop and live across it.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline))
+#else
+inline
+#endif
+double yaw_from_sin_cos(double sn, double cs) { return atan2(sn, cs); }
+
 // the 15 FrenetPath values of sample k of one candidate (data_structures.py:164-178 order)
 template <class Tab>
 FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const Tab &lon_tab, const double *q, int k,
@@ -1294,7 +1304,7 @@ FOT_HD void final_sample(const DevParams &P, const LonInfo &L, const Tab &lon_ta
     o[0] = (double)k * P.dt;
     o[1] = ls.s; o[2] = ls.sd; o[3] = ls.sdd; o[4] = sddd;
     o[5] = d; o[6] = d_d; o[7] = d_dd; o[8] = d_ddd;
-    o[9] = c.x; o[10] = c.y; o[11] = atan2(c.sin_t, c.cos_t);
+    o[9] = c.x; o[10] = c.y; o[11] = yaw_from_sin_cos(c.sin_t, c.cos_t);
     o[12] = c.v; o[13] = c.a; o[14] = c.kappa;
 }
 
