@@ -68,7 +68,7 @@ struct Workspace {
     PinnedBuf staging;
     DevBuf dMeta;                            // InstDesc[]
     DevBuf dState;
-    DevBuf dCost, dVlast, dTravel, dStatus, dKeep;
+    DevBuf dCost, dStatus, dKeep, dParts;
     DevBuf dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: culled entry lists + per-wave chunk ranges
     DevBuf dNanFlag;                         // one flag per pedestrian track (NanScan)
     DevBuf dDone;                            // tiles evaluated so far, per instance (tile_done)
@@ -76,7 +76,7 @@ struct Workspace {
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
-        DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dVlast, &dTravel, &dStatus, &dKeep,
+        DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dParts, &dStatus, &dKeep,
                            &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag, &dDone };
         for (DevBuf *b : bufs) b->release();
         staging.release();
@@ -274,8 +274,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dState.ensure(sizeof(InstState) * (size_t)L.n_inst));
     const size_t slots = (size_t)std::max<int64_t>(L.n_slots, 1);
     HIP_TRY(h, w.dCost.ensure(sizeof(double) * slots));
-    HIP_TRY(h, w.dVlast.ensure(sizeof(double) * slots));
-    HIP_TRY(h, w.dTravel.ensure(sizeof(double) * slots));
+    HIP_TRY(h, w.dParts.ensure(sizeof(TilePart) * (size_t)std::max(L.n_tiles, 1)));
     HIP_TRY(h, w.dStatus.ensure(slots));
     HIP_TRY(h, w.dKeep.ensure(slots));
     const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
@@ -301,7 +300,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     const DevParams *dP = h->dP.as<DevParams>();
     const SplineView sv = spline_view(h);
     CandArrays ca;
-    ca.cost = w.dCost.as<double>(); ca.v_last = w.dVlast.as<double>(); ca.travel = w.dTravel.as<double>();
+    ca.cost = w.dCost.as<double>(); ca.parts = w.dParts.as<TilePart>();
     ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
 
     EntryArrays ea;

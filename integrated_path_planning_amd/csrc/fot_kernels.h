@@ -7,9 +7,18 @@
 namespace fot {
 
 // per-candidate arrays in HBM, one slot per candidate (instances padded to multiples of 64)
+// what one tile's wave leaves for the selection: its cheapest 'ok' candidate (index inside the instance, kept samples)
+// and the histogram of its candidates' final statuses (FOT_ST_* 0..7)
+struct TilePart {
+    double cost;
+    int32_t idx, keep;
+    int32_t cnt[8];
+};
+
 struct CandArrays {
-    double *cost, *v_last, *travel;
+    double *cost;                       // per candidate, for fot_debug_candidates: cost, final status, kept samples
     uint8_t *status, *keep;
+    TilePart *parts;                    // [n_tiles of the batch]
 };
 
 // What k_cull leaves per (tile, time step) for k_evaluate: the chunk range the tile's own profiles can reach

@@ -384,13 +384,23 @@ __device__ __forceinline__ float min_sqdist32_f16(const f16 &c, float fx, float 
 // k_evaluate's only parameter, i.e. the layout of its argument segment.  What only rare branches or the epilogue
 // read -- the spline view, the float64 / sample-id entry arrays, the output arrays -- is fetched from the segment at
 // the point of use instead of occupying scalar registers across the time-step loop.
+// Agent-coherent accesses to the candidate arrays: written by one wave, read by the wave that selects for the
+// instance -- possibly on another XCD, whose L2 is a different one.  Relaxed atomic accesses at agent scope are plain
+// loads / stores with the sc1 bit (write-through / read-through the XCD's L2): no L2 writeback or invalidation, which
+// is what an agent-scope fence costs on this multi-XCD part (every wave paying one made the launch 45 % longer).
+template <typename T>
+__device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct EvalKernArgs {
     const DevParams *Pp; SplineView sp; const InstDesc *desc; const InstState *state;
     int row_budget, lds_knots, ablate, n_inst, max_tiles;
     const int32_t *tile_cand0, *tile_n;
     const TileStep *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
-    double *cand_cost, *cand_vlast, *cand_travel; uint8_t *cand_status, *cand_keep;
-    fot_result *out; int32_t *inst_done;             // selection by the wave that finishes an instance's last tile (tile_done)
+    double *cand_cost; uint8_t *cand_status, *cand_keep;      // per candidate: for fot_debug_candidates only
+    TilePart *parts;                                 // per tile: what its wave found (tile_done)
+    fot_result *out; int32_t *inst_done;             // selection by the wave that finishes an instance's last tile
 };
 // k_evaluate's argument segment: EVAL_LEAD_PTRS read-only pointers (passed on their own so that they carry
 // `__restrict__`: only no-alias inputs are certain to keep their loads on the scalar unit), then this struct
@@ -637,7 +647,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
                                               const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
                                               const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32,
                                               const EvalKernArgs &a, const SplineView &sp_lds,
-                                              double *my_rows, int inst, int tile, int lane, int tl_tag,
+                                              double *my_rows, int inst, int tile, int lane, int tl_tag, TilePart &tp,
                                               int sub = 0, int n_sub = 1, double *s_part = nullptr, int grp_tile0 = 0)
 {
     constexpr bool SPLIT = MODE == TILE_SPLIT, GROUP = MODE == TILE_GROUP;
@@ -814,15 +824,28 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
             hit |= __popcll(hit_mask) > D.max_viol;
         }
     }
+    // The candidate's final status (stop-distance filter included, frenet_planner.py:307-324) and, per tile, what the
+    // selection needs: the histogram of the statuses and the cheapest 'ok' candidate (lowest index among equals)
+    int st_final = FOT_ST_DROPPED;
+    ScanBest mine = { INFINITY, -1 };
+    int my_keep = 0;
     if (has_cand) {
         CandResult r;
         finish_candidate(P, D, L, tab, q, g, hit, r);
+        st_final = final_status(r.status, r.v_last, r.travel, D.max_stop);
         const EvalKernArgs &KA = eval_kernargs();
         KA.cand_cost[slot] = r.cost;
-        KA.cand_vlast[slot] = r.v_last;
-        KA.cand_travel[slot] = r.travel;
-        KA.cand_status[slot] = (uint8_t)r.status;
+        KA.cand_status[slot] = (uint8_t)st_final;
         KA.cand_keep[slot] = (uint8_t)r.keep;
+        my_keep = r.keep;
+        if (st_final == FOT_ST_OK) { mine.dist = r.cost; mine.idx = cand0 + lane; }
+    }
+    {
+        const ScanBest best = wave_argmin(mine);                 // every lane of the wave is here
+        tp.cost = best.dist; tp.idx = best.idx;
+        tp.keep = __builtin_amdgcn_readfirstlane(__shfl(my_keep, best.idx >= 0 ? best.idx - cand0 : 0, WAVE));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tp.cnt[c] = __popcll(__ballot(st_final == c));
     }
 #ifdef FOT_TIMELINE
     tl_rows = (uint64_t)__shfl((unsigned long long)tl_rows, 0);
@@ -847,6 +870,14 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 // instance's LAST tile (tile_done below) -- no separate launch behind the evaluation, and the selections of the
 // instances that finish early overlap with the evaluation of the others.  A real function: its registers (final_sample
 // holds an arc tangent) must not count against the time-step loop's.
+__device__ __forceinline__ TilePart tile_part_empty()
+{
+    TilePart t;
+    t.cost = INFINITY; t.idx = -1; t.keep = 0;
+    for (int c = 0; c < 8; ++c) t.cnt[c] = 0;
+    return t;
+}
+
 __device__ __forceinline__ void select_instance_wave(int inst, int lane)
 {
     const EvalKernArgs &KA = eval_kernargs();
@@ -866,24 +897,31 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
         }
         return;
     }
+    // over the instance's tiles (lane = tile): histogram summed, first-minimum arg-min (lowest index wins ties)
     int cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     ScanBest best = { INFINITY, -1 };
-    for (int idx = lane; idx < S.n_cand; idx += WAVE) {
-        const int64_t slot = (int64_t)D.cand_off + idx;
-        int st = KA.cand_status[slot];
-        st = final_status(st, KA.cand_vlast[slot], KA.cand_travel[slot], D.max_stop);
-        KA.cand_status[slot] = (uint8_t)st;
+    int keep_l = 0;
+    for (int t = lane; t < D.n_tiles; t += WAVE) {
+        const TilePart *tpp = KA.parts + D.tile0 + t;
+        const double c_t = ld_agent(&tpp->cost);
+        const int i_t = ld_agent(&tpp->idx), k_t = ld_agent(&tpp->keep);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) cnt[c] += (st == c) ? 1 : 0;
-        if (st == FOT_ST_OK) {
-            const double cost = KA.cand_cost[slot];
-            if (cost < best.dist) { best.dist = cost; best.idx = idx; }   // first strict minimum of this lane
-        }
+        for (int c = 0; c < 8; ++c) cnt[c] += ld_agent(&tpp->cnt[c]);
+        const ScanBest o = { c_t, i_t };
+        const int before = best.idx;
+        scan_merge(best, o);
+        if (best.idx != before) keep_l = k_t;
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         for (int off = 32; off >= 1; off >>= 1) cnt[c] += __shfl_xor(cnt[c], off, WAVE);
-    best = wave_argmin(best);                                              // lowest index wins ties
+    {
+        const int mine_idx = best.idx;
+        best = wave_argmin(best);
+        // the keep of the winning tile: held by the lane whose own best it is
+        const unsigned long long who = __ballot(mine_idx == best.idx && best.idx >= 0);
+        keep_l = who ? __shfl(keep_l, __ffsll((long long)who) - 1, WAVE) : 0;
+    }
     if (lane == 0) {
         R.status = best.idx >= 0 ? FOT_PLAN_OK : FOT_PLAN_NO_PATH;
         R.best_index = best.idx;
@@ -898,7 +936,7 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
         if (lane == 0) { R.n_keep = 0; R.new_last_kappa = D.ego.last_kappa; }
         return;
     }
-    const int keep = KA.cand_keep[(int64_t)D.cand_off + best.idx];
+    const int keep = keep_l;
     const CandDecode cd = decode_candidate(P, D, S.frenet0, best.idx);
     const LonInfo L = profile_info(P, D, S.frenet0, cd.lon_slot, false);
     ComputeTab tab;
@@ -922,18 +960,26 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
     }
 }
 
-// A wave is done with one tile of instance `inst` (its candidates' results are stored, or the tile was empty).  Every
-// tile of the instance arrives exactly once; the wave that completes the count selects.  k_frenet_state zeroes the
-// counters.  Agent-scope release / acquire around the counter: the other tiles' results may come from other CUs.
-__device__ __forceinline__ void tile_done(int inst, int lane)
+// A wave is done with tile `tile` of instance `inst`: it leaves what it found (tp; empty for a tile without candidates)
+// and counts itself.  Every tile of the instance arrives exactly once; the wave that completes the count selects.
+// k_frenet_state zeroes the counters.  The partial results travel as agent-coherent stores / loads (st_agent,
+// ld_agent): once this wave's stores are acknowledged (vmcnt) they are visible to every CU, so the count needs no fence.
+__device__ __forceinline__ void tile_done(int inst, int tile, int lane, const TilePart &tp)
 {
     const EvalKernArgs &KA = eval_kernargs();
-    __threadfence();                                              // this wave's stores, before the count
+    if (lane == 0) {
+        TilePart *dst = KA.parts + KA.desc[inst].tile0 + tile;
+        st_agent(&dst->cost, tp.cost); st_agent(&dst->idx, tp.idx); st_agent(&dst->keep, tp.keep);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) st_agent(&dst->cnt[c], tp.cnt[c]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores, before the count
     int last = 0;
-    if (lane == 0) last = atomicAdd(&KA.inst_done[inst], 1) == KA.desc[inst].n_tiles - 1 ? 1 : 0;
+    if (lane == 0)
+        last = __hip_atomic_fetch_add(&KA.inst_done[inst], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+               == KA.desc[inst].n_tiles - 1 ? 1 : 0;
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
-    __threadfence();                                              // the count, before the other waves' results are read
     select_instance_wave(inst, lane);
 }
 
@@ -978,9 +1024,10 @@ k_evaluate(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int inst = x + N_XCD * j;
     const int n_tiles = desc[inst].n_tiles;
     if (pos >= n_tiles) return;                                  // a shorter lattice than the batch's longest
+    TilePart tp = tile_part_empty();
     evaluate_tile<TILE_WAVE>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, my_rows, inst,
-                         n_tiles - 1 - pos, lane, x);
-    tile_done(inst, lane);
+                         n_tiles - 1 - pos, lane, x, tp);
+    tile_done(inst, n_tiles - 1 - pos, lane, tp);
 }
 
 // The same for a handful of egos (fewer tiles than the GPU has SIMDs): a tile alone on its SIMD is a chain of
@@ -1008,9 +1055,10 @@ k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
     const int n_tiles = desc[inst].n_tiles;
     if (pos >= n_tiles) return;
     const int tile = n_tiles - 1 - pos;
+    TilePart tp = tile_part_empty();
     evaluate_tile<TILE_SPLIT>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile, lane, x,
-                              seg, n_seg, s_part);
-    if (seg == 0) tile_done(inst, lane);                         // (the wave that merged the segments and stored the results)
+                              tp, seg, n_seg, s_part);
+    if (seg == 0) tile_done(inst, tile, lane, tp);               // (the wave that merged the segments and holds the results)
 }
 
 // The grouped cut (fot_math.hpp): one workgroup per group of GROUP_TILES tiles, one shared row table, four such
@@ -1035,9 +1083,10 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
     const int n_groups = desc[inst].n_tiles / GROUP_TILES;
     if (pos >= n_groups) return;                                 // a shorter lattice than the batch's longest
     const int tile0 = (n_groups - 1 - pos) * GROUP_TILES;
+    TilePart tp = tile_part_empty();
     evaluate_tile<TILE_GROUP>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile0 + wv,
-                              lane, x, wv, GROUP_TILES, nullptr, tile0);
-    tile_done(inst, lane);
+                              lane, x, tp, wv, GROUP_TILES, nullptr, tile0);
+    tile_done(inst, tile0 + wv, lane, tp);
 }
 
 // ---------------------------------------------------------------------------
@@ -1681,7 +1730,7 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     a.n_inst = n_inst; a.max_tiles = tiles.max_tiles;
     a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
-    a.cand_cost = c.cost; a.cand_vlast = c.v_last; a.cand_travel = c.travel; a.cand_status = c.status; a.cand_keep = c.keep;
+    a.cand_cost = c.cost; a.cand_status = c.status; a.cand_keep = c.keep; a.parts = c.parts;
     a.out = out; a.inst_done = inst_done;
     if (tiles.n_tiles <= 0) {
         k_select_only<<<(unsigned)n_inst, WAVE, 0, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
