@@ -52,6 +52,17 @@ sys.path.insert(0, ROOT)
 
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                 # MI355X peak engine clock
+# Issue cost of one wave64 vector instruction on a SIMD that holds at least two waves, in cycles
+# (MI355X_MICROARCH.md constants table: v_fma_f32 2, transcendental 8, fp64 at half rate; the other classes measured with
+# scripts/micro/issue_bench.hip on the same part, profiles/r03_issue_costs.jsonl, relative to v_add_f32 = 2:
+# compares / three-source VOP3 / packed-float32 / moves of 64-bit pairs 3.5-4, v_readlane 4).
+ISSUE_CYCLES = {"f64": 4.0, "trans_f64": 16.0, "f32": 2.0, "trans_f32": 8.0, "int": 2.0, "cvt": 4.0, "other": 3.5}
+ISSUE_CLASSES = {"f64": ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"),
+                 "trans_f64": ("SQ_INSTS_VALU_TRANS_F64",),
+                 "f32": ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"),
+                 "trans_f32": ("SQ_INSTS_VALU_TRANS_F32",),
+                 "int": ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"),
+                 "cvt": ("SQ_INSTS_VALU_CVT",)}
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, MI355X_MICROARCH.md "8 TB/s peak (spec)"
 # algorithmic HBM bytes per candidate of config 3/4/5
 B_ALG = 119.0
@@ -364,13 +375,18 @@ def main():
         return (d[hit], hit) if hit else ({}, None)
 
     traffic_d, traffic_fresh = committed("traffic.json")
+    inst_launch = n_inst / launches_per_step                       # instances one launch of the dominant kernel handles
+    prof_inst_t = int((traffic_d or {}).get("_meta", {}).get("instances_per_launch", 256))
     traffic = of_kernel(traffic_d, dom)[0].get("hbm_bytes_gfx950_corrected") if traffic_fresh else None
+    if traffic is not None:
+        traffic = traffic * inst_launch / prof_inst_t               # (counted per launch of prof_inst_t instances)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
                 "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "candidates_per_launch": cand_launch, "launches_per_step": launches_per_step,
                 "measured_in": "serial leg (one plan call in flight)",
-                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources)"
+                "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources; "
+                                   "counted on %d instances per launch, scaled to this launch's %d)" % (prof_inst_t, int(inst_launch))
                                    if traffic is not None else
                                    "null: profiles/traffic.json was taken on other kernel sources (hash mismatch)"
                                    if traffic_d else "null: no committed profile"),
@@ -378,24 +394,43 @@ def main():
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     if traffic is not None:
         roofline["achieved_from_traffic"] = traffic / (dom_ms * 1e-3) / 1e9
-    # what the kernel actually issues (rocprofv3 --pmc SQ_INSTS_VALU, profiles/): the time its vector instructions
-    # alone would take at one wave64 instruction per 4 cycles per SIMD, against the measured launch time
+    # What the kernel actually issues (rocprofv3 --pmc, profiles/pmc.json): its vector instructions BY CLASS, each class
+    # weighted with its issue cost on a SIMD that holds two or more waves (ISSUE_CYCLES) -- the time the vector pipes
+    # would need for exactly this instruction stream -- against the measured launch time.  Next to it, from the same
+    # profile: how busy the VALU pipes were and how many waves a SIMD held on average (SQ_* count quad-cycles).
     issue = None
     pmc_d, pmc_fresh = committed("pmc.json")
     pmc_k, pmc_name = of_kernel(pmc_d, dom)
     if "SQ_INSTS_VALU" in pmc_k:
         prof_inst = int(pmc_d.get("_meta", {}).get("instances_per_launch", 256))
-        n_valu = float(pmc_k["SQ_INSTS_VALU"]) * (n_inst / launches_per_step) / prof_inst    # (the work is per instance)
-        issue_ms = n_valu * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
+        scale = inst_launch / prof_inst                              # (the work is per instance)
+        n_valu = float(pmc_k["SQ_INSTS_VALU"])
+        by_class = {c: sum(float(pmc_k.get(k, 0.0)) for k in ks) for c, ks in ISSUE_CLASSES.items()}
+        have_classes = any(k in pmc_k for ks in ISSUE_CLASSES.values() for k in ks)
+        by_class["other"] = max(n_valu - sum(by_class.values()), 0.0) if have_classes else 0.0
+        if have_classes:
+            cycles = sum(by_class[c] * ISSUE_CYCLES[c] for c in by_class)
+        else:                                                        # an old profile without the class counters
+            cycles = n_valu * 4.0
+        issue_ms = cycles * scale / (N_SIMD * CLOCK_HZ) * 1e3
         issue = {"kernel": dom, "bound": "valu_issue", "unit": "ms", "achieved": issue_ms, "peak": dom_ms,
-                 "frac": issue_ms / dom_ms, "valu_instructions_per_launch": n_valu, "cycles_per_instruction": 4,
+                 "frac": issue_ms / dom_ms, "valu_instructions_per_launch": n_valu * scale,
+                 "instructions_by_class": {c: v * scale for c, v in by_class.items()} if have_classes else None,
+                 "cycles_per_instruction_by_class": ISSUE_CYCLES if have_classes else {"all": 4.0},
+                 "mean_cycles_per_instruction": cycles / n_valu if n_valu else None,
                  "simds": N_SIMD, "clock_ghz": CLOCK_HZ / 1e9,
                  "profiled_kernel": pmc_name,
                  "source": "profiles/pmc.json" + (" (%s)" % pmc_d.get("_meta", {}).get("tag", "?")),
                  "source_matches_build": pmc_fresh,
-                 "note": "executed VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over the measured launch "
-                         "time of the serial leg; counted on %d instances per launch, scaled to this launch's %d" %
-                         (prof_inst, int(n_inst / launches_per_step))}
+                 "note": "sum over instruction classes of executed VALU wave-instructions x issue cycles of the class / "
+                         "(1024 SIMDs x 2.4 GHz) over the measured launch time of the serial leg; counted on %d instances "
+                         "per launch, scaled to this launch's %d" % (prof_inst, int(inst_launch))}
+        prof_ms = pmc_d.get("_meta", {}).get("kernel_ms", {}).get(pmc_name)      # the launch time IN the profiled run
+        if prof_ms and "SQ_ACTIVE_INST_VALU" in pmc_k and "SQ_WAVE_CYCLES" in pmc_k:
+            simd_cycles = N_SIMD * prof_ms * 1e-3 * CLOCK_HZ
+            issue["valu_busy"] = float(pmc_k["SQ_ACTIVE_INST_VALU"]) * 4.0 / simd_cycles
+            issue["resident_waves_per_simd"] = float(pmc_k["SQ_WAVE_CYCLES"]) * 4.0 / simd_cycles
+            issue["profiled_launch_ms"] = prof_ms
     kernels = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items() if v["launches"]}
 
     # ---- parity spot check against the oracle (checker only, outside the timed region)

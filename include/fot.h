@@ -225,6 +225,11 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
  * (synchronises the device); applies to the handle's later plan calls. */
 int fot_debug_set_tile_cut(fot_handle *h, int32_t cut);
 
+/* FrenetPlanner._build_time_cache (frenet_planner.py:586-617) as the library holds it for a horizon of `time`
+ * seconds: the sample count n_t = round(time / dt) + 1 and the closed-form inverses of the quartic / quintic
+ * boundary-value matrices (row-major 2x2 and 3x3) that every lattice polynomial is solved with.  Host only. */
+int fot_debug_time_info(const fot_handle *h, double time, int32_t *n_t, double *quartic_inv4, double *quintic_inv9);
+
 /* FrenetPlanner._path_is_collision_free (frenet_planner.py:1035-1233) for n_paths externally
  * supplied paths against ONE obstacle set.  x, y, yaw, t: [n_paths][FOT_MAX_NT] host, len[n_paths];
  * static_xy [n_static][2] double host; dyn [S][P][T][2] double host with mode as in dyn_dims.
@@ -293,10 +298,12 @@ int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const 
                              int32_t use_footprint, fot_safety *out);
 
 /* ---- compact wire form of the records, for the all-gather of selected paths across GPUs ------------
- * fot_result is the host view (float64, FOT_MAX_NT slots per array: 7 856 bytes).  On the wire a record is
+ * fot_result is the host view (float64, FOT_MAX_NT slots per array: 15 536 bytes).  On the wire a record is
  *   fot_wire_header (176 bytes) | float path[15][n_total] (fot_result array order t .. c) | padding to 256 bytes
  * e.g. 3 328 bytes at n_total = 51.  The header keeps cost, the state updates and the Frenet start state in float64;
- * the path samples travel as float32 (2^-24 relative: 6e-6 m at 100 m, inside the 1e-5 the north star allows).
+ * the path samples travel as float32, s / x / y as OFFSETS from the record's own start (frenet0[0], ref0[1], ref0[2]):
+ * 2^-24 of the path's length (4e-6 m at 70 m) at any world coordinate, inside the 1e-5 the north star allows; the
+ * other arrays are small numbers (d, speeds, curvature).  Samples past n_keep are zero.
  * n_total = round(max_t / dt) + 1 of the planner (fot_wire_n_total).  Pack / unpack on the host are pure format
  * conversions (no GPU); fot_pack_records_device converts device-resident records on `stream`. */
 typedef struct fot_wire_header {

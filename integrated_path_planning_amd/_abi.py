@@ -99,7 +99,7 @@ LIB_PATH = os.path.join(_HERE, "libfot.so")
 SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_set_path_waypoints",
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
-           "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
+           "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
            "fot_predict_cv", "fot_safety_metrics_batch", "fot_wire_n_total", "fot_wire_record_bytes",
            "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 3                      # FOT_PROFILE_KERNELS (include/fot.h)
@@ -116,15 +116,50 @@ class FotError(RuntimeError):
         self.code = code
 
 
-HIP_SONAME = "libamdhip64.so.7"          # what libfot.so carries as DT_NEEDED
 hip_runtime_path = None                  # which HIP runtime lib() bound libfot to (diagnostics / tests)
+
+
+def _needed_sonames(path):
+    """DT_NEEDED entries of an ELF64 shared object (what the loader will ask for), read from the file itself."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return []
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    out = []
+    for sec in secs:
+        if sec[1] != 6:                                          # SHT_DYNAMIC
+            continue
+        strtab = secs[sec[6]]                                    # sh_link: its string table
+        for off in range(sec[4], sec[4] + sec[5], 16):
+            tag, val = struct.unpack_from("<qQ", data, off)
+            if tag == 1:                                         # DT_NEEDED
+                beg = strtab[4] + val
+                out.append(data[beg:data.index(b"\0", beg)].decode())
+            if tag == 0:
+                break
+    return out
+
+
+def hip_soname():
+    """The HIP runtime SONAME libfot.so was linked against (its DT_NEEDED), e.g. libamdhip64.so.7."""
+    try:
+        for n in _needed_sonames(LIB_PATH):
+            if n.startswith("libamdhip64"):
+                return n
+    except OSError:
+        pass
+    return "libamdhip64.so"
 
 
 def _bind_hip_runtime():
     """ONE HIP runtime per process, whatever the import order.
 
     PyTorch-ROCm ships its own HIP + HSA runtime in ``torch/lib`` and asks for it by FILE name (``libamdhip64.so``,
-    found through its RPATH); libfot asks for the SONAME ``libamdhip64.so.7``.  If libfot came first the loader would
+    found through its RPATH); libfot asks for a versioned SONAME (``hip_soname()``, e.g. ``libamdhip64.so.7``).  If libfot came first the loader would
     pick the system copy for it and later a second, different copy for torch -- two HSA runtimes in one process, and
     the second one finds no GPU.  So before libfot is opened: (1) a runtime that is already in the process is reused
     (the loader matches libfot's DT_NEEDED against its SONAME); (2) otherwise, when this interpreter has a torch
@@ -132,7 +167,7 @@ def _bind_hip_runtime():
     the loader's normal search (the system ROCm) applies.  torch itself is NOT imported here."""
     global hip_runtime_path
     noload = getattr(os, "RTLD_NOLOAD", 4)
-    for name in (HIP_SONAME, "libamdhip64.so"):
+    for name in (hip_soname(), "libamdhip64.so"):
         try:
             C.CDLL(name, mode=noload | os.RTLD_NOW)
             hip_runtime_path = f"(already loaded: {name})"
@@ -189,6 +224,7 @@ def lib():
     L.fot_debug_margins.argtypes = [vp, C.c_int32, C.c_int32, dp]
     L.fot_debug_set_eval_segments.argtypes = [vp, C.c_int32]
     L.fot_debug_set_tile_cut.argtypes = [vp, C.c_int32]
+    L.fot_debug_time_info.argtypes = [vp, C.c_double, ip, dp, dp]
     L.fot_check_paths.argtypes = [vp, C.c_int32, ip, ip] + [dp] * 9 + [C.POINTER(Overrides), C.c_double, C.c_int32, dp,
                                                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip]
     L.fot_resample_n_dense.argtypes = [C.POINTER(ResampleParams), C.c_int32]

@@ -272,17 +272,27 @@ class BatchedClosedLoop:
     MAX_REPLAN = 3                                               # integrated_simulator.py:383
 
     def __init__(self, config, ped_tracks: Sequence[np.ndarray], ego_initial_states: Optional[Sequence] = None,
-                 device: int = -1, engine=None, resampler=None):
+                 device: int = -1, engine=None, resampler=None, sample_source=None):
+        """sample_source: the multi-sample predictor in front of the planner -- a callable
+        ``(obs_last [P, 2], obs_prev [P, 2]) -> raw samples [S, pred_len, P, 2]`` at the predictor's own time step
+        (what S forward passes of Social-GAN on PyTorch-ROCm return for the pedestrians of all running episodes; the
+        tests script one).  With it the episodes plan against the whole distribution when the configuration says
+        ``distribution_aware_planning`` (integrated_simulator.py:459-460, 514-525), otherwise against the sample closest
+        to the mean (``predict_single_best``, trajectory_predictor.py:340-352).  None: the constant-velocity predictor."""
         self.config = config if not isinstance(config, dict) else _Cfg(config)
         c = self.config
         self.dt = float(c.dt)
         self.ego_radius = getattr(c, "ego_radius", 1.0)
         self.ped_radius = getattr(c, "ped_radius", 0.3)
         self.footprint = footprint_from_config(c)
-        if getattr(c, "prediction_method", "sgan") != "cv":
-            raise NotImplementedError("only the constant-velocity predictor is part of this build (SURVEY 8 f1)")
-        if getattr(c, "distribution_aware_planning", False):
-            raise NotImplementedError("the cv predictor yields one sample: no distribution to plan against")
+        self.sample_source = sample_source
+        if sample_source is None and getattr(c, "prediction_method", "sgan") != "cv":
+            raise NotImplementedError("the Social-GAN / LSTM networks are not part of this build (SURVEY 8 f1): hand "
+                                      "their samples in through sample_source, or use prediction_method='cv'")
+        self.distribution_aware = bool(getattr(c, "distribution_aware_planning", False))
+        if self.distribution_aware and sample_source is None:
+            raise ValueError("distribution_aware_planning needs a multi-sample predictor (sample_source): the "
+                             "constant-velocity predictor yields one sample")
         self.static_obstacle_points = expand_static_obstacles(getattr(c, "static_obstacles", None), step=0.5)
         # engine / resampler: objects with BatchPlanner's / PredictionResampler's methods; the tests drive the
         # host logic with stand-ins when there is no GPU, the product always builds the libfot handle below
@@ -387,25 +397,42 @@ class BatchedClosedLoop:
                                               use_footprint=self.footprint is not None)
 
     def _predict(self, sel, off, pos):
-        """_update_prediction (:424-527): one CV launch over the pedestrians of all running episodes.  Returns the
-        prediction [sum P, T, 2] (None while the observer fills) and, per episode, whether the current positions are
-        prepended (:503-511)."""
+        """_update_prediction (:424-527): one launch over the pedestrians of all running episodes.  Returns the
+        prediction [sum P, T, 2] (None while the observer fills), per episode whether the current positions are
+        prepended (:503-511), and the whole distribution [S, sum P, T, 2] (None unless a sample source predicts)."""
         t0 = time.perf_counter()
-        pred = None
+        pred, dist = None, None
         if self.observer.is_ready:
             rows = self._rows_of(sel)
             hist = self.observer.history
-            obs = np.stack([hist[-2][rows], hist[-1][rows]], axis=0)          # CV reads the last two samples
+            obs = np.stack([hist[-2][rows], hist[-1][rows]], axis=0)          # the last two samples
             last = self.observer.last_sample_time
             stale = max(self.ped_time - last, 0.0) if last is not None else 0.0
-            pred = self.resampler.predict_cv(obs, staleness=stale, float32_observations=True)
+            if self.sample_source is None:
+                pred = self.resampler.predict_cv(obs, staleness=stale, float32_observations=True)
+            else:
+                # the observer hands over float32 tensors (observer.py:134); the samples are resampled to the
+                # simulation step on the device (process_prediction, :233-313), all pedestrians in one launch
+                o32 = obs.astype(np.float32).astype(np.float64)
+                raw = np.asarray(self.sample_source(o32[1], o32[0]), dtype=np.float64)       # [S, pred_len, sum P, 2]
+                dist = self.resampler.process_prediction(raw, anchor_pos=o32[1], staleness=stale)
+                if raw.shape[0] == 1:
+                    pred, dist = dist[0], None
+                else:
+                    # predict_single_best (:340-352), per episode: the sample closest to the sample mean over the
+                    # episode's own pedestrians
+                    dev = np.linalg.norm(dist - dist.mean(axis=0)[None], axis=-1).sum(axis=2)      # [S, sum P]
+                    per_ep = np.add.reduceat(dev, off[:-1], axis=1) if dev.shape[1] else np.zeros((len(dist), len(sel)))
+                    per_ep[:, off[:-1] == off[1:]] = 0.0                                      # (episodes without pedestrians)
+                    best = np.argmin(per_ep, axis=0)                                         # [episodes]
+                    pred = dist[np.repeat(best, off[1:] - off[:-1]), np.arange(dist.shape[1])]
         t_pred = (time.perf_counter() - t0) / len(sel)
         if pred is None:
-            return None, np.zeros(len(sel), bool), t_pred
+            return None, np.zeros(len(sel), bool), t_pred, None
         # np.allclose(pred[:, 0], current) of the reference (rtol 1e-5, atol 1e-8; finite inputs), per episode
         close = np.all(np.abs(pred[:, 0, :] - pos) <= 1e-8 + 1e-5 * np.abs(pos), axis=1)
         same = np.logical_and.reduceat(close, off[:-1]) if len(close) else np.zeros(len(sel), bool)
-        return pred, ~same, t_pred
+        return pred, ~same, t_pred, dist if self.distribution_aware else None
 
     # ------------------------------------------------------------------------------------------------------
     def step(self) -> int:
@@ -420,7 +447,7 @@ class BatchedClosedLoop:
         off = np.concatenate([[0], np.cumsum(counts)])
         pos = self._ped_frame("trajectories", sel)
         vel = self._ped_frame("velocities", sel)
-        pred, prepend, t_pred = self._predict(sel, off, pos)          # 2. prediction
+        pred, prepend, t_pred, dist = self._predict(sel, off, pos)    # 2. prediction
         m = self._metrics(sel, off, pos, vel)                         # 3. planning cycle (:529-653)
         t0 = time.perf_counter()
         clearance, clearance_ahead = m["clearance"].copy(), m["clearance_ahead"].copy()
@@ -445,7 +472,20 @@ class BatchedClosedLoop:
             dyn[~ped_pre, :-1] = pred[~ped_pre]
             t_len = np.where(prepend, T1, T1 - 1)
         T_alloc = dyn.shape[1]
-        if t_len.min() != T_alloc:                                    # mixed case: per-episode [P, t_len, 2] blocks
+        n_smp = np.ones(n, np.int64)
+        mode = np.where(counts > 0, 1, 0)
+        if dist is not None:
+            # the planner consumes the whole distribution (:622-630); the current positions lead EVERY sample,
+            # whatever the single sample's prepend decided (:514-525): per episode a [S, P, T + 1, 2] block
+            S_ = dist.shape[0]
+            full = np.concatenate([np.broadcast_to(pos[None, :, None, :], (S_, len(pos), 1, 2)), dist], axis=2)
+            blocks = [np.ascontiguousarray(full[:, off[i]:off[i + 1]]).reshape(-1, 2) for i in range(n)]
+            d_xy = np.concatenate(blocks, axis=0) if blocks else np.empty((0, 2))
+            t_len = np.full(n, full.shape[2], np.int64)
+            d_off_ep = np.concatenate([[0], np.cumsum(S_ * counts * t_len)])[:-1]
+            n_smp = np.full(n, S_, np.int64)
+            mode = np.where(counts > 0, 2, 0)
+        elif t_len.min() != T_alloc:                                  # mixed case: per-episode [P, t_len, 2] blocks
             blocks = [np.ascontiguousarray(dyn[off[i]:off[i + 1], :t_len[i]]).reshape(-1, 2) for i in range(n)]
             d_xy = np.concatenate(blocks, axis=0)
             d_off_ep = np.concatenate([[0], np.cumsum(counts * t_len)])[:-1]
@@ -466,7 +506,7 @@ class BatchedClosedLoop:
             ego["prev_s"] = np.where(chain | np.isnan(prev_s), 0.0, prev_s)
             s_xy = np.tile(pts, (r, 1)) if len(pts) else None
             s_off = np.arange(r + 1, dtype=np.int64) * len(pts) if len(pts) else None
-            d_dims = np.stack([np.where(counts[who] > 0, 1, 0), np.ones(r, np.int64), counts[who], t_len[who]], axis=1)
+            d_dims = np.stack([mode[who], n_smp[who], counts[who], t_len[who]], axis=1)
             return self.engine.plan_arrays(ego, tgt, ov, stop, s_xy, s_off, d_xy, d_off_ep[who], d_dims)
 
         rec = plan(everyone, st0, sm.clear_ahead[sel], self.prev_s[sel], np.zeros(n, bool))

@@ -964,8 +964,11 @@ int fot_pack_records_host(int32_t n_total, int32_t n, const fot_result *records,
         std::memcpy(w, &H, sizeof(H));
         float *path = (float *)(w + sizeof(H));
         const double *arr = R.t;
-        for (int f = 0; f < 15; ++f)
-            for (int k = 0; k < n_total; ++k) path[f * n_total + k] = (float)arr[f * FOT_MAX_NT + k];
+        for (int f = 0; f < 15; ++f) {                           // (k_pack_wire: offsets for s, x, y; zeros past n_keep)
+            const double base = f == 1 ? R.frenet0[0] : f == 9 ? R.ref0[1] : f == 10 ? R.ref0[2] : 0.0;
+            for (int k = 0; k < n_total; ++k)
+                path[f * n_total + k] = k < R.n_keep ? (float)(arr[f * FOT_MAX_NT + k] - base) : 0.0f;
+        }
     }
     return FOT_OK;
 }
@@ -992,8 +995,10 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
         const float *path = (const float *)(w + sizeof(H));
         double *arr = R.t;
         const int keep = H.n_keep < n_total ? H.n_keep : n_total;
-        for (int f = 0; f < 15; ++f)
-            for (int k = 0; k < keep; ++k) arr[f * FOT_MAX_NT + k] = (double)path[f * n_total + k];
+        for (int f = 0; f < 15; ++f) {
+            const double base = f == 1 ? R.frenet0[0] : f == 9 ? R.ref0[1] : f == 10 ? R.ref0[2] : 0.0;
+            for (int k = 0; k < keep; ++k) arr[f * FOT_MAX_NT + k] = base + (double)path[f * n_total + k];
+        }
     }
     return FOT_OK;
 }
@@ -1013,6 +1018,17 @@ int fot_debug_set_tile_cut(fot_handle *h, int32_t cut)
         return fail(h, FOT_ERR_INVALID, "fot_debug_set_tile_cut: 0 (automatic), 1 (per-wave rows), 2 (groups)");
     if (cut == h->tile_cut) return FOT_OK;
     return upload_tile_shapes(h, cut);
+}
+
+int fot_debug_time_info(const fot_handle *h, double time, int32_t *n_t, double *quartic_inv4, double *quintic_inv9)
+{
+    if (!h || !(time > 0.0)) return FOT_ERR_INVALID;
+    TimeInfo ti;
+    if (!time_info(time, h->params.dt, ti)) return FOT_ERR_UNSUPPORTED;      // more than FOT_MAX_NT samples
+    if (n_t) *n_t = ti.n_t;
+    if (quartic_inv4) std::memcpy(quartic_inv4, ti.qa, sizeof(ti.qa));
+    if (quintic_inv9) std::memcpy(quintic_inv9, ti.qi, sizeof(ti.qi));
+    return FOT_OK;
 }
 
 int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)

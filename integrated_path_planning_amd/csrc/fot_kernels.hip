@@ -1439,8 +1439,14 @@ k_pack_wire(int n, int n_total, int stride, const fot_result *__restrict__ src, 
     if (lane < 6) { H->frenet0[lane] = R.frenet0[lane]; H->ref0[lane] = R.ref0[lane]; }
     float *path = (float *)(w + sizeof(fot_wire_header));
     const double *arr = R.t;                                  // the 15 arrays are contiguous, FOT_MAX_NT doubles each
-    for (int f = 0; f < 15; ++f)
-        for (int k = lane; k < n_total; k += WAVE) path[f * n_total + k] = (float)arr[f * FOT_MAX_NT + k];
+    // s, x and y travel as offsets from the record's own start state (s0, reference point): float32 then resolves the
+    // path to 2^-24 of its LENGTH (4e-6 m at 70 m), wherever in the world it lies; samples past n_keep are zero
+    const int keep = R.n_keep;
+    for (int f = 0; f < 15; ++f) {
+        const double base = f == 1 ? R.frenet0[0] : f == 9 ? R.ref0[1] : f == 10 ? R.ref0[2] : 0.0;
+        for (int k = lane; k < n_total; k += WAVE)
+            path[f * n_total + k] = k < keep ? (float)(arr[f * FOT_MAX_NT + k] - base) : 0.0f;
+    }
     // padding bytes stay as they are (never read)
 }
 

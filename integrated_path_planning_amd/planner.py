@@ -20,8 +20,39 @@ from .data_structures import EgoVehicleState, FrenetPath, FrenetState
 from .params import (D_ROAD_W, D_T_S, DT, MAX_ACCEL, MAX_CURVATURE, MAX_ROAD_WIDTH, MAX_SPEED, MAX_T, MIN_T,
                      N_S_SAMPLE, ROBOT_RADIUS, TARGET_SPEED, make_params)
 
+from dataclasses import dataclass
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
+
+
+# carrier types of the reference's polynomial builders (frenet_planner.py:95-123), for the shim's views of them
+@dataclass(frozen=True)
+class TimeCache:
+    t: np.ndarray
+    t2: np.ndarray
+    t3: np.ndarray
+    t4: np.ndarray
+    t5: np.ndarray
+    quartic_A_inv: np.ndarray
+    quintic_A_inv: np.ndarray
+
+
+@dataclass(frozen=True)
+class LongitudinalProfile:
+    t: np.ndarray
+    s: np.ndarray
+    s_d: np.ndarray
+    s_dd: np.ndarray
+    s_ddd: np.ndarray
+
+
+@dataclass(frozen=True)
+class LateralProfile:
+    d: np.ndarray
+    d_d: np.ndarray
+    d_dd: np.ndarray
+    d_ddd: np.ndarray
 
 
 def _as_dp(a: np.ndarray):
@@ -318,6 +349,14 @@ class BatchPlanner:
         cut = {"auto": 0, "wave": 1, "group": 2}.get(cut, cut)
         _abi.check(self._h, self._lib.fot_debug_set_tile_cut(self._h, int(cut)))
 
+    def time_info(self, time: float):
+        """(n_t, quartic inverse [2, 2], quintic inverse [3, 3]) the library solves a horizon of ``time`` seconds with
+        (``fot_debug_time_info``)."""
+        n_t = C.c_int32(0)
+        qa, qi = np.zeros(4), np.zeros(9)
+        _abi.check(self._h, self._lib.fot_debug_time_info(self._h, float(time), C.byref(n_t), _as_dp(qa), _as_dp(qi)))
+        return int(n_t.value), qa.reshape(2, 2), qi.reshape(3, 3)
+
     def candidate_path(self, index: int, inst: int = 0) -> FrenetPath:
         """Candidate ``index`` of the last plan call as generated + converted, before truncation."""
         arr = np.zeros((15, _abi.MAX_NT))
@@ -580,6 +619,45 @@ class FrenetPlanner:
     # look at, not a path plan() takes.
     _FRENET_FIELDS = ("t", "s", "s_d", "s_dd", "s_ddd", "d", "d_d", "d_dd", "d_ddd")
     _CART_FIELDS = ("x", "y", "yaw", "v", "a", "c")
+
+    # --- the reference's polynomial builders, as views (its test-suite calls them; plan() never does: the lattice is
+    # generated on the device).  The boundary-value inverses are the library's own closed forms.
+    def _build_time_cache(self, time: float) -> "TimeCache":
+        """frenet_planner.py:586-617: inclusive sample grid of the horizon, its powers, the two inverses."""
+        n_t, qa, qi = self._engine.time_info(time)
+        t = np.arange(n_t) * self.dt
+        t2 = t * t
+        return TimeCache(t=t, t2=t2, t3=t2 * t, t4=t2 * t2, t5=t2 * t2 * t, quartic_A_inv=qa, quintic_A_inv=qi)
+
+    def _build_longitudinal_profiles(self, frenet_state, target_velocities, time: float, time_cache) -> list:
+        """frenet_planner.py:619-658: one quartic per terminal speed (s(0), s'(0), s''(0) from the state; s'(T) = tv,
+        s''(T) = 0), sampled on the cache's grid."""
+        tc = time_cache
+        a0, a1, a2 = frenet_state.s, frenet_state.s_d, frenet_state.s_dd / 2.0
+        out = []
+        for tv in np.asarray(target_velocities, dtype=float):
+            a3, a4 = tc.quartic_A_inv @ np.array([tv - a1 - 2.0 * a2 * time, -2.0 * a2])
+            out.append(LongitudinalProfile(
+                t=tc.t, s=a0 + a1 * tc.t + a2 * tc.t2 + a3 * tc.t3 + a4 * tc.t4,
+                s_d=a1 + 2.0 * a2 * tc.t + 3.0 * a3 * tc.t2 + 4.0 * a4 * tc.t3,
+                s_dd=2.0 * a2 + 6.0 * a3 * tc.t + 12.0 * a4 * tc.t2, s_ddd=6.0 * a3 + 24.0 * a4 * tc.t))
+        return out
+
+    def _build_lateral_profiles(self, frenet_state, lateral_offsets, time: float, time_cache) -> list:
+        """frenet_planner.py:660-701: one quintic per lateral target (d, d', d'' from the state; d(T) = di,
+        d'(T) = d''(T) = 0)."""
+        tc = time_cache
+        a0, a1, a2 = frenet_state.d, frenet_state.d_d, frenet_state.d_dd / 2.0
+        out = []
+        for di in np.asarray(lateral_offsets, dtype=float):
+            a3, a4, a5 = tc.quintic_A_inv @ np.array([di - a0 - a1 * time - a2 * time * time, -a1 - 2.0 * a2 * time,
+                                                      -2.0 * a2])
+            out.append(LateralProfile(
+                d=a0 + a1 * tc.t + a2 * tc.t2 + a3 * tc.t3 + a4 * tc.t4 + a5 * tc.t5,
+                d_d=a1 + 2.0 * a2 * tc.t + 3.0 * a3 * tc.t2 + 4.0 * a4 * tc.t3 + 5.0 * a5 * tc.t4,
+                d_dd=2.0 * a2 + 6.0 * a3 * tc.t + 12.0 * a4 * tc.t2 + 20.0 * a5 * tc.t3,
+                d_ddd=6.0 * a3 + 24.0 * a4 * tc.t + 60.0 * a5 * tc.t2))
+        return out
 
     def _lattice_from(self, frenet_state, target_speed):
         fs = frenet_state

@@ -68,8 +68,8 @@ def main():
         pmc[k] = {"launches_fetch_pass": fetch.get(k, (0, 0))[1], "launches_write_pass": write.get(k, (0, 0))[1],
                   "FETCH_SIZE_bytes_per_launch": fb, "WRITE_SIZE_bytes_per_launch": wb}
         traffic[k] = {"fetch_bytes_reported": fb, "write_bytes": wb, "hbm_bytes_gfx950_corrected": 2.0 * fb + wb}
-    for path in (glob.glob(os.path.join(root, "sq", "**", "*counter_collection.csv"), recursive=True)
-                 + glob.glob(os.path.join(root, "sq2", "**", "*counter_collection.csv"), recursive=True)):
+    for path in sum((glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True)
+                     for d in ("sq", "sq2", "sq3", "sq4")), []):
         acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
         with open(path) as f:
             for row in csv.DictReader(f):
@@ -80,7 +80,14 @@ def main():
         for k, cs in acc.items():
             pmc.setdefault(k, {}).update({c: v[0] / v[1] for c, v in cs.items() if v[1]})
     # which build and workload the counters belong to: bench.py only trusts them for the same kernel sources
-    meta = {"tag": tag, "source_hash": kernel_source_hash(),
+    kernel_ms = {}
+    for path in glob.glob(os.path.join(out, f"{tag}_kernel_stats.csv")):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row.get("Name", ""))
+                if k.startswith("k_") and row.get("AverageNs"):
+                    kernel_ms[k] = float(row["AverageNs"]) * 1e-6
+    meta = {"tag": tag, "source_hash": kernel_source_hash(), "kernel_ms": kernel_ms,
             "instances_per_launch": int(os.environ.get("FOT_PROFILE_INSTANCES", "256")),
             "bench_args": os.environ.get("FOT_PROFILE_ARGS", "")}
     pmc["_meta"] = meta

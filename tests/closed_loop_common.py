@@ -21,6 +21,14 @@ def load_episodes():
     return d
 
 
+def load_dist_episodes():
+    """distribution-aware episodes (tests/golden/make_closed_loop_distribution.py)"""
+    z = np.load(os.path.join(GOLDEN_DIR, "closed_loop", "reference_dist_episodes.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["meta"] = json.loads(str(d["meta"]))
+    return d
+
+
 def scenario_config(meta, name="base"):
     return dict(meta["variants"][name]["config"])
 
@@ -81,17 +89,20 @@ class OracleEngine:
             st = None
             if static_xy is not None:
                 st = np.asarray(static_xy)[int(static_off[i]):int(static_off[i + 1])]
-            dyn = None
+            dyn, dist = None, None
             if dyn_xy is not None and dyn_dims[i][0] == 1:
                 P, T = int(dyn_dims[i][2]), int(dyn_dims[i][3])
                 dyn = np.asarray(dyn_xy)[int(dyn_off[i]):int(dyn_off[i]) + P * T].reshape(P, T, 2)
+            if dyn_xy is not None and dyn_dims[i][0] == 2:
+                S, P, T = int(dyn_dims[i][1]), int(dyn_dims[i][2]), int(dyn_dims[i][3])
+                dist = np.asarray(dyn_xy)[int(dyn_off[i]):int(dyn_off[i]) + S * P * T].reshape(S, P, T, 2)
             e = ego[i]
             reqs.append(PlanRequest(x=float(e["x"]), y=float(e["y"]), yaw=float(e["yaw"]), v=float(e["v"]), a=float(e["a"]),
                                     target_speed=float(target_speed[i]), last_kappa=float(e["last_kappa"]),
                                     prev_s=float(e["prev_s"]) if e["has_prev_s"] == 1 else None,
                                     chain_prev_s=bool(e["has_prev_s"] == 2), overrides=ov,
                                     max_stop_distance=None if np.isnan(max_stop[i]) else float(max_stop[i]),
-                                    static=st, dyn=dyn))
+                                    static=st, dyn=dyn, dist=dist))
         res = self.plan_batch(reqs)
         out = np.zeros(n, dtype=self.RESULT_DT)
         for i in range(n):
@@ -144,6 +155,35 @@ class OracleResampler:
         obs = np.asarray(obs_traj)
         return orc.predict_cv(obs[-1], obs[-2] if obs.shape[0] >= 2 else None, staleness,
                               float32_observations=float32_observations, **self.kw)
+
+
+    def process_prediction(self, pred_traj, anchor_pos=None, staleness=0.0):
+        pred = np.asarray(pred_traj, dtype=np.float64)
+        kw = {k: v for k, v in self.kw.items() if k != "pred_len"}
+        return np.stack([orc.process_prediction(p, anchor_pos, staleness, **kw) for p in pred])
+
+
+def scripted_raw_sample(obs_last, obs_prev, k, n_samples, pred_len, sgan_dt):
+    """Sample k of a scripted multi-sample predictor: [pred_len, P, 2] positions at the predictor's own step.
+
+    Stands in for ONE Social-GAN forward pass in the reference-generated fixture of distribution-aware episodes (the
+    network weights are not available offline) and in the tests that replay it: every pedestrian keeps walking with
+    its last observed velocity, turned by a sample-dependent angle and scaled by a sample-dependent factor.  Plain
+    NumPy float64 on both sides: the reference run calls it from its predictor's predict(), the tests hand it to
+    BatchedClosedLoop as sample_source."""
+    obs_last, obs_prev = np.asarray(obs_last, np.float64), np.asarray(obs_prev, np.float64)
+    vel = (obs_last - obs_prev) / sgan_dt
+    ang = 0.08 * (k - 0.5 * (n_samples - 1))
+    gain = 1.0 + 0.06 * ((k % 3) - 1)
+    c, s_ = np.cos(ang) * gain, np.sin(ang) * gain
+    v = np.stack([c * vel[:, 0] - s_ * vel[:, 1], s_ * vel[:, 0] + c * vel[:, 1]], axis=1)
+    steps = (np.arange(pred_len) + 1.0) * sgan_dt
+    return obs_last[None, :, :] + steps[:, None, None] * v[None, :, :]
+
+
+def scripted_sample_source(n_samples, pred_len, sgan_dt=0.4):
+    return lambda obs_last, obs_prev: np.stack([scripted_raw_sample(obs_last, obs_prev, k, n_samples, pred_len, sgan_dt)
+                                                for k in range(n_samples)])
 
 
 def assert_episode_matches(hist, termination, ep, name, tol=1e-6):

@@ -325,12 +325,43 @@ def run_case(ref, case, out_dir):
           f"cost={float(out['best_cost']):.6f} stats={out['stats'].tolist()}")
 
 
+def run_time_cache(ref, out_dir):
+    """The reference's polynomial builders (_build_time_cache, _build_longitudinal_profiles, _build_lateral_profiles,
+    frenet_planner.py:586-701) on a few horizons and one Frenet state: what the shim's views of them must return."""
+    FrenetPlanner, CubicSpline2D, _Ego, _Fp = ref
+    sys.path.insert(0, "/root/reference")
+    from src.core.data_structures import FrenetState
+    wx, wy = waypoints("straight")
+    out = {}
+    for tag, dt in (("dt01", 0.1), ("dt005", 0.05)):
+        pl = FrenetPlanner(CubicSpline2D(wx, wy), dt=dt)
+        fs = FrenetState(s=12.5, s_d=6.25, s_dd=-0.75, d=0.4, d_d=-0.3, d_dd=0.125)
+        tvs, dis = np.array([8.0, 6.5, 0.0]), np.array([-3.5, 0.0, 1.5])
+        for T in (0.5, 1.0, 4.0, 4.7, 5.0):
+            tc = pl._build_time_cache(T)
+            key = f"{tag}_T{T}"
+            out[key + "_t"] = tc.t; out[key + "_t5"] = tc.t5
+            out[key + "_qa"] = tc.quartic_A_inv; out[key + "_qi"] = tc.quintic_A_inv
+            lon = pl._build_longitudinal_profiles(fs, tvs, T, tc)
+            lat = pl._build_lateral_profiles(fs, dis, T, tc)
+            out[key + "_lon"] = np.stack([np.stack([p.s, p.s_d, p.s_dd, p.s_ddd]) for p in lon])
+            out[key + "_lat"] = np.stack([np.stack([p.d, p.d_d, p.d_dd, p.d_ddd]) for p in lat])
+    out["state"] = np.array([12.5, 6.25, -0.75, 0.4, -0.3, 0.125])
+    out["tvs"], out["dis"] = np.array([8.0, 6.5, 0.0]), np.array([-3.5, 0.0, 1.5])
+    os.makedirs(os.path.join(out_dir, "builders"), exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, "builders", "time_cache.npz"), **out)
+    print("builders/time_cache.npz", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     ref = import_reference(args.ref)
+    if args.only == "time_cache":
+        run_time_cache(ref, HERE)
+        return
     for case in build_cases():
         if args.only and args.only not in case["name"]:
             continue

@@ -4,8 +4,8 @@ simulator, with oracle-backed stand-ins for the libfot calls."""
 import numpy as np
 import pytest
 
-from closed_loop_common import (OracleEngine, OracleResampler, assert_episode_matches, assert_npz_layout, load_episodes,
-                                scenario_config)
+from closed_loop_common import (OracleEngine, OracleResampler, assert_episode_matches, assert_npz_layout, load_dist_episodes,
+                                load_episodes, scenario_config, scripted_sample_source)
 from integrated_path_planning_amd.closed_loop import BatchedClosedLoop, Observer, ReplayPedestrians
 
 
@@ -23,6 +23,23 @@ def test_episodes_free_running(episodes, name):
     assert_episode_matches(hist, sim.episodes[0].termination_reason, episodes, name)
     arrays = sim.trajectory_arrays(hist)
     assert_npz_layout(arrays, episodes["meta"]["variants"][name]["npz_keys"], len(hist))
+
+
+@pytest.mark.parametrize("name", ["s4_eps0", "s5_best_only"])
+def test_distribution_episodes_free_running(name):
+    """A multi-sample predictor in front of the planner (scripted: closed_loop_common.scripted_raw_sample, the one the
+    reference-generated fixture used in the place of a Social-GAN forward pass): samples resampled to the simulation
+    step, the sample closest to the mean recorded as the prediction, and -- with distribution_aware_planning -- every
+    plan() call checked against the whole distribution under the chance constraint (integrated_simulator.py:459-460,
+    514-525)."""
+    ep = load_dist_episodes()
+    var = ep["meta"]["variants"][name]
+    cfg = dict(var["config"])
+    src = scripted_sample_source(var["n_samples"], cfg["pred_len"])
+    sim = BatchedClosedLoop(cfg, [ep[name + "_ped_traj"]], engine=OracleEngine(cfg), resampler=OracleResampler(cfg),
+                            sample_source=src)
+    hist = sim.run()[0]
+    assert_episode_matches(hist, sim.episodes[0].termination_reason, ep, name)
 
 
 def test_two_episodes_in_lock_step_equal_their_solo_runs(episodes):

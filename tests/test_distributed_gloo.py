@@ -137,7 +137,7 @@ def _fabricate(lo, hi, rank, n_total=51):
         for k in range(8):
             r.stats[k] = g + k
         for k in range(6):
-            r.frenet0[k], r.ref0[k] = g + 0.1 * k, g - 0.1 * k
+            r.frenet0[k], r.ref0[k] = g + 0.125 * k, g - 0.125 * k           # (offsets of s, x, y stay representable)
         for f_i, f in enumerate(_abi.PATH_FIELDS):
             arr = getattr(r, f)
             for k in range(r.n_keep):
@@ -162,10 +162,19 @@ def test_wire_record_round_trip():
         for f in _abi.PATH_FIELDS:
             assert list(getattr(a, f)[: a.n_keep]) == list(getattr(b, f)[: a.n_keep]), f
             assert all(v == 0.0 for v in getattr(b, f)[a.n_keep:])
-    # float32 rounding of a value that is not representable: within 2^-24 relative
+    # float32 rounding of a value that is not representable: within 2^-24 of its OFFSET from the record's reference
+    # point -- so a path far from the origin keeps its resolution (x, y, s travel as offsets)
     recs[0].x[1] = 97.123456789
     back = unpack_records(pack_records_host(recs, 5, 51), 5, 51)
-    assert abs(back[0].x[1] - 97.123456789) <= 97.123456789 * 2.0 ** -24
+    assert abs(back[0].x[1] - 97.123456789) <= (97.123456789 - recs[0].ref0[1]) * 2.0 ** -24
+    far = _fabricate(0, 1, 0)
+    far[0].ref0[1], far[0].ref0[2], far[0].frenet0[0] = 1.0e4, -2.0e4, 5.0e3
+    for k in range(far[0].n_keep):
+        far[0].x[k], far[0].y[k], far[0].s[k] = 1.0e4 + 0.7 * k + 1e-7, -2.0e4 - 0.3 * k + 1e-7, 5.0e3 + 0.9 * k + 1e-7
+    back = unpack_records(pack_records_host(far, 1, 51), 1, 51)
+    for f in ("x", "y", "s"):
+        err = max(abs(getattr(back[0], f)[k] - getattr(far[0], f)[k]) for k in range(far[0].n_keep))
+        assert err <= 1e-6, (f, err)                  # (plain float32 of 2e4 would be off by 1e-3)
 
 
 def _wire_worker(rank, world, port, n_total, ret):

@@ -6,7 +6,8 @@ import time
 import numpy as np
 import pytest
 
-from closed_loop_common import assert_episode_matches, assert_npz_layout, load_episodes, scenario_config
+from closed_loop_common import (assert_episode_matches, assert_npz_layout, load_dist_episodes, load_episodes, scenario_config,
+                                scripted_sample_source)
 from integrated_path_planning_amd.closed_loop import BatchedClosedLoop
 
 pytestmark = pytest.mark.gpu
@@ -58,3 +59,20 @@ def test_replicated_episodes_are_identical(episodes):
     for h in hists[1:]:
         assert [r.ego.x for r in h] == x0
     sim.close()
+
+
+@pytest.mark.parametrize("name", ["s6_eps02", "s4_eps0", "s5_best_only"])
+def test_distribution_aware_episodes_match_the_reference(name):
+    """Rolling-horizon episodes of the headline workload's kind: every step a sampled prediction DISTRIBUTION of all
+    pedestrians goes through the device resampler into the planner, which applies the chance constraint
+    (floor(0.2 * 6) = 1 colliding sample allowed / none allowed / planning on the best sample only).  Reference episodes
+    generated with the same scripted sample source in the place of the Social-GAN forward pass; two copies per batch."""
+    ep = load_dist_episodes()
+    var = ep["meta"]["variants"][name]
+    cfg = dict(var["config"])
+    src = scripted_sample_source(var["n_samples"], cfg["pred_len"])
+    with BatchedClosedLoop(cfg, [ep[name + "_ped_traj"]] * 2, sample_source=src) as sim:
+        hists = sim.run()
+        for h, e in zip(hists, sim.episodes):
+            assert_episode_matches(h, e.termination_reason, ep, name)
+        assert [r.ego.x for r in hists[0]] == [r.ego.x for r in hists[1]]

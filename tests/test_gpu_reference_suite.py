@@ -567,3 +567,33 @@ def test_stage_view_collision_geometry_and_selection():                     # te
     d = {"ok": [roll, stop, far]}
     pl._apply_stop_distance_filter(d, 3.0)
     assert d["ok"] == [stop] and d["stop_distance_error"] == [roll, far]
+
+
+@pytest.mark.parametrize("tag,dt", [("dt01", 0.1), ("dt005", 0.05)])
+def test_polynomial_builder_views_match_the_reference(tag, dt):             # frenet_planner.py:586-701
+    """_build_time_cache / _build_longitudinal_profiles / _build_lateral_profiles as views of the shim (the reference's
+    test-suite calls them, e.g. tests/test_frenet_conventions.py:121, :165): sample grid with its end point, the two
+    boundary-value inverses the LIBRARY solves its lattice with, and the profiles built from them -- against vectors
+    generated by the reference (tests/golden/builders/time_cache.npz, make_golden.py --only time_cache)."""
+    import os
+    from integrated_path_planning_amd.data_structures import FrenetState
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "builders", "time_cache.npz"), allow_pickle=False)
+    pl = FrenetPlanner(reference_path=straight_spline(100.0, 11), dt=dt)
+    st = z["state"]
+    fs = FrenetState(s=st[0], s_d=st[1], s_dd=st[2], d=st[3], d_d=st[4], d_dd=st[5])
+    for T in (0.5, 1.0, 4.0, 4.7, 5.0):
+        key = f"{tag}_T{T}"
+        tc = pl._build_time_cache(T)
+        assert len(tc.t) == len(z[key + "_t"]) and np.isclose(tc.t[-1], T)
+        np.testing.assert_allclose(tc.t, z[key + "_t"], rtol=1e-15, atol=0)
+        np.testing.assert_allclose(tc.t5, z[key + "_t5"], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(tc.quartic_A_inv, z[key + "_qa"], rtol=1e-11, atol=0)
+        np.testing.assert_allclose(tc.quintic_A_inv, z[key + "_qi"], rtol=1e-10, atol=0)
+        lon = pl._build_longitudinal_profiles(fs, z["tvs"], T, tc)
+        lat = pl._build_lateral_profiles(fs, z["dis"], T, tc)
+        for i, p in enumerate(lon):
+            np.testing.assert_allclose(np.stack([p.s, p.s_d, p.s_dd, p.s_ddd]), z[key + "_lon"][i], rtol=1e-9, atol=1e-9)
+        for i, p in enumerate(lat):
+            np.testing.assert_allclose(np.stack([p.d, p.d_d, p.d_dd, p.d_ddd]), z[key + "_lat"][i], rtol=1e-9, atol=1e-9)
+    # tests/test_frenet_conventions.py:118-123
+    assert len(pl._build_time_cache(4.0).t) == (41 if dt == 0.1 else 81)
