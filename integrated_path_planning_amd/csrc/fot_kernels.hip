@@ -515,6 +515,52 @@ struct FusedSink {
         }
     }
 
+    // (-DFOT_TIER) the point in the instance-local float32 frame; get_exact(px, py) yields its float64 coordinates, asked for only
+    // by the lanes whose float32 distance to some entry lies between the two thresholds
+    template <class GetExact>
+    __device__ __forceinline__ void put32(int k, int, float fx, float fy, bool alive, const GetExact &get_exact)
+    {
+        if (n_chunks == 0) return;                                // wave-uniform
+        if (!alive || hit) return;                                // lanes whose collision outcome is already settled
+        bool sure = false;                                        // some obstacle is certainly within its radius
+        const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
+            const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // (may be odd: the last pair then tests one chunk)
+            const f2x8 *cp = row + c0;
+            uint32_t near_bits = 0;                               // chunk c0+i within the threshold -> bit nb-1-i
+            // Branch-free loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns out of
+            // order, so a compiler-placed wait for the chunk in use would also wait for the prefetch behind it;
+            // the loads are therefore inline asm (invisible to the waitcnt pass) and each buffer is waited for
+            // right before its own use, one chunk of arithmetic after its load was issued.  The last pair
+            // prefetches one chunk past the list (allocated slack, never used).
+            f16 ca, cb;
+            sload_chunk<0>(ca, cp);
+            swait_chunk(ca);
+            for (int c = 0; c < nb; c += 2) {
+                sload_chunk_ahead<64>(cb, cp, fx);
+                const float ma = min_sqdist32_f16(ca, fx, fy);
+                near_bits = (near_bits << 1) | (uint32_t)(ma <= thr);
+                sure |= ma <= thr_fatal;
+                swait_chunk(cb);
+                sload_chunk_ahead<128>(ca, cp, fx);
+                if (c + 1 < nb) {                                     // wave-uniform
+                    const float mb = min_sqdist32_f16(cb, fx, fy);
+                    near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
+                    sure |= mb <= thr_fatal;
+                }
+                swait_chunk(ca);
+                cp += 2;
+            }
+            // a single violation is fatal (no chance constraint budget): a certain float32 hit settles the candidate
+            if (sure) { hit = true; return; }
+            if (near_bits != 0) {
+                double px, py;
+                get_exact(px, py);
+                exact(k, c0, nb, near_bits, px, py, fx, fy);
+            }
+        }
+    }
+
     // rare: exact float64 re-check of the chunks whose float32 distance came within the threshold
     __device__ __forceinline__ void exact(int k, int c0, int nb, uint32_t near_bits, double px, double py, float fx,
                                           float fy)
@@ -537,6 +583,7 @@ struct FusedSink {
     }
 
     __device__ __forceinline__ bool collided() const { return hit; }
+    __device__ __forceinline__ void restart() { hit_mask = 0; viol = 0; hit = false; }   // (the second, float64 walk)
 };
 
 // Longitudinal rows of a tile's profiles in the wave's own slice of LDS: the 64 candidates of a tile share two or
@@ -785,7 +832,20 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
                           "+v"(lc.road_lim));
         lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
         asm volatile("" : "+s"(lc.n_circ_fp));
-        evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);
+        if constexpr (SPLIT) {
+            evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);      // (a handful of egos: latency, not issue, bound)
+        } else {
+            // -DFOT_TIER: the float32 tier (fot_math.hpp tier_walk): certified float32 steps, float64 where float32
+            // proves nothing.  Exact (the CPU logic test runs it against the float64 walk on every reference candidate and
+            // checks its error bounds sample by sample) but SLOWER on this kernel as built -- 0.39 ms against 0.23 ms: 144
+            // vector registers (three waves per SIMD), 59 lane-spilled scalars, and the bounds cost as much as the
+            // arithmetic they certify -- so the shipped walk is the float64 one.
+#ifdef FOT_TIER
+            tier_walk(P, D, L, tab, q, k1, sink, g);
+#else
+            evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);
+#endif
+        }
         hit_mask = sink.hit_mask; hit = sink.hit;
 #ifdef FOT_TIMELINE
         tl_rows = tab.t_rows;
@@ -831,7 +891,11 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
     int my_keep = 0;
     if (has_cand) {
         CandResult r;
-        finish_candidate(P, D, L, tab, q, g, hit, r);
+        {
+            LonInfo Lf = *tab.info;                              // (read again here: not carried through the walk)
+            Lf.n_t = L.n_t;
+            finish_candidate(P, D, Lf, tab, q, g, hit, r);
+        }
         st_final = final_status(r.status, r.v_last, r.travel, D.max_stop);
         const EvalKernArgs &KA = eval_kernargs();
         KA.cand_cost[slot] = r.cost;
@@ -1064,7 +1128,14 @@ k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
 // The grouped cut (fot_math.hpp): one workgroup per group of GROUP_TILES tiles, one shared row table, four such
 // workgroups per CU -- four waves per SIMD.  Same order as above with groups in the place of tiles: queue x holds the
 // groups of the instances x, x + 8, ... position-major, an instance's last group first.
-__global__ void __launch_bounds__(GROUP_TILES * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef FOT_GROUP_WAVES
+#ifdef FOT_TIER
+#define FOT_GROUP_WAVES 3                // (the tier build needs 144 vector registers: three waves per SIMD)
+#else
+#define FOT_GROUP_WAVES 4
+#endif
+#endif
+__global__ void __launch_bounds__(GROUP_TILES * WAVE) __attribute__((amdgpu_waves_per_eu(FOT_GROUP_WAVES, FOT_GROUP_WAVES)))
 k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
                  const InstState *__restrict__ state, const int32_t *__restrict__ tile_cand0,
                  const int32_t *__restrict__ tile_n, const TileStep *__restrict__ wave_rng,

@@ -738,6 +738,349 @@ FOT_HD void evaluate_segment(const DevParams &P, const LoopConst &C, const LonIn
     }
 }
 
+// ---------------------------------------------------------------------------
+// The float32 tier of the candidate walk (throughput kernels).
+//
+// Every decision of the reference is a comparison of a float64 quantity with a threshold.  A time step is first
+// evaluated in float32 together with a first-order bound of the float32 error of every compared quantity (inputs
+// rounded to float32: 2^-24 relative each; d', d'' of the quintic: an absolute bound from the candidate's coefficient
+// magnitudes; every operation 2^-24 relative; the bounds carry a factor of four on top).  A comparison whose float32
+// value lies further from its threshold than its bound has the same outcome in float64 -- it is CERTIFIED.  A step in
+// which any candidate of the wave has an uncertified comparison (or a non-finite value, or falls under the low-speed
+// rules) is evaluated again with the float64 code, which then decides; nothing float32 ever decides a status on its
+// own.  What stays float64 throughout: the lateral offset d (road-bound test: the outermost lateral target converges to
+// the bound itself), 1 - kappa_r d (singularity test), the cost.  Positions go to the collision broad phase as float32
+// (instance-local frame; its thresholds carry the position error, filter_threshold) and are rebuilt in float64 only for
+// the entries float32 cannot settle.  The largest step length is compared at the end, in float32, against the step limit
+// +- 0.1 %: inside that band the whole candidate is walked again in float64 (tier_walk returns true).
+// ---------------------------------------------------------------------------
+
+FOT_HD float rcp_f32(float a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(a);
+#else
+    return 1.0f / a;
+#endif
+}
+
+FOT_HD float rsq_f32(float a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(a);
+#else
+    return 1.0f / sqrtf(a);
+#endif
+}
+
+constexpr float TIER_U = 2.3841858e-7f;                          // 4 x 2^-24: unit roundoff with the safety factor
+
+struct Tier32 {                          // per candidate
+    float c1[5];                         // d'  = c1[0] + t (c1[1] + t (c1[2] + t (c1[3] + t c1[4])))
+    float c2[4];                         // d'' = c2[0] + t (c2[1] + t (c2[2] + t c2[3]))
+    float e1, e2;                        // absolute error bounds of the float32 d', d''
+    float dt;
+    float max_step2;                     // largest squared step so far (float32 positions)
+    float px, py;                        // previous sample, instance-local float32
+};
+
+FOT_HD void tier_init(Tier32 &t, const double *q, double T, double dt)
+{
+    const double a[6] = { fabs(q[0]), fabs(q[1]), fabs(q[2]), fabs(q[3]), fabs(q[4]), fabs(q[5]) };
+    t.c1[0] = (float)q[1]; t.c1[1] = (float)(2.0 * q[2]); t.c1[2] = (float)(3.0 * q[3]); t.c1[3] = (float)(4.0 * q[4]);
+    t.c1[4] = (float)(5.0 * q[5]);
+    t.c2[0] = (float)(2.0 * q[2]); t.c2[1] = (float)(6.0 * q[3]); t.c2[2] = (float)(12.0 * q[4]); t.c2[3] = (float)(20.0 * q[5]);
+    const double T2 = T * T, T3 = T2 * T;
+    const double B1 = a[1] + 2.0 * a[2] * T + 3.0 * a[3] * T2 + 4.0 * a[4] * T3 + 5.0 * a[5] * T2 * T2;
+    const double B2 = 2.0 * a[2] + 6.0 * a[3] * T + 12.0 * a[4] * T2 + 20.0 * a[5] * T3;
+    const double B3 = 6.0 * a[3] + 24.0 * a[4] * T + 60.0 * a[5] * T2;
+    // Horner in float32 (rounded coefficients, rounded t, one rounding per operation) on terms bounded by B1 / B2;
+    // the rounding of t moves d' by |d''| dt_err <= B2 T u and d'' by B3 T u
+    t.e1 = (float)((12.0 * B1 + 2.0 * B2 * T) * TIER_U);
+    t.e2 = (float)((10.0 * B2 + 2.0 * B3 * T) * TIER_U);
+    t.dt = (float)dt;
+    t.max_step2 = -INFINITY; t.px = 0.0f; t.py = 0.0f;
+}
+
+struct Cart32 {
+    float x, y, cos_t, sin_t, kappa, v, a, lat;
+    float e_v, e_a, e_k, e_lat;          // bounds of |float32 value - float64 value|
+};
+
+// frenet_to_cart in float32, with the error bounds.  rx, ry: reference point in the instance-local frame.
+// e1, e2: absolute error bounds of d_d, d_dd.
+FOT_HD void frenet_to_cart_f32(float sd, float sdd, float rx, float ry, float cos_r, float sin_r, float kr, float dkr,
+                               float inv_sd, float d, float omkd, float d_d, float d_dd, float e1, float e2, Cart32 &o)
+{
+    const float u = TIER_U;
+    const float ainv = fabsf(inv_sd);
+    const float dp = d_d * inv_sd;
+    const float e_dp = e1 * ainv + u * fabsf(dp);
+    const float w = dp * sdd;
+    const float inv_sd2 = inv_sd * inv_sd;
+    const float dpp = (d_dd - w) * inv_sd2;
+    const float e_dpp = (e2 + e_dp * fabsf(sdd) + u * (fabsf(d_dd) + fabsf(w))) * inv_sd2 + u * fabsf(dpp);
+    const float e_om = u * (1.0f + fabsf(kr * d));                 // (omkd itself arrives rounded from float64)
+    const float aom = fabsf(omkd);
+    const float hh = dp * dp + omkd * omkd;
+    const float e_hh = 2.0f * (fabsf(dp) * e_dp + aom * e_om) + u * hh;
+    const float inv_h = rsq_f32(hh);
+    const float ih2 = inv_h * inv_h;
+    const float r_h = 0.5f * e_hh * ih2 + u;                       // relative error of h and of 1 / h
+    const float h = hh * inv_h;
+    const float inv_om = rcp_f32(omkd);
+    const float cos_d = omkd * inv_h, sin_d = dp * inv_h;
+    const float krdp = dkr * d + kr * dp;
+    const float e_k0 = u * (fabsf(dkr * d) + fabsf(kr * dp)) + fabsf(kr) * e_dp;
+    // kappa = ((d'' (1 - kd) + krdp d') / h^2 + kr) / h
+    const float n1 = dpp * omkd, n2 = krdp * dp;
+    const float num = n1 + n2;
+    const float e_num = e_dpp * aom + fabsf(dpp) * e_om + e_k0 * fabsf(dp) + fabsf(krdp) * e_dp + u * (fabsf(n1) + fabsf(n2));
+    const float kin = num * ih2;
+    const float kappa = (kin + kr) * inv_h;
+    const float e_kap = (e_num * ih2 + fabsf(kin) * 2.0f * r_h + u * (fabsf(kin) + fabsf(kr))) * inv_h + fabsf(kappa) * (r_h + u);
+    const float hk = h * kappa;
+    const float dtp = hk - kr;
+    const float e_dtp = h * e_kap + fabsf(hk) * r_h + u * (fabsf(hk) + fabsf(kr));
+    const float inv_cos = h * inv_om;
+    const float r_ic = r_h + e_om * fabsf(inv_om) + 2.0f * u;
+    const float g1 = dp * dtp;
+    const float g = g1 - krdp;
+    const float e_g = e_dp * fabsf(dtp) + fabsf(dp) * e_dtp + e_k0 + u * (fabsf(g1) + fabsf(krdp));
+    const float sd2 = sd * sd;
+    const float a1 = sdd * h, a2f = sd2 * inv_cos;
+    const float a2 = a2f * g;
+    o.a = a1 + a2;
+    o.e_a = fabsf(a1) * (r_h + u) + fabsf(a2f) * (e_g + fabsf(g) * (r_ic + 2.0f * u)) + u * (fabsf(a1) + fabsf(a2));
+    o.v = fabsf(sd) * h;
+    o.e_v = o.v * (r_h + 2.0f * u);
+    o.kappa = kappa; o.e_k = e_kap;
+    const float v2 = o.v * o.v;
+    o.lat = v2 * fabsf(kappa);
+    o.e_lat = 2.0f * o.v * o.e_v * fabsf(kappa) + v2 * e_kap + 2.0f * u * o.lat;
+    o.x = rx - sin_r * d;
+    o.y = ry + cos_r * d;
+    o.cos_t = cos_d * cos_r - sin_d * sin_r;
+    o.sin_t = sin_d * cos_r + cos_d * sin_r;
+}
+
+// lateral offset alone, float64 (the rest of the lateral state goes through Tier32)
+FOT_HD double lat_offset(const double *q, int k, int n_eval, double dt)
+{
+    const double t = (double)(k < n_eval ? k : n_eval - 1) * dt;
+    return q[0] + t * (q[1] + t * (q[2] + t * (q[3] + t * (q[4] + t * q[5]))));
+}
+
+// |value - threshold| within the error bound (or not a number): the float32 comparison proves nothing
+FOT_HD bool tier_unsure(float value, float threshold, float bound)
+{
+    return !(fabsf(value - threshold) > bound + TIER_U * fabsf(threshold));
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// (CPU logic test only: how often the float32 tier certifies a step)
+inline long *tier_stats() { static long c[8] = { 0 }; return c; }
+#endif
+
+FOT_HD bool wave_any(bool b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(b) != 0ull;
+#else
+    return b;
+#endif
+}
+
+// One float64 time step of one candidate (what evaluate_segment does per step, the collision point aside); the row and
+// the predecessor sample are rebuilt here rather than carried through the float32 steps.  Returns false when the sample
+// ended the kept prefix (NaN position); else the point in the instance-local float32 frame + heading.
+template <class Tab>
+FOT_HD bool tier_step_f64(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab, const double *q,
+                          int k, double d, double ox, double oy, SegState &g, Tier32 &t, float &fx, float &fy,
+                          float &fct, float &fst)
+{
+    const LoopConst C = loop_const(P, D);                         // (read where it is needed: the rare path)
+    LonSample ls;
+    lon_tab.load(k, ls);
+    double u0, d_d, d_dd, d_ddd;
+    lat_sample(q, k, L.n_eval, C.dt, u0, d_d, d_dd, d_ddd);
+    CartSample c;
+    frenet_to_cart(ls, d, d_d, d_dd, c);
+    if (isnan(c.x)) { g.acc.fl |= CK_SEEN_NAN; g.first_nan = k; return false; }
+    // a local accumulator: the predecessor sample is rebuilt here, never carried across steps (sixteen registers that
+    // would otherwise live through the float32 steps)
+    CheckAcc a;
+    check_init(a);
+    a.fl = g.acc.fl;
+    if (k > 0) {                                                  // (it exists and was no NaN sample)
+        LonSample lp;
+        lon_tab.load(k - 1, lp);
+        double pd, pd_d, pd_dd, pd_ddd;
+        lat_sample(q, k - 1, L.n_eval, C.dt, pd, pd_d, pd_dd, pd_ddd);
+        CartSample pc;
+        frenet_to_cart(lp, pd, pd_d, pd_dd, pc);
+        a.prev.x = pc.x; a.prev.y = pc.y; a.prev.cos_t = pc.cos_t; a.prev.sin_t = pc.sin_t;
+        a.prev.kappa = pc.kappa; a.prev.v = pc.v; a.prev.a = pc.a; a.prev.d = pd;
+    }
+    PathSample ps;
+    ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
+    ps.v = c.v; ps.a = c.a; ps.d = d;
+    check_sample(C, a, k, ps, true, true, [&] { return fabs(lon_tab.s_at(k) - lon_tab.s_at(k - 1)); });
+    g.acc.fl = a.fl;
+    if (k > 0) {                                                  // this step's squared length, both accumulators
+        if (a.max_step2 > g.acc.max_step2) g.acc.max_step2 = a.max_step2;
+        const float s2 = (float)a.max_step2;
+        t.max_step2 = s2 > t.max_step2 ? s2 : t.max_step2;
+    }
+    fx = (float)(c.x - ox); fy = (float)(c.y - oy); fct = (float)c.cos_t; fst = (float)c.sin_t;
+    g.v_last = c.v;
+    return true;
+}
+
+// The whole walk of one candidate, time steps [0, n_loop): a first pass through the tier and, when a candidate of the
+// wave ends inside the step-limit band, a second pass with every step in float64.  ox, oy: origin of the
+// instance-local frame (the ego position, as in the entry lists).  Sink::put32(k, circle, fx, fy, alive, get_exact):
+// the collision point in that frame; get_exact(px, py) rebuilds its float64 coordinates for the lanes that need them.
+template <class Tab, class Sink>
+FOT_HD void tier_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
+                      const double *q, int n_loop, Sink &sink, SegState &g)
+{
+    const int n_t = L.n_t;
+    CheckAcc &acc = g.acc;
+    const double ox = D.ego.x, oy = D.ego.y, dt64 = P.dt, road_lim = P.road_lim;
+    const float lim_speed = (float)D.lim_speed, lim_accel = (float)D.lim_accel, lim_curv = (float)D.lim_curv,
+                lim_lat = (float)D.lim_lat;
+    const int n_circ_fp = P.has_footprint ? P.n_circ : 0;
+    bool force64 = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        Tier32 t;
+        tier_init(t, q, (double)(L.n_eval - 1) * dt64, dt64);
+        bool any32 = false;
+        for (int k = 0; k < n_loop; ++k) {
+          // the row, rounded to float32 at once (the float64 step and the exact collision point read it again)
+          float r_sd, r_sdd, r_rx, r_ry, r_cos, r_sin, r_kr, r_dkr, r_inv;
+          double kr64;
+          {
+              LonSample ls;
+              lon_tab.load(k, ls);
+              r_sd = (float)ls.sd; r_sdd = (float)ls.sdd; r_rx = (float)(ls.rx - ox); r_ry = (float)(ls.ry - oy);
+              r_cos = (float)ls.cos_r; r_sin = (float)ls.sin_r; r_kr = (float)ls.kr; r_dkr = (float)ls.dkr;
+              r_inv = (float)ls.inv_sd; kr64 = ls.kr;
+          }
+          sink.row_begin(k);
+          if (k < n_t) {
+            const double d = lat_offset(q, k, L.n_eval, dt64);
+            g.d_last = d;
+            const double omkd64 = 1.0 - kr64 * d;
+            check_flag(acc, isfinite(omkd64) && omkd64 <= 0.05, CK_SINGULAR);   // SINGULARITY_EPS, any sample, float64
+            if (!(acc.fl & CK_SEEN_NAN)) {
+                bool need64 = force64;
+                float fx = 0.0f, fy = 0.0f, fct = 1.0f, fst = 0.0f, step2 = 0.0f, v32 = 0.0f;
+                uint32_t fl32 = 0;
+                if (!force64) {
+                    const float tt = (float)k * t.dt;
+                    float d_d = 0.0f, d_dd = 0.0f;
+                    const bool poly = k < L.n_eval;                              // (brake padding: d' = d'' = 0 exactly)
+                    if (poly) {
+                        d_d = t.c1[0] + tt * (t.c1[1] + tt * (t.c1[2] + tt * (t.c1[3] + tt * t.c1[4])));
+                        d_dd = t.c2[0] + tt * (t.c2[1] + tt * (t.c2[2] + tt * t.c2[3]));
+                    }
+                    Cart32 c;
+                    frenet_to_cart_f32(r_sd, r_sdd, r_rx, r_ry, r_cos, r_sin, r_kr, r_dkr, r_inv, (float)d, (float)omkd64,
+                                       d_d, d_dd, poly ? t.e1 : 0.0f, poly ? t.e2 : 0.0f, c);
+                    // what float32 cannot certify (a NaN makes every comparison below "unsure")
+                    bool unsure = !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)) || isnan(c.x) || isnan(c.y);
+                    if (k > 0) {
+                        const float sx = c.x - t.px, sy = c.y - t.py;
+                        step2 = sx * sx + sy * sy;
+                        unsure |= isnan(step2);
+                        unsure |= tier_unsure(c.v, lim_speed, c.e_v);
+                        unsure |= tier_unsure(fabsf(c.a), lim_accel, c.e_a);
+                        unsure |= !(c.v - c.e_v > 0.5f * (1.0f + TIER_U));      // at or under the low-speed gate: float64 rules
+                        unsure |= tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
+                        unsure |= tier_unsure(c.lat, lim_lat, c.e_lat);
+                        fl32 |= c.v > lim_speed ? CK_SPEED : 0u;
+                        fl32 |= fabsf(c.a) > lim_accel ? CK_ACCEL : 0u;
+                        fl32 |= fabsf(c.kappa) > lim_curv ? CK_CURV : 0u;
+                        fl32 |= c.lat > lim_lat ? CK_LAT : 0u;
+                        fl32 |= fabs(d) > road_lim ? CK_ROAD : 0u;               // (float64: exact)
+                    }
+                    need64 = wave_any(unsure);
+#if !defined(__HIP_DEVICE_COMPILE__)
+                    {
+                        long *st = tier_stats();
+                        st[0] += 1; st[1] += unsure ? 1 : 0;
+                        if (k > 0 && !unsure) { }
+                        if (k > 0) {
+                            st[2] += tier_unsure(c.v, lim_speed, c.e_v); st[3] += tier_unsure(fabsf(c.a), lim_accel, c.e_a);
+                            st[4] += !(c.v - c.e_v > 0.5f * (1.0f + TIER_U)); st[5] += tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
+                            st[6] += tier_unsure(c.lat, lim_lat, c.e_lat);
+                            st[7] += !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)) || isnan(c.x);
+                        }
+                    }
+#endif
+                    fx = c.x; fy = c.y; fct = c.cos_t; fst = c.sin_t; v32 = c.v;
+                }
+                bool counted = true;
+                if (need64) {
+                    counted = tier_step_f64(P, D, L, lon_tab, q, k, d, ox, oy, g, t, fx, fy, fct, fst);
+                } else {
+                    any32 = true;
+                    acc.fl |= fl32;
+                    if (k > 0) t.max_step2 = step2 > t.max_step2 ? step2 : t.max_step2;
+                    g.v_last = (double)v32;
+                }
+                if (counted) {
+                    t.px = fx; t.py = fy;
+                    g.k_last = k;
+                    const bool alive = (acc.fl & CK_FAILED) == 0;
+                    // collision points: float32, instance-local; the exact point only where float32 cannot settle an entry
+                    const int n_circ = n_circ_fp > 0 ? n_circ_fp : 1;
+                    for (int ci = 0; ci < n_circ; ++ci) {
+                        const float off = n_circ_fp > 0 ? (float)P.circ_off[ci] : 0.0f;
+                        sink.put32(k, ci, fx + off * fct, fy + off * fst, alive, [&](double &px, double &py) {
+                            LonSample ls;
+                            lon_tab.load(k, ls);
+                            double u0, e_d, e_dd, e_ddd;
+                            lat_sample(q, k, L.n_eval, dt64, u0, e_d, e_dd, e_ddd);
+                            CartSample ce;
+                            frenet_to_cart(ls, d, e_d, e_dd, ce);
+                            const double o64 = n_circ_fp > 0 ? P.circ_off[ci] : 0.0;
+                            px = ce.x + o64 * ce.cos_t; py = ce.y + o64 * ce.sin_t;
+                        });
+                    }
+                }
+            }
+          }
+          sink.row_end(k);
+        }
+        // --- what the float32 steps left approximate
+        bool rewalk = false;
+        if (any32) {
+            if (!(acc.fl & CK_NANSTEP) && g.k_last >= 1) {
+                // the largest step against the step limit (frenet_planner.py:953-956): certain, or walk again
+                const float lim2 = (float)(D.step_limit * D.step_limit);
+                if (t.max_step2 > lim2 * 1.002f) acc.max_step2 = INFINITY;
+                else if (t.max_step2 < lim2 * 0.998f) acc.max_step2 = 0.0;
+                else rewalk = true;
+            }
+            if (!isnan(D.max_stop) && g.k_last >= 0) {            // the stop filter compares the LAST speed: float64
+                LonSample ls;
+                lon_tab.load(g.k_last, ls);
+                double dd, d_d, d_dd, d_ddd;
+                lat_sample(q, g.k_last, L.n_eval, dt64, dd, d_d, d_dd, d_ddd);
+                CartSample c;
+                frenet_to_cart(ls, dd, d_d, d_dd, c);
+                g.v_last = c.v;
+            }
+        }
+        if (!wave_any(rewalk)) break;
+        seg_init(g);                                              // once more, every step in float64
+        sink.restart();
+        force64 = true;
+    }
+}
+
 // g (segments up to some k) followed by n (the segment that starts there and holds a sample below n_t).  Returns
 // false when g already ended the kept prefix (a NaN sample): n's checks and collision points then do not count.
 FOT_HD bool seg_merge(SegState &g, const SegState &n)
@@ -1123,9 +1466,11 @@ FOT_HD FilterConst filter_const(double sq, double sq_min)
 
 FOT_HD FilterConst filter_const(double sq) { return filter_const(sq, sq); }
 
+// (e: 2^-21 since the float32 tier: the candidate's point may itself be computed in float32 -- frenet_to_cart_f32, a
+// handful of roundings of coordinates of this magnitude -- instead of being the rounding of its float64 value)
 FOT_HD float filter_threshold(const FilterConst &f, float px, float py)
 {
-    const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 4.0f) * 1.1920929e-7f;
+    const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 12.0f) * 4.7683716e-7f;
     return (f.sq + 4.0f * f.r * e) * 1.000002f + 1e-30f;
 }
 
@@ -1136,7 +1481,7 @@ FOT_HD float filter_threshold(double sq, float px, float py) { return filter_thr
 // (A float32 value below sq means |d| < R + 1, so the same rounding bound applies; <= 0 when nothing is certain.)
 FOT_HD float filter_threshold_sure(const FilterConst &f, float px, float py)
 {
-    const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 4.0f) * 1.1920929e-7f;
+    const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 12.0f) * 4.7683716e-7f;
     return (f.sq_lo - 4.0f * f.r * e) * 0.999998f - 1e-30f;
 }
 
@@ -1219,12 +1564,17 @@ struct EntryCollider {
     }
     FOT_HD void row_begin(int) {}
     FOT_HD void row_end(int) {}
-    FOT_HD void put(int k, int, double px, double py, bool alive)
+    FOT_HD void put(int k, int ci, double px, double py, bool alive)
+    {
+        put32(k, ci, (float)(px - ox), (float)(py - oy), alive, [&](double &ex, double &ey) { ex = px; ey = py; });
+    }
+    // the point in the instance-local float32 frame; get_exact(px, py): its float64 coordinates, where they are needed
+    template <class GetExact>
+    FOT_HD void put32(int k, int, float fx, float fy, bool alive, const GetExact &get_exact)
     {
         if (!rng || !alive || hit) return;
         const int c_lo = (int)(rng[k] >> 16), c_hi = (int)(rng[k] & 0xffffu);
         const int64_t base = (int64_t)k * ent_cap;
-        const float fx = (float)(px - ox), fy = (float)(py - oy);
         const FilterConst fc = filter_const(sq_max, sq_dyn < sq_static ? sq_dyn : sq_static);
         const float thr = thr_k ? thr_k[k] : filter_threshold(fc, fx, fy);
         const float thr_sure = thr_sure_k ? thr_sure_k[k] : filter_threshold_sure(fc, fx, fy);
@@ -1232,10 +1582,13 @@ struct EntryCollider {
             const float m = min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy);
             if (m > thr) continue;
             if (max_viol == 0 && m <= thr_sure) { hit = true; break; }      // certain hit: one violation is fatal
+            double px, py;
+            get_exact(px, py);
             exact_chunk_f32first(*(const f2x8 *)(e32 + base + c), e64 + base + c, sid + base + c, fx, fy, thr, thr_sure,
                                  px, py, sq_static, sq_dyn, max_viol, hit_mask, viol, hit);
         }
     }
+    FOT_HD void restart() { hit_mask = 0; viol = 0; hit = false; }
     FOT_HD bool collided() const { return hit; }
 };
 
