@@ -370,7 +370,10 @@ FOT_HD int profile_rows(const DevParams &P, const InstDesc &D, int slot)
 //    share the CU's LDS: four waves per SIMD (k_evaluate then has to make do with 128 vector registers, which it
 //    does).  A shape's tile list is padded with empty tiles (n = 0) so that group g is tiles [4g, 4g + 4).
 // The handle picks the cut by the number of tiles either one makes of its lattice (build_tile_shapes).
-constexpr int GROUP_TILES = 4, GROUP_ROWS = 512, GROUP_MAX_PROFILES = 16;
+#ifndef FOT_GROUP_TILES
+#define FOT_GROUP_TILES 4
+#endif
+constexpr int GROUP_TILES = FOT_GROUP_TILES, GROUP_ROWS = 128 * FOT_GROUP_TILES, GROUP_MAX_PROFILES = 4 * FOT_GROUP_TILES;
 FOT_HD int tile_row_budget(int n_total)
 {
     const int want = 3 * n_total + 8, cap = 176;
