@@ -152,11 +152,15 @@ __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__re
     struct Pt { T x, y; };
     const Pt *base = (const Pt *)dyn_xy + D.dyn_off;
     if (D.dyn_tmajor) {                                          // [T][S][P]: thread = track, rows n_tracks apart
-        for (int j = j0 + (int)threadIdx.x; j < j1; j += FRENET_WG) {
+        constexpr int TU = 8;                                     // rows in flight per thread (neighbouring threads read
+        for (int j = j0 + (int)threadIdx.x; j < j1; j += FRENET_WG) {   // neighbouring points of a row)
             bool bad = false;
-            for (int t = 0; t < D.T; ++t) {
-                const Pt p = base[(int64_t)t * n_tracks + j];
-                bad |= (p.x != p.x) | (p.y != p.y);
+            for (int t0 = 0; t0 < D.T; t0 += TU) {
+                Pt p[TU];
+#pragma unroll
+                for (int u = 0; u < TU; ++u) p[u] = base[(int64_t)(t0 + u < D.T ? t0 + u : D.T - 1) * n_tracks + j];
+#pragma unroll
+                for (int u = 0; u < TU; ++u) bad |= (p[u].x != p[u].x) | (p[u].y != p[u].y);
             }
             if (bad) f[j] = 1;
         }
@@ -425,7 +429,6 @@ struct FusedSink {
     float thr, thr_fatal;                // of the current time step (wave-uniform)
     const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
     int chunks_per_k;                    // ent_cap / 8
-    double oxd, oyd;
     uint64_t hit_mask;
     int viol;
     bool hit;
@@ -479,7 +482,7 @@ struct FusedSink {
     {
         if (n_chunks == 0) return;                                // wave-uniform
         if (!alive || hit) return;                                // lanes whose collision outcome is already settled
-        float fx = (float)(px - oxd), fy = (float)(py - oyd);
+        float fx = (float)px, fy = (float)py;                     // (the rows are instance-local: evaluate_tile)
         bool sure = false;                                        // some obstacle is certainly within its radius
         const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
         for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
@@ -567,6 +570,7 @@ struct FusedSink {
     {
         const DevParams &P = *Pp;
         const InstDesc &D = *Dp;
+        px += D.ego.x; py += D.ego.y;                             // the exact entries are in the caller's frame
         const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
         const EvalKernArgs &KA = eval_kernargs();
         const float thr_sure = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_sure), k & (WAVE - 1)));
@@ -613,6 +617,7 @@ constexpr int SEG_F64 = 4, SEG_I32 = 4;  // d_last, v_last, max_step2, hit_mask 
 constexpr int SEG_DOUBLES = (SEG_F64 + SEG_I32 / 2) * WAVE;
 
 struct StagedTab {
+    static constexpr bool LOCAL = true;  // rx, ry relative to the ego position (evaluate_tile builds them so)
     int lds_row0;                        // index of this lane's profile row 0 in s_lon
     int k_max;                           // last row of the run (grid: n_t - 1; brake ladder: the hold row n_eval)
     double dt;
@@ -748,7 +753,9 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         double sddd;
         make_lon_sample(sp_lds, Lp, k, P.dt, ls, sddd);         // (k == n_eval of a brake profile: its hold state)
         double *r = my_rows + (int64_t)i * ROW_FIELDS;
-        r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx; r[3] = ls.ry;
+        // the reference point in the instance-local frame (origin: the ego position, like the entry lists): the walk then
+        // hands its points to the collision test as they are, and nothing else of it depends on the frame
+        r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx - D.ego.x; r[3] = ls.ry - D.ego.y;
         r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
     }
     lds_fence();
@@ -819,7 +826,6 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         sink.step_base = step_base0; sink.step_row = D.tile0 + tile; sink.lane_id = lane;
         sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
         sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
-        sink.oxd = D.ego.x; sink.oyd = D.ego.y;
         sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
         sink.no_warm = (a.ablate & 2) != 0;
         // loop constants as opaque register values: the compiler then keeps them instead of re-fetching each one from

@@ -648,12 +648,14 @@ FOT_HD double lateral_jerk_sum(const double *q, int n_eval, double dt)
 // GlobalTab reads a [field][FOT_MAX_NT] table from memory, ComputeTab evaluates the row on the spot (rows past the
 // profile's n_t are never used and come back unspecified).
 struct GlobalTab {
+    static constexpr bool LOCAL = false;                 // rows in the caller's frame (k_evaluate's rows: instance-local)
     const double *tab;
     FOT_HD void load(int k, LonSample &L) const { load_lon_sample(tab, k, L); }
     FOT_HD double s_at(int k) const { return tab[k]; }
 };
 
 struct ComputeTab {
+    static constexpr bool LOCAL = false;
     SplineView sp;
     LonInfo L;
     double dt;
@@ -776,12 +778,12 @@ FOT_HD float rsq_f32(float a)
 #endif
 }
 
-constexpr float TIER_U = 2.3841858e-7f;                          // 4 x 2^-24: unit roundoff with the safety factor
+constexpr float TIER_U = 1.1920929e-7f;                          // 2 x 2^-24: unit roundoff with a safety factor of two
 
 struct Tier32 {                          // per candidate
     float c1[5];                         // d'  = c1[0] + t (c1[1] + t (c1[2] + t (c1[3] + t c1[4])))
     float c2[4];                         // d'' = c2[0] + t (c2[1] + t (c2[2] + t c2[3]))
-    float e1, e2;                        // absolute error bounds of the float32 d', d''
+    float e1, e2;                        // absolute error bounds of the float32 d', d'' (whole horizon; tier_poly: per step)
     float dt;
     float max_step2;                     // largest squared step so far (float32 positions)
     float px, py;                        // previous sample, instance-local float32
@@ -803,6 +805,18 @@ FOT_HD void tier_init(Tier32 &t, const double *q, double T, double dt)
     t.e2 = (float)((10.0 * B2 + 2.0 * B3 * T) * TIER_U);
     t.dt = (float)dt;
     t.max_step2 = -INFINITY; t.px = 0.0f; t.py = 0.0f;
+}
+
+// d', d'' at t with the error bounds of THIS step: Horner on the coefficients' magnitudes bounds the terms (the whole-
+// horizon bounds e1, e2 are one to two orders larger early in the walk and where the polynomial's terms cancel)
+FOT_HD void tier_poly(const Tier32 &t, float tt, float &d_d, float &d_dd, float &e1, float &e2)
+{
+    d_d = t.c1[0] + tt * (t.c1[1] + tt * (t.c1[2] + tt * (t.c1[3] + tt * t.c1[4])));
+    d_dd = t.c2[0] + tt * (t.c2[1] + tt * (t.c2[2] + tt * t.c2[3]));
+    const float m1 = fabsf(t.c1[0]) + tt * (fabsf(t.c1[1]) + tt * (fabsf(t.c1[2]) + tt * (fabsf(t.c1[3]) + tt * fabsf(t.c1[4]))));
+    const float m2 = fabsf(t.c2[0]) + tt * (fabsf(t.c2[1]) + tt * (fabsf(t.c2[2]) + tt * fabsf(t.c2[3])));
+    e1 = 8.0f * TIER_U * m1;             // rounded coefficients and t (relative u each, t up to the fourth power), eight operations
+    e2 = 8.0f * TIER_U * m2;
 }
 
 struct Cart32 {
@@ -950,7 +964,8 @@ FOT_HD void tier_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, c
 {
     const int n_t = L.n_t;
     CheckAcc &acc = g.acc;
-    const double ox = D.ego.x, oy = D.ego.y, dt64 = P.dt, road_lim = P.road_lim;
+    // (origin of the instance-local float32 frame, in the frame the table's rows are in)
+    const double ox = Tab::LOCAL ? 0.0 : D.ego.x, oy = Tab::LOCAL ? 0.0 : D.ego.y, dt64 = P.dt, road_lim = P.road_lim;
     const float lim_speed = (float)D.lim_speed, lim_accel = (float)D.lim_accel, lim_curv = (float)D.lim_curv,
                 lim_lat = (float)D.lim_lat;
     const int n_circ_fp = P.has_footprint ? P.n_circ : 0;
@@ -982,15 +997,11 @@ FOT_HD void tier_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, c
                 uint32_t fl32 = 0;
                 if (!force64) {
                     const float tt = (float)k * t.dt;
-                    float d_d = 0.0f, d_dd = 0.0f;
-                    const bool poly = k < L.n_eval;                              // (brake padding: d' = d'' = 0 exactly)
-                    if (poly) {
-                        d_d = t.c1[0] + tt * (t.c1[1] + tt * (t.c1[2] + tt * (t.c1[3] + tt * t.c1[4])));
-                        d_dd = t.c2[0] + tt * (t.c2[1] + tt * (t.c2[2] + tt * t.c2[3]));
-                    }
+                    float d_d = 0.0f, d_dd = 0.0f, e1 = 0.0f, e2 = 0.0f;
+                    if (k < L.n_eval) tier_poly(t, tt, d_d, d_dd, e1, e2);       // (brake padding: d' = d'' = 0 exactly)
                     Cart32 c;
                     frenet_to_cart_f32(r_sd, r_sdd, r_rx, r_ry, r_cos, r_sin, r_kr, r_dkr, r_inv, (float)d, (float)omkd64,
-                                       d_d, d_dd, poly ? t.e1 : 0.0f, poly ? t.e2 : 0.0f, c);
+                                       d_d, d_dd, e1, e2, c);
                     // what float32 cannot certify (a NaN makes every comparison below "unsure")
                     bool unsure = !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)) || isnan(c.x) || isnan(c.y);
                     if (k > 0) {

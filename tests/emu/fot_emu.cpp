@@ -319,17 +319,13 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     CartSample c64;
                     frenet_to_cart(ls, d, d_d, d_dd, c64);
                     const float tk = (float)k * tt.dt;
-                    float f_d = 0.0f, f_dd = 0.0f;
-                    const bool poly = k < Li.n_eval;
-                    if (poly) {
-                        f_d = tt.c1[0] + tk * (tt.c1[1] + tk * (tt.c1[2] + tk * (tt.c1[3] + tk * tt.c1[4])));
-                        f_dd = tt.c2[0] + tk * (tt.c2[1] + tk * (tt.c2[2] + tk * tt.c2[3]));
-                    }
-                    if (std::fabs((double)f_d - d_d) > (double)tt.e1 || std::fabs((double)f_dd - d_dd) > (double)tt.e2) return -123;
+                    float f_d = 0.0f, f_dd = 0.0f, e1 = 0.0f, e2 = 0.0f;
+                    if (k < Li.n_eval) tier_poly(tt, tk, f_d, f_dd, e1, e2);
+                    if (std::fabs((double)f_d - d_d) > (double)e1 + 1e-30 || std::fabs((double)f_dd - d_dd) > (double)e2 + 1e-30) return -123;
                     Cart32 c32;
                     frenet_to_cart_f32((float)ls.sd, (float)ls.sdd, (float)(ls.rx - D.ego.x), (float)(ls.ry - D.ego.y),
                                        (float)ls.cos_r, (float)ls.sin_r, (float)ls.kr, (float)ls.dkr, (float)ls.inv_sd, (float)d,
-                                       (float)(1.0 - ls.kr * d), f_d, f_dd, poly ? tt.e1 : 0.0f, poly ? tt.e2 : 0.0f, c32);
+                                       (float)(1.0 - ls.kr * d), f_d, f_dd, e1, e2, c32);
                     if (!(std::isfinite(c32.v) && std::isfinite(c32.a) && std::isfinite(c32.kappa))) continue;   // (float64 decides)
                     if (std::fabs((double)c32.v - c64.v) > (double)c32.e_v + 1e-20) return -124;
                     if (std::fabs((double)c32.a - c64.a) > (double)c32.e_a + 1e-20) {
