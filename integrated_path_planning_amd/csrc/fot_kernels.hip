@@ -652,6 +652,64 @@ struct StagedTab {
     }
 };
 
+#ifdef FOT_TIER2
+// Rows of the float32 walk (tier2_walk, fot_math.hpp), same 72 bytes: nine float32 fields, then the float64 reference
+// point and tangent the exact collision point is rebuilt from.
+struct TierRow { float sd, sdd, rx, ry, cos_r, sin_r, kr, dkr, inv_sd, pad; double rx64, ry64, cos64, sin64; };
+static_assert(sizeof(TierRow) == ROW_FIELDS * sizeof(double), "a tier row takes the place of a float64 row");
+
+struct TierTab {
+    int lds_row0, k_max;
+    double dt;
+    const LonInfo *info;                 // in LDS
+    __device__ __forceinline__ const TierRow &row(int k) const
+    {
+        return *(const TierRow *)(s_lon + lds_row0 + (k < k_max ? k : k_max) * ROW_FIELDS);
+    }
+    __device__ __forceinline__ void load32(int k, Row32 &r) const
+    {
+        const TierRow &t = row(k);
+        r.sd = t.sd; r.sdd = t.sdd; r.rx = t.rx; r.ry = t.ry; r.cos_r = t.cos_r; r.sin_r = t.sin_r; r.kr = t.kr;
+        r.dkr = t.dkr; r.inv_sd = t.inv_sd;
+        asm volatile("" : "+v"(r.sd), "+v"(r.sdd), "+v"(r.rx), "+v"(r.ry), "+v"(r.cos_r), "+v"(r.sin_r), "+v"(r.kr),
+                          "+v"(r.dkr), "+v"(r.inv_sd));           // (in registers before the sink's scalar warm-up loads)
+    }
+    __device__ __forceinline__ void load_exact(int k, double &rx, double &ry, double &cr, double &sr) const
+    {
+        const TierRow &t = row(k);
+        rx = t.rx64; ry = t.ry64; cr = t.cos64; sr = t.sin64;    // (instance-local, like FusedSink's points)
+    }
+    __device__ __forceinline__ double s_at(int k) const
+    {
+        double s_, u0, u1, u2;
+        lon_sample(*info, k, dt, s_, u0, u1, u2);
+        return s_;
+    }
+};
+
+// The float64 walk of a tile the float32 walk gave up on: its rows are not in LDS (the tier's are), every lane rebuilds
+// the row it needs from its profile -- the same function that fills a float64 row table, the same values.
+struct RebuildTab {
+    static constexpr bool LOCAL = true;
+    SplineView sp;                       // (in LDS when short)
+    const LonInfo *info;                 // in LDS
+    int k_max;
+    double dt, ox, oy;
+    __device__ __forceinline__ void load(int k, LonSample &o) const
+    {
+        double sddd;
+        make_lon_sample(sp, *info, k < k_max ? k : k_max, dt, o, sddd);
+        o.rx -= ox; o.ry -= oy;
+    }
+    __device__ __forceinline__ double s_at(int k) const
+    {
+        double s_, u0, u1, u2;
+        lon_sample(*info, k, dt, s_, u0, u1, u2);
+        return s_;
+    }
+};
+#endif
+
 #ifdef FOT_TIMELINE
 // diagnostic build (scripts/timeline.sh): per tile of the last k_evaluate launch -- tile start, start of the sample
 // loop (after the LDS rows are built), tile end on the 100 MHz clock, and the chunks its strip ranges cover
@@ -755,6 +813,16 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         double *r = my_rows + (int64_t)i * ROW_FIELDS;
         // the reference point in the instance-local frame (origin: the ego position, like the entry lists): the walk then
         // hands its points to the collision test as they are, and nothing else of it depends on the frame
+#ifdef FOT_TIER2
+        if constexpr (!SPLIT) {
+            TierRow &t = *(TierRow *)r;
+            const double lx = ls.rx - D.ego.x, ly = ls.ry - D.ego.y;
+            t.sd = (float)ls.sd; t.sdd = (float)ls.sdd; t.rx = (float)lx; t.ry = (float)ly; t.cos_r = (float)ls.cos_r;
+            t.sin_r = (float)ls.sin_r; t.kr = (float)ls.kr; t.dkr = (float)ls.dkr; t.inv_sd = (float)ls.inv_sd; t.pad = 0.0f;
+            t.rx64 = lx; t.ry64 = ly; t.cos64 = ls.cos_r; t.sin64 = ls.sin_r;
+            continue;
+        }
+#endif
         r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx - D.ego.x; r[3] = ls.ry - D.ego.y;
         r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
     }
@@ -827,7 +895,28 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
         sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
         sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
+#ifdef FOT_TIER2
+        sink.no_warm = true;                 // (no load in flight across the sample arithmetic: scalar registers are short)
+#else
         sink.no_warm = (a.ablate & 2) != 0;
+#endif
+#ifdef FOT_TIER2
+        // The float32 walk first (tier2_walk: certifies every decision of the candidate or gives up); a tile one of
+        // whose candidates it gave up on is walked by the float64 code.  Not tried where its preconditions fail: footprint
+        // circles, a stop-distance directive, an ego so slow that most of the lattice lives under the low-speed rules.
+        bool walk64 = true;
+        if constexpr (!SPLIT) {
+            const bool tier_ok = !P.has_footprint && isnan(D.max_stop) && S.frenet0[1] > 1.0;      // wave-uniform
+            if (tier_ok) {
+                TierTab tt;
+                tt.lds_row0 = tab.lds_row0; tt.k_max = tab.k_max; tt.dt = tab.dt; tt.info = tab.info;
+                const bool gave_up = tier2_walk(P, D, L, tt, q, k1, sink, g);
+                walk64 = __ballot(gave_up) != 0ull;
+                if (walk64) { seg_init(g); sink.restart(); }
+            }
+        }
+        if (walk64) {
+#endif
         // loop constants as opaque register values: the compiler then keeps them instead of re-fetching each one from
         // the parameter blocks, behind a scalar-memory wait, in every time step
         LoopConst lc = loop_const(P, D);
@@ -841,17 +930,22 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         if constexpr (SPLIT) {
             evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);      // (a handful of egos: latency, not issue, bound)
         } else {
-            // -DFOT_TIER: the float32 tier (fot_math.hpp tier_walk): certified float32 steps, float64 where float32
-            // proves nothing.  Exact (the CPU logic test runs it against the float64 walk on every reference candidate and
-            // checks its error bounds sample by sample) but SLOWER on this kernel as built -- 0.39 ms against 0.23 ms: 144
-            // vector registers (three waves per SIMD), 59 lane-spilled scalars, and the bounds cost as much as the
-            // arithmetic they certify -- so the shipped walk is the float64 one.
-#ifdef FOT_TIER
+            // -DFOT_TIER: the first form of the float32 tier (fot_math.hpp tier_walk): certified float32 steps, float64
+            // where float32 proves nothing, step by step.  Exact but SLOWER as built -- 0.39 ms against 0.23 ms: 144
+            // vector registers (three waves per SIMD), 59 lane-spilled scalars.
+#if defined(FOT_TIER)
             tier_walk(P, D, L, tab, q, k1, sink, g);
+#elif defined(FOT_TIER2)
+            RebuildTab rt;
+            rt.sp = sp_lds; rt.info = tab.info; rt.k_max = tab.k_max; rt.dt = tab.dt; rt.ox = D.ego.x; rt.oy = D.ego.y;
+            evaluate_segment(P, lc, L, rt, q, k0, k1, sink, g);
 #else
             evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);
 #endif
         }
+#ifdef FOT_TIER2
+        }
+#endif
         hit_mask = sink.hit_mask; hit = sink.hit;
 #ifdef FOT_TIMELINE
         tl_rows = tab.t_rows;

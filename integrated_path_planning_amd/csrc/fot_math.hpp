@@ -9,6 +9,8 @@
 #pragma once
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "fot_types.h"
 
 namespace fot {
@@ -1020,19 +1022,6 @@ FOT_HD void tier_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, c
                         fl32 |= fabs(d) > road_lim ? CK_ROAD : 0u;               // (float64: exact)
                     }
                     need64 = wave_any(unsure);
-#if !defined(__HIP_DEVICE_COMPILE__)
-                    {
-                        long *st = tier_stats();
-                        st[0] += 1; st[1] += unsure ? 1 : 0;
-                        if (k > 0 && !unsure) { }
-                        if (k > 0) {
-                            st[2] += tier_unsure(c.v, lim_speed, c.e_v); st[3] += tier_unsure(fabsf(c.a), lim_accel, c.e_a);
-                            st[4] += !(c.v - c.e_v > 0.5f * (1.0f + TIER_U)); st[5] += tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
-                            st[6] += tier_unsure(c.lat, lim_lat, c.e_lat);
-                            st[7] += !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)) || isnan(c.x);
-                        }
-                    }
-#endif
                     fx = c.x; fy = c.y; fct = c.cos_t; fst = c.sin_t; v32 = c.v;
                 }
                 bool counted = true;
@@ -1093,6 +1082,123 @@ FOT_HD void tier_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, c
         sink.restart();
         force64 = true;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Tier, second form (-DFOT_TIER2): ONE float32 walk of the whole candidate that either certifies every decision or
+// gives up -- then the tile is walked again by the float64 code (evaluate_segment), untouched.  The two walks are two
+// loops, one after the other, so the float64 state costs the float32 loop no registers.  What the float32 walk keeps in
+// float64: the lateral offset d (road test, final offset, the low-speed slip rule together with the arc length from the
+// profile's polynomial) and the collision point of the entries float32 cannot settle (reference point + d * normal from
+// the float64 half of the row).  Tab: load32(k, Row32), load_exact(k, rx, ry, cos_r, sin_r), s_at(k).
+// Not for footprint circles or a stop-distance directive (their consumers need float64 headings / final speed): the
+// caller walks those in float64 from the start.
+// ---------------------------------------------------------------------------
+
+struct Row32 { float sd, sdd, rx, ry, cos_r, sin_r, kr, dkr, inv_sd; };
+
+template <class Tab, class Sink>
+FOT_HD bool tier2_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &tab, const double *q,
+                       int n_loop, Sink &sink, SegState &g)
+{
+    const int n_t = L.n_t, n_eval = L.n_eval;
+    const double dt64 = P.dt, road_lim = P.road_lim;
+    const float lim_speed = (float)D.lim_speed, lim_accel = (float)D.lim_accel, lim_curv = (float)D.lim_curv,
+                lim_lat = (float)D.lim_lat;
+    Tier32 t;
+    tier_init(t, q, (double)(n_eval - 1) * dt64, dt64);
+    uint32_t fl = 0;
+    bool unsure = false;
+    float pct = 1.0f, pst = 0.0f;                                 // previous heading (low-speed yaw rule)
+    double prev_d = 0.0;
+    int first_nan = -1, k_last = -1;
+    for (int k = 0; k < n_loop; ++k) {
+        Row32 r;
+        tab.load32(k, r);
+        sink.row_begin(k);
+        if (k < n_t) {
+            const double d = lat_offset(q, k, n_eval, dt64);
+            g.d_last = d;
+            const float d32 = (float)d;
+            const float kd = r.kr * d32;
+            const float omkd = 1.0f - kd;
+            if (omkd == omkd) {                                    // (NaN beyond the path end: not finite, no flag -- as in float64)
+                if (!(fabsf(omkd - 0.05f) > 4.0f * TIER_U * (1.0f + fabsf(kd)))) unsure = true;
+                else if (omkd <= 0.05f) fl |= CK_SINGULAR;        // SINGULARITY_EPS, any sample
+            }
+            if (!(fl & CK_SEEN_NAN)) {
+                float d_d = 0.0f, d_dd = 0.0f, e1 = 0.0f, e2 = 0.0f;
+                if (k < n_eval) tier_poly(t, (float)k * t.dt, d_d, d_dd, e1, e2);   // (brake padding: d' = d'' = 0 exactly)
+                Cart32 c;
+                frenet_to_cart_f32(r.sd, r.sdd, r.rx, r.ry, r.cos_r, r.sin_r, r.kr, r.dkr, r.inv_sd, d32, omkd, d_d, d_dd, e1, e2, c);
+                if (isnan(c.x)) {
+                    fl |= CK_SEEN_NAN; first_nan = k;             // the reference point is NaN there: exact in either precision
+                } else {
+                    unsure |= !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa));
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define TIER_CAUSE(i, cond) do { if (cond) tier_stats()[4 + (i)] += 1; } while (0)
+#else
+#define TIER_CAUSE(i, cond) do { } while (0)
+#endif
+                    TIER_CAUSE(0, !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)));
+                    if (k > 0) {
+                        const float sx = c.x - t.px, sy = c.y - t.py;
+                        const float step2 = sx * sx + sy * sy;
+                        unsure |= isnan(step2);
+                        t.max_step2 = step2 > t.max_step2 ? step2 : t.max_step2;
+                        unsure |= tier_unsure(c.v, lim_speed, c.e_v);
+                        unsure |= tier_unsure(fabsf(c.a), lim_accel, c.e_a);
+                        unsure |= tier_unsure(c.lat, lim_lat, c.e_lat);
+                        TIER_CAUSE(1, tier_unsure(c.v, lim_speed, c.e_v) || tier_unsure(fabsf(c.a), lim_accel, c.e_a) || tier_unsure(c.lat, lim_lat, c.e_lat));
+                        fl |= c.v > lim_speed ? CK_SPEED : 0u;
+                        fl |= fabsf(c.a) > lim_accel ? CK_ACCEL : 0u;
+                        fl |= c.lat > lim_lat ? CK_LAT : 0u;
+                        fl |= fabs(d) > road_lim ? CK_ROAD : 0u;                  // (float64: exact)
+                        if (c.v - c.e_v > 0.5f * (1.0f + TIER_U)) {               // above the LOW_SPEED_CURVATURE_GATE for certain
+                            unsure |= tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
+                            fl |= fabsf(c.kappa) > lim_curv ? CK_CURV : 0u;
+                        } else if (c.v + c.e_v < 0.5f * (1.0f - TIER_U)) {        // under it for certain: the low-speed rules
+                            // lateral slip: float64 throughout, the very expressions of check_sample
+                            const double dd = fabs(d - prev_d);
+                            const double d_s = fabs(tab.s_at(k) - tab.s_at(k - 1));
+                            fl |= dd > fmax(1.5 * d_s, 0.02) ? CK_CURV : 0u;
+                            // yaw step: the cap is at least 0.1 rad and |atan2(sn, cs)| <= |sn| / cs; float32 sines and cosines
+                            // (errors of a few 1e-6) prove the step harmless with the margin between 0.085 and 0.09
+                            const float sn = c.sin_t * pct - c.cos_t * pst, cs = c.cos_t * pct + c.sin_t * pst;
+                            // ... and |yaw step| >= |sin(yaw step)| = |sn| proves it over the cap max(kappa_max * step, 0.1)
+                            const float cap_hi = fmaxf(lim_curv * sqrtf(step2) * 1.001f, 0.1f);
+                            const bool over = fabsf(sn) - 1e-4f > cap_hi, harmless = cs > 0.5f && fabsf(sn) <= 0.085f * cs;
+                            fl |= over ? CK_CURV : 0u;
+                            if (!over && !harmless) unsure = true;
+                            TIER_CAUSE(2, !over && !harmless);
+                        } else {
+                            unsure = true;                                      // at the gate
+                            TIER_CAUSE(3, true);
+                        }
+                    }
+                    t.px = c.x; t.py = c.y; pct = c.cos_t; pst = c.sin_t; prev_d = d;
+                    k_last = k;
+                    const bool alive = (fl & CK_FAILED) == 0;
+                    sink.put32(k, 0, c.x, c.y, alive, [&](double &px, double &py) {
+                        double rx, ry, cr, sr;
+                        tab.load_exact(k, rx, ry, cr, sr);
+                        px = rx - sr * d; py = ry + cr * d;       // (frenet_to_cart's x, y)
+                    });
+                }
+            }
+        }
+        sink.row_end(k);
+    }
+    g.acc.fl = fl; g.first_nan = first_nan; g.k_last = k_last; g.v_last = 0.0;   // (v_last: no stop directive here)
+    g.acc.max_step2 = -INFINITY;
+    if (k_last >= 1 && !(fl & CK_NANSTEP)) {
+        // the largest step against the step limit (frenet_planner.py:953-956): certain, or float64
+        const float lim2 = (float)(D.step_limit * D.step_limit);
+        if (t.max_step2 > lim2 * 1.002f) g.acc.max_step2 = INFINITY;
+        else if (t.max_step2 < lim2 * 0.998f) g.acc.max_step2 = 0.0;
+        else unsure = true;
+    }
+    return unsure;
 }
 
 // g (segments up to some k) followed by n (the segment that starts there and holds a sample below n_t).  Returns

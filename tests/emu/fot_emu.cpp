@@ -257,6 +257,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         int cnt_st[8] = { 0 };
         ScanBest best = { INFINITY, -1 };
         int best_keep = 0;
+        bool tile_unsure = false;
         for (int idx = 0; idx < S.n_cand; ++idx) {
             const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
             const LonInfo &Li = lon_info[D.lon_off + cd.lon_slot];
@@ -337,6 +338,41 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     const double ex = std::fabs((double)c32.x - (c64.x - D.ego.x)), ey = std::fabs((double)c32.y - (c64.y - D.ego.y));
                     const double epos = 4.7683716e-7 * (std::fabs(c64.x - D.ego.x) + std::fabs(c64.y - D.ego.y) + 12.0);   // filter_threshold's e
                     if (ex > epos || ey > epos) return -128;
+                }
+            }
+            if (!P.has_footprint && std::isnan(D.max_stop)) {
+                // tier, second form (tier2_walk): a candidate it certifies has the float64 walk's record, bit for bit
+                struct EmuTierTab {
+                    GlobalTab gt; double ox, oy;
+                    void load32(int k, Row32 &r) const {
+                        LonSample ls; gt.load(k, ls);
+                        r.sd = (float)ls.sd; r.sdd = (float)ls.sdd; r.rx = (float)(ls.rx - ox); r.ry = (float)(ls.ry - oy);
+                        r.cos_r = (float)ls.cos_r; r.sin_r = (float)ls.sin_r; r.kr = (float)ls.kr; r.dkr = (float)ls.dkr;
+                        r.inv_sd = (float)ls.inv_sd;
+                    }
+                    void load_exact(int k, double &rx, double &ry, double &cr, double &sr) const {
+                        LonSample ls; gt.load(k, ls); rx = ls.rx; ry = ls.ry; cr = ls.cos_r; sr = ls.sin_r;
+                    }
+                    double s_at(int k) const { return gt.s_at(k); }
+                } ttab = { GlobalTab{ tab }, D.ego.x, D.ego.y };
+                EntryCollider e2;
+                e2.init(P, D);
+                e2.rng = ec.rng; e2.e32 = ec.e32; e2.e64 = ec.e64; e2.sid = ec.sid; e2.thr_k = ec.thr_k; e2.thr_sure_k = ec.thr_sure_k;
+                SegState g2;
+                seg_init(g2);
+                const bool unsure = tier2_walk(P, D, Li, ttab, q, P.n_total, e2, g2);
+                long *ts = tier_stats();
+                ts[0] += 1; ts[1] += unsure ? 1 : 0;
+                tile_unsure |= unsure;
+                if ((idx & 63) == 63 || idx == S.n_cand - 1) { ts[2] += 1; ts[3] += tile_unsure ? 1 : 0; tile_unsure = false; }
+                if (!unsure) {
+                    CandResult r2;
+                    finish_candidate(P, D, Li, GlobalTab{ tab }, q, g2, e2.collided(), r2);
+                    if (r2.status != r.status || r2.keep != r.keep) {
+                        if (getenv("FOT_EMU_DEBUG")) fprintf(stderr, "tier2 cand %d status %d vs %d keep %d vs %d fl %x vs %x\n", idx, r2.status, r.status, r2.keep, r.keep, g2.acc.fl, 0u);
+                        return -130;
+                    }
+                    if (std::memcmp(&r2.cost, &r.cost, sizeof(double)) != 0) return -131;
                 }
             }
             for (int n_seg = 2; n_seg <= 4; ++n_seg) {   // k_evaluate_split: time segments merged == the single walk
