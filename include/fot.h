@@ -145,9 +145,9 @@ typedef struct fot_batch {
     const int32_t *static_off;           /* [n_inst+1] host, or NULL (no static obstacles) */
     /* dynamic_obstacles [P,T,2] / dynamic_obstacles_distribution [S,P,T,2] per instance, concatenated;
      * instance i starts at point dyn_off[i]; dyn_dims[i] = {mode, S, P, T} (S = 1 for FOT_DYN_SINGLE).
-     * Non-finite coordinates never hit.  The reference drops a pedestrian whose track holds a NaN at EVERY time
-     * step (np.min / np.max in its box pre-filter, frenet_planner.py:1211-1219): pass such a track as all-NaN to
-     * reproduce that (the Python packer does, batch.py). */
+     * Non-finite coordinates never hit, and a pedestrian whose track holds a NaN anywhere is no obstacle at ANY
+     * time step, as in the reference (np.min / np.max in its box pre-filter, frenet_planner.py:1211-1219): the
+     * library scans the tensor for such tracks itself, whoever produced it. */
     const void *dyn_xy;                  /* host | device */
     const int64_t *dyn_off;              /* [n_inst] host, or NULL (no dynamic obstacles) */
     const int32_t *dyn_dims;             /* [n_inst][4] host */
@@ -296,6 +296,56 @@ typedef struct fot_safety {
 int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const int32_t *ped_off,
                              const double *ped_pos, const double *ped_vel, double ego_radius, double ped_radius,
                              int32_t use_footprint, fot_safety *out);
+
+/* ---- the device work of one closed-loop step (IntegratedSimulator.step, integrated_simulator.py:678-747)
+ * of n episodes in two calls with ONE synchronisation each; the prediction tensor never leaves HBM.
+ *
+ * fot_loop_plan, with a frame: _update_prediction's constant-velocity branch (:424-527 -> trajectory_predictor.py
+ * :188-231) for the pedestrians of all episodes, written into the handle's own tensor -- per episode a [P_e][T_e][2]
+ * float64 block, T_e = n_dense + prepend[e] -- and compute_safety_metrics_static on the current ego states (:529-560);
+ * then n_req plan() calls (:562-600), request j against the block of episode req[j].episode.  Without a frame
+ * (NULL) the requests run against the tensor of the previous call: the escalation retries of one step (:602-644).
+ * *records points at n_req records in pinned host memory owned by the handle, valid until the next fot_loop_plan.
+ *
+ * fot_loop_observe: the metrics of the new ego states against the same frame's pedestrians (:864-870) and the arc
+ * length of the nearest point of the reference path (the goal test's converter, :873-883), ego i = episode i:
+ * ego5 [n][5] = x, y, yaw, v, a; prev_s [n], NaN = no cached arc length.  _begin enqueues the two launches and returns,
+ * _end waits and hands the results over (any may be NULL); no other call on the handle in between.
+ *
+ * fot_loop_set_static: the static obstacle points every request of the loop sees (kept in HBM, one copy per request). */
+typedef struct fot_loop_frame {
+    int32_t n_episodes;
+    int32_t pred_len;               /* of the predictor (trajectory_predictor.py:188) */
+    int32_t use_footprint;          /* as fot_safety_metrics_batch */
+    int32_t _pad;
+    const int32_t *ped_off;         /* [n_episodes + 1]: pedestrians of episode e = rows [ped_off[e], ped_off[e+1]) */
+    const double *ped_pos, *ped_vel;    /* [sum P][2] current positions / velocities */
+    const float *obs_last, *obs_prev;   /* [sum P][2] the observer's last two samples; obs_last NULL: the predictor is
+                                           not ready and the tensor is the current positions alone (T = 1, :495-498) */
+    const uint8_t *prepend;         /* [n_episodes] 1: the current positions lead the episode's tracks (:503-511) */
+    const double *ego;              /* [n_episodes][4] x, y, yaw, v for the metrics; NULL = no metrics */
+    double staleness;               /* time since the observer's last sample (:463-470) */
+    double ego_radius, ped_radius;
+    fot_resample_params rp;
+} fot_loop_frame;
+typedef struct fot_loop_request {
+    fot_ego ego;
+    fot_overrides overrides;
+    double target_speed;
+    double max_stop_distance;       /* NaN = None */
+    int32_t episode;                /* whose pedestrians */
+    int32_t _pad;
+} fot_loop_request;
+int fot_loop_set_static(fot_handle *h, int32_t n_points, const double *xy);
+int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, const fot_loop_request *req,
+                  fot_safety *safety_out, const fot_result **records);
+int fot_loop_observe(fot_handle *h, int32_t n, const double *ego5, const double *prev_s,
+                     fot_safety *safety_out, double *new_prev_s);
+int fot_loop_observe_begin(fot_handle *h, int32_t n, const double *ego5, const double *prev_s);
+int fot_loop_observe_end(fot_handle *h, fot_safety *safety_out, double *new_prev_s);
+/* Host utility (no GPU): the first kmax samples of the 15 path arrays of records[index[i]], i < n, as one dense block
+ * out[15][n][kmax] in fot_result array order (t .. c) -- what a history keeps of a step's records. */
+int fot_gather_paths(const fot_result *records, int32_t n, const int32_t *index, int32_t kmax, double *out);
 
 /* ---- compact wire form of the records, for the all-gather of selected paths across GPUs ------------
  * fot_result is the host view (float64, FOT_MAX_NT slots per array: 15 536 bytes).  On the wire a record is

@@ -82,6 +82,19 @@ class Safety(C.Structure):
                 ("clearance_ahead", C.c_double), ("collision", C.c_int32), ("_pad", C.c_int32)]
 
 
+class LoopFrame(C.Structure):                                      # fot_loop_frame
+    _fields_ = [("n_episodes", C.c_int32), ("pred_len", C.c_int32), ("use_footprint", C.c_int32), ("_pad", C.c_int32),
+                ("ped_off", C.c_void_p), ("ped_pos", C.c_void_p), ("ped_vel", C.c_void_p),
+                ("obs_last", C.c_void_p), ("obs_prev", C.c_void_p), ("prepend", C.c_void_p), ("ego", C.c_void_p),
+                ("staleness", C.c_double), ("ego_radius", C.c_double), ("ped_radius", C.c_double),
+                ("rp", ResampleParams)]
+
+
+class LoopRequest(C.Structure):                                    # fot_loop_request
+    _fields_ = [("ego", Ego), ("overrides", Overrides), ("target_speed", C.c_double),
+                ("max_stop_distance", C.c_double), ("episode", C.c_int32), ("_pad", C.c_int32)]
+
+
 class Batch(C.Structure):
     _fields_ = [("n_inst", C.c_int32), ("obstacle_dtype", C.c_int32),
                 ("ego", C.POINTER(Ego)), ("target_speed", C.POINTER(C.c_double)),
@@ -100,7 +113,7 @@ SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_se
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
            "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
-           "fot_predict_cv", "fot_safety_metrics_batch", "fot_wire_n_total", "fot_wire_record_bytes",
+           "fot_predict_cv", "fot_safety_metrics_batch", "fot_loop_set_static", "fot_loop_plan", "fot_loop_observe", "fot_loop_observe_begin", "fot_loop_observe_end", "fot_gather_paths", "fot_wire_n_total", "fot_wire_record_bytes",
            "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 3                      # FOT_PROFILE_KERNELS (include/fot.h)
 EGO_IS_FRENET = 3                        # FOT_EGO_IS_FRENET (fot_ego.has_prev_s)
@@ -233,6 +246,12 @@ def lib():
     L.fot_predict_cv.argtypes = [vp, C.POINTER(ResampleParams), C.c_int32, C.c_int32, vp, vp, C.c_int32, dp,
                                  C.c_double, vp, C.c_int32, C.c_int32, ip, vp]
     L.fot_safety_metrics_batch.argtypes = [vp, C.c_int32, dp, ip, dp, dp, C.c_double, C.c_double, C.c_int32, C.POINTER(Safety)]
+    L.fot_loop_set_static.argtypes = [vp, C.c_int32, vp]
+    L.fot_loop_plan.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+    L.fot_loop_observe.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    L.fot_loop_observe_begin.argtypes = [vp, C.c_int32, vp, vp]
+    L.fot_loop_observe_end.argtypes = [vp, vp, vp]
+    L.fot_gather_paths.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
     L.fot_wire_n_total.argtypes = [vp]
     L.fot_wire_record_bytes.argtypes = [C.c_int32]
     L.fot_pack_records_device.argtypes = [vp, C.c_int32, vp, vp, vp]

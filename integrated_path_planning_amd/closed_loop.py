@@ -189,13 +189,14 @@ class _VectorStateMachine:
 
 
 class EpisodeHistory:
-    """One episode's steps as a read-only sequence of ``StepRecord`` built on demand from the loop's per-step arrays."""
+    """One episode's steps as a read-only sequence of ``StepRecord`` built on demand from the loop's per-step arrays
+    (every episode takes part in every lock step from the first one until it ends: its step i is lock step i)."""
 
     def __init__(self, loop: "BatchedClosedLoop", e: int):
-        self._loop, self._e, self._steps = loop, e, []
+        self._loop, self._e = loop, e
 
     def __len__(self):
-        return len(self._steps)
+        return int(self._loop.step_counts[self._e])
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -205,14 +206,32 @@ class EpisodeHistory:
             return [self[k] for k in range(*i.indices(len(self)))]
         if i < 0:
             i += len(self)
-        return self._loop._record(self._steps[i], self._e)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._loop._record(i, self._e)
 
 
-@dataclass
+_TERMINATION = (None, "collision", "goal", "timeout")
+
+
 class Episode:
-    history: EpisodeHistory
-    termination_reason: Optional[str] = None
-    step_count: int = 0
+    """View of one episode of the loop: its history, how many steps it ran and why it ended (None while it runs)."""
+
+    def __init__(self, loop: "BatchedClosedLoop", e: int):
+        self._loop, self._e = loop, e
+        self.history = EpisodeHistory(loop, e)
+
+    @property
+    def step_count(self) -> int:
+        return int(self._loop.step_counts[self._e])
+
+    @property
+    def termination_reason(self) -> Optional[str]:
+        return _TERMINATION[int(self._loop.termination[self._e])]
+
+    @termination_reason.setter
+    def termination_reason(self, reason: Optional[str]) -> None:
+        self._loop.termination[self._e] = _TERMINATION.index(reason)
 
 
 def _cfg(config, name, default=None):
@@ -272,7 +291,7 @@ class BatchedClosedLoop:
     MAX_REPLAN = 3                                               # integrated_simulator.py:383
 
     def __init__(self, config, ped_tracks: Sequence[np.ndarray], ego_initial_states: Optional[Sequence] = None,
-                 device: int = -1, engine=None, resampler=None, sample_source=None):
+                 device: int = -1, engine=None, resampler=None, sample_source=None, fused: Optional[bool] = None):
         """sample_source: the multi-sample predictor in front of the planner -- a callable
         ``(obs_last [P, 2], obs_prev [P, 2]) -> raw samples [S, pred_len, P, 2]`` at the predictor's own time step
         (what S forward passes of Social-GAN on PyTorch-ROCm return for the pedestrians of all running episodes; the
@@ -307,6 +326,14 @@ class BatchedClosedLoop:
             k_lon=c.k_lon, chance_epsilon=getattr(c, "chance_epsilon", 0.0),
             collision_margin_inflation=getattr(c, "collision_margin_inflation", 1.0), footprint=self.footprint)
         self.s_end = float(self.engine.path_coeffs()[0][-1])
+        # the step's device work in two calls, prediction resident in HBM (fot_loop_*): the constant-velocity predictor
+        # on the library's own engine; a sample source hands its samples over on the host, stand-in engines have no device
+        can_fuse = sample_source is None and resampler is None and hasattr(self.engine, "loop_plan")
+        if fused and not can_fuse:
+            raise ValueError("fused=True needs the constant-velocity predictor on the library's own engine")
+        self._fused = can_fuse if fused is None else bool(fused)
+        if self._fused:
+            self.engine.loop_set_static(self.static_obstacle_points)
         self.sgan_dt = 0.4                                            # integrated_simulator.py:323-327
         self.resampler = resampler if resampler is not None else PredictionResampler(
             self.engine, pred_len=c.pred_len, sgan_dt=self.sgan_dt, sim_dt=c.dt, plan_horizon=getattr(c, "max_t", 5.0))
@@ -345,11 +372,27 @@ class BatchedClosedLoop:
         self.time = 0.0
         self.alive = np.ones(n, bool)
         self._steps: List[dict] = []
-        self.episodes: List[Episode] = [Episode(EpisodeHistory(self, e)) for e in range(n)]
+        # Where the selected paths of every step are kept (15 arrays x episodes x samples per step): chunks of whole steps,
+        # touched when they are allocated -- fresh pages cost the step that first writes them about as much as the device
+        # work of the whole step.  The first chunk covers the configured duration.
+        self._arena: List[np.ndarray] = []
+        self._arena_steps = 0
+        self._arena_slot = len(_abi.PATH_FIELDS) * max(n, 1) * int(getattr(self.engine, "n_total_samples", _abi.MAX_NT))
+        if hasattr(self.engine, "gather_paths"):
+            self._grow_arena(int(getattr(c, "total_time", 0.0) / self.dt) + 1)
+        self.step_counts = np.zeros(n, np.int64)                     # lock steps each episode took part in
+        self.termination = np.zeros(n, np.int8)                      # index into _TERMINATION
+        self.episodes: List[Episode] = [Episode(self, e) for e in range(n)]
         self._warmup()
 
     def close(self) -> None:
         """Release the libfot handle (streams, workspace) now rather than at garbage collection."""
+        if self.engine is not None:
+            for s in self._steps:                                     # predictions of fused steps nobody has read yet
+                if s["pred"] is None and s.get("pred_src") is not None:
+                    o32, stale = s["pred_src"]
+                    s["pred"] = self.resampler.predict_cv(o32, staleness=stale, float32_observations=True)
+                    s["pred_src"] = None
         if self._owns_engine and self.engine is not None:
             self.engine.close()
         self.engine = None
@@ -361,6 +404,25 @@ class BatchedClosedLoop:
         self.close()
 
     # ------------------------------------------------------------------------------------------------------
+    ARENA_CHUNK_BYTES = 1 << 28
+
+    def _grow_arena(self, steps: int) -> None:
+        steps = max(1, min(int(steps), self.ARENA_CHUNK_BYTES // (8 * self._arena_slot) or 1))
+        chunk = np.empty((steps, self._arena_slot))
+        chunk.fill(0.0)                                               # (touch the pages now, not inside a step)
+        self._arena.append(chunk)
+        self._arena_steps += steps
+
+    def _history_block(self, k: int, n: int, kmax: int) -> np.ndarray:
+        """[15, n, kmax] block of lock step k in the arena."""
+        while k >= self._arena_steps:
+            self._grow_arena(64)
+        for chunk in self._arena:
+            if k < len(chunk):
+                return chunk[k, : len(_abi.PATH_FIELDS) * n * kmax].reshape(len(_abi.PATH_FIELDS), n, kmax)
+            k -= len(chunk)
+        raise IndexError(k)
+
     def _ped_frame(self, which: str, sel: np.ndarray) -> np.ndarray:
         """positions / velocities of the episodes ``sel`` at the current frame, concatenated [sum P, 2]."""
         frame = self._ped_all[which][min(self.frame, len(self._ped_all[which]) - 1)]
@@ -447,16 +509,18 @@ class BatchedClosedLoop:
         off = np.concatenate([[0], np.cumsum(counts)])
         pos = self._ped_frame("trajectories", sel)
         vel = self._ped_frame("velocities", sel)
+        st0 = sm.state[sel]
+        n_lvl = np.minimum(3 - st0, 1 + self.MAX_REPLAN)             # NORMAL -> CAUTION -> EMERGENCY, then no change
+        everyone = np.arange(n)
+        speed = self.ego[sel, 3].copy()
+        if self._fused:
+            return self._step_fused(sel, off, counts, pos, vel, st0, n_lvl, everyone, speed)
         pred, prepend, t_pred, dist = self._predict(sel, off, pos)    # 2. prediction
         m = self._metrics(sel, off, pos, vel)                         # 3. planning cycle (:529-653)
         t0 = time.perf_counter()
         clearance, clearance_ahead = m["clearance"].copy(), m["clearance_ahead"].copy()
         self.last_clearance[sel] = clearance_ahead
-        speed = self.ego[sel, 3].copy()
         # --- level 0 of every episode = the current state's configuration (issued from LAST step's clearance)
-        st0 = sm.state[sel]
-        n_lvl = np.minimum(3 - st0, 1 + self.MAX_REPLAN)             # NORMAL -> CAUTION -> EMERGENCY, then no change
-        everyone = np.arange(n)
         # --- obstacles: the same static points for every request; one dynamic tensor per episode, shared by its levels
         pts = self.static_obstacle_points
         if pred is None:                                              # not ready: current positions only (:495-498)
@@ -509,7 +573,74 @@ class BatchedClosedLoop:
             d_dims = np.stack([mode[who], n_smp[who], counts[who], t_len[who]], axis=1)
             return self.engine.plan_arrays(ego, tgt, ov, stop, s_xy, s_off, d_xy, d_off_ep[who], d_dims)
 
-        rec = plan(everyone, st0, sm.clear_ahead[sel], self.prev_s[sel], np.zeros(n, bool))
+        return self._finish_step(sel, off, pos, vel, pred, None, t_pred, t0, plan, st0, n_lvl, everyone, speed, clearance,
+                                 clearance_ahead, lambda new_ego: (lambda r=(self._metrics(sel, off, pos, vel), self.engine.nearest_s_arrays(
+                                     new_ego[:, 0], new_ego[:, 1], new_ego[:, 2], new_ego[:, 3], new_ego[:, 4],
+                                     self.goal_prev_s[sel])): r))
+
+    def _step_fused(self, sel, off, counts, pos, vel, st0, n_lvl, everyone, speed):
+        """Steps 2-5 with the device work in two libfot calls (fot_loop_plan / fot_loop_observe): prediction, current
+        metrics and the level-0 plans in one enqueue -- the prediction tensor is written and read in HBM --, the new
+        state's metrics and the goal test's nearest point in another.  The step record keeps the observer's two samples
+        instead of the prediction, which is computed again (same kernel, same numbers) if somebody reads it."""
+        sm = self.sm
+        n = len(sel)
+        t0 = time.perf_counter()
+        frame = dict(ped_off=off, ped_pos=pos, ped_vel=vel, ego=self.ego[sel, :4], ego_radius=self.ego_radius,
+                     ped_radius=self.ped_radius, use_footprint=self.footprint is not None)
+        pred_src = None
+        if self.observer.is_ready:
+            rows = self._rows_of(sel)
+            hist = self.observer.history
+            o32 = np.stack([hist[-2][rows], hist[-1][rows]], axis=0).astype(np.float32)
+            last = self.observer.last_sample_time
+            stale = max(self.ped_time - last, 0.0) if last is not None else 0.0
+            # np.allclose(pred[:, 0], current) (:503-511) needs the first predicted sample only: obs_last + v (dt + stale),
+            # the velocity formed in float32 as the kernel (and the reference, trajectory_predictor.py:216) forms it
+            vel32 = (o32[1] - o32[0]) / np.float32(self.sgan_dt)
+            first = o32[1].astype(np.float64) + vel32.astype(np.float64) * ((self.dt + 0.0 * self.dt) + stale)
+            far = np.any(np.abs(first - pos) > 1e-8 + 1e-5 * np.abs(pos), axis=1)
+            n_far = np.concatenate([[0], np.cumsum(far)])
+            same = n_far[off[1:]] == n_far[off[:-1]]                  # per episode (True without pedestrians)
+            frame.update(obs_last=o32[1], obs_prev=o32[0], prepend=~same, staleness=stale,
+                         pred_len=self.resampler.pred_len, rp=self.resampler.params)
+            pred_src = (o32, stale)
+
+        def requests(who, state, clear_ahead, prev_s, chain):
+            # fot_loop_request is 15 eight-byte slots: x y yaw v a last_kappa prev_s | has_prev_s, pad | 4 overrides |
+            # target_speed max_stop_distance | episode, pad -- filled column-wise through a float64 / int32 view
+            tgt, ov, stop = sm.config(state, clear_ahead)
+            req = np.zeros(len(who), dtype=self.engine.LOOP_REQUEST_DT)
+            f64 = req.view(np.float64).reshape(len(who), 15)
+            i32 = req.view(np.int32).reshape(len(who), 30)
+            f64[:, 0:5] = self.ego[sel[who]]
+            f64[:, 5] = self.last_kappa[sel[who]]
+            f64[:, 6] = np.where(chain | np.isnan(prev_s), 0.0, prev_s)
+            i32[:, 14] = np.where(chain, 2, ~np.isnan(prev_s))
+            f64[:, 8:12] = ov
+            f64[:, 12], f64[:, 13] = tgt, stop
+            i32[:, 28] = who
+            return req
+
+        rec0, m = self.engine.loop_plan(requests(everyone, st0, sm.clear_ahead[sel], self.prev_s[sel], np.zeros(n, bool)),
+                                        frame)
+        t_pred = 0.0                                                  # (inside the one call: not separable)
+        clearance, clearance_ahead = m["clearance"].copy(), m["clearance_ahead"].copy()
+        self.last_clearance[sel] = clearance_ahead
+        plan = lambda *a: self.engine.loop_plan(requests(*a))[0]
+        return self._finish_step(sel, off, pos, vel, None, pred_src, t_pred, t0, plan, st0, n_lvl, everyone, speed,
+                                 clearance, clearance_ahead, lambda new_ego: self.engine.loop_observe_begin(new_ego, self.goal_prev_s[sel]),
+                                 first=rec0)
+
+    def _finish_step(self, sel, off, pos, vel, pred, pred_src, t_pred, t0, plan, st0, n_lvl, everyone, speed, clearance,
+                     clearance_ahead, observe, first=None):
+        """The rest of a lock step, whoever planned: replay of the retry loop, ego update, result metrics, history.
+        ``plan(who, state, clear_ahead, prev_s, chain)`` -> records; ``observe(new_ego)`` -> a callable that returns
+        (metrics, nearest s) -- the fused step enqueues the two launches and collects them behind the bookkeeping;
+        ``first``: the records of level 0 when they were planned already (with the frame's prediction and metrics)."""
+        c, sm = self.config, self.sm
+        n = len(sel)
+        rec = first if first is not None else plan(everyone, st0, sm.clear_ahead[sel], self.prev_s[sel], np.zeros(n, bool))
         # --- replay of the retry loop (:576-653).  Episodes whose first attempt failed get every further escalation
         #     level they can reach planned in ONE more launch (the configurations update(False, ...) would issue on THIS
         #     step's metrics, nearest-point cache chained from attempt to attempt); the control flow is then replayed.
@@ -523,8 +654,9 @@ class BatchedClosedLoop:
             base1 = np.concatenate([[0], np.cumsum(extra)])[:-1]
             lvl = 1 + np.arange(len(who)) - np.repeat(base1, extra)
             nps0 = rec["new_prev_s"][who]
-            rec = np.concatenate([rec, plan(who, st0[who] + lvl, clearance_ahead[who],
-                                            np.where(np.isnan(nps0), self.prev_s[sel][who], nps0), lvl > 1)])
+            head = rec.copy()                                         # (a view of the handle's block when fused)
+            rec = np.concatenate([head, plan(who, st0[who] + lvl, clearance_ahead[who],
+                                             np.where(np.isnan(nps0), self.prev_s[sel][who], nps0), lvl > 1)])
             found_all = rec["status"] == 0
             next_rec = np.full(n, -1, np.int64)                       # record of level 1 of each failed episode
             next_rec[failed] = n + base1
@@ -589,30 +721,28 @@ class BatchedClosedLoop:
             self.last_kappa[sel[brake]] = 0.0                         # planner.reset_ego_curvature()
         self.ego[sel], self.jerk[sel] = new_ego, jerk
         # --- 5. result metrics on the new ego state, goal test (:864-883)
-        after = self._metrics(sel, off, pos, vel)
-        s_now = self.engine.nearest_s_arrays(new_ego[:, 0], new_ego[:, 1], new_ego[:, 2], new_ego[:, 3], new_ego[:, 4],
-                                             self.goal_prev_s[sel])
-        self.goal_prev_s[sel] = s_now
+        pending = observe(new_ego)                                    # enqueued; collected below, behind the bookkeeping
         chosen = np.maximum(path_rec, 0)
         kmax = int(keep.max()) if n else 0
         slot = np.full(len(self.episodes), -1, np.int64)
         slot[sel] = everyone
+        if hasattr(self.engine, "gather_paths"):                      # one dense block, copied by the library
+            block = self.engine.gather_paths(rec, chosen, kmax, out=self._history_block(len(self._steps), n, kmax))
+            paths = {f: block[j] for j, f in enumerate(_abi.PATH_FIELDS)}
+        else:
+            paths = {f: rec[f][chosen, :kmax].copy() for f in _abi.PATH_FIELDS}
+        after, s_now = pending()
+        self.goal_prev_s[sel] = s_now
         self._steps.append(dict(
             time=self.time, slot=slot, off=off, ego=new_ego, jerk=jerk, state=sm.state[sel].copy(), pos=pos, vel=vel,
-            pred=pred, after=after, stats=self.last_stats[sel].copy(), has_path=path_rec >= 0, keep=keep,
-            cost=rec["cost"][chosen], paths={f: rec[f][chosen, :kmax].copy() for f in _abi.PATH_FIELDS},
+            pred=pred, pred_src=pred_src, after=after, stats=self.last_stats[sel].copy(), has_path=path_rec >= 0, keep=keep,
+            cost=rec["cost"][chosen], paths=paths,
             t_pred=t_pred, t_plan=t_plan, sel=sel))
-        k = len(self._steps) - 1
         collided = after["collision"] != 0
         at_goal = self.s_end - s_now < 2.0
-        for i, e in enumerate(sel):
-            ep = self.episodes[e]
-            ep.history._steps.append(k)
-            ep.step_count += 1
-            if collided[i]:
-                ep.termination_reason = "collision"
-            elif at_goal[i]:
-                ep.termination_reason = "goal"
+        self.step_counts[sel] += 1
+        self.termination[sel[at_goal & ~collided]] = 2
+        self.termination[sel[collided]] = 1
         self.alive[sel[collided | at_goal]] = False
         self.time += self.dt
         return n
@@ -635,6 +765,10 @@ class BatchedClosedLoop:
         if s["stats"][i, 0] >= 0:
             m["n_collision_rejected"] = int(s["stats"][i, _abi.ST_COLLISION])
         p = self.peds[e]
+        if s["pred"] is None and s.get("pred_src") is not None:       # fused step: the prediction stayed in HBM
+            o32, stale = s["pred_src"]
+            s["pred"] = self.resampler.predict_cv(o32, staleness=stale, float32_observations=True)
+            s["pred_src"] = None
         return StepRecord(s["time"], ego, s["pos"][lo:hi].copy(), s["vel"][lo:hi].copy(), p.goals.copy(),
                           None if s["pred"] is None else s["pred"][lo:hi], path, m,
                           {"prediction": s["t_pred"], "planning": s["t_plan"]})

@@ -86,6 +86,29 @@ struct Workspace {
     }
 };
 
+// fot_loop_*: what one closed-loop step leaves behind for the step's later calls
+struct LoopState {
+    PinnedBuf hFrame, hObserve, hOut, hRec;  // frame inputs | fot_loop_observe's inputs | small outputs | records
+    DevBuf dDyn, dStatic;                    // the prediction tensor; the static points, one copy per request
+    std::vector<double> static_xy;           // host copy of the static points
+    int static_tiles = 0;                    // copies resident in dStatic
+    std::vector<int32_t> ped_off;            // of the frame
+    std::vector<int64_t> blk_off;            // first point of each episode's block in the tensor
+    std::vector<int32_t> t_len;              // samples per track of each episode's block
+    bool have_frame = false;
+    const void *dyn_ptr = nullptr;           // the tensor: dDyn, or the pinned current positions (predictor not ready)
+    const int32_t *p_off = nullptr;          // the frame's pedestrians in hFrame
+    const double *p_pos = nullptr, *p_vel = nullptr;
+    double ego_radius = 0.0, ped_radius = 0.0;
+    int use_footprint = 0;
+    int observe_n = -1;                      // egos of a fot_loop_observe_begin not collected yet
+    void release()
+    {
+        hFrame.release(); hObserve.release(); hOut.release(); hRec.release();
+        dDyn.release(); dStatic.release();
+    }
+};
+
 constexpr int FOT_LANES = 4;                  // lanes available; lanes_cfg of them are used (FOT_LANES env, default 1)
 constexpr int FOT_SPLIT_MIN_INSTANCES = 32;  // smaller batches run as one piece on the caller's stream
 
@@ -115,6 +138,7 @@ struct fot_handle {
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     PinnedBuf hSmallIn, hSmallOut;           // ... and, for small calls, pinned host blocks the kernels use directly
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
+    LoopState loop;
     bool last_valid = false;
     // profiling: event pairs around kernel launches
     bool prof_on = false;
@@ -478,6 +502,7 @@ void fot_destroy(fot_handle *h)
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
     h->hSmallIn.release(); h->hSmallOut.release();
+    h->loop.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->order_done) (void)hipEventDestroy(h->order_done);
@@ -732,6 +757,220 @@ int fot_safety_metrics_batch(fot_handle *h, int32_t n, const double *ego, const 
                                 h->params.footprint_radius, use_footprint, h->dTmpC.as<fot_safety>(), st));
     HIP_TRY(h, hipMemcpyAsync(out, h->dTmpC.p, sizeof(fot_safety) * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
+    return FOT_OK;
+}
+
+int fot_loop_set_static(fot_handle *h, int32_t n_points, const double *xy)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n_points < 0 || (n_points > 0 && !xy)) return fail(h, FOT_ERR_INVALID, "static points");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                 // nothing may still be reading the old copies
+    h->loop.static_xy.assign(xy, xy + 2 * (size_t)n_points);
+    h->loop.static_tiles = 0;
+    return FOT_OK;
+}
+
+int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, const fot_loop_request *req,
+                  fot_safety *safety_out, const fot_result **records)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    if (n_req < 0 || (n_req > 0 && (!req || !records))) return fail(h, FOT_ERR_INVALID, "requests");
+    LoopState &L = h->loop;
+    if (!frame && !L.have_frame) return fail(h, FOT_ERR_INVALID, "no frame: the first fot_loop_plan of a step carries one");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    { int r = order_begin(h, st); if (r != FOT_OK) return r; }
+    bool metrics = false;
+    if (frame) {
+        const int n = frame->n_episodes;
+        if (n < 0 || (n > 0 && !frame->ped_off)) return fail(h, FOT_ERR_INVALID, "frame: n_episodes / ped_off");
+        L.have_frame = false;
+        for (int i = 0; i < n; ++i)
+            if (frame->ped_off[i + 1] < frame->ped_off[i] || frame->ped_off[0] != 0)
+                return fail(h, FOT_ERR_INVALID, "ped_off must start at 0 and be non-decreasing");
+        const size_t n_ped = n > 0 ? (size_t)frame->ped_off[n] : 0;
+        if (n_ped > 0 && (!frame->ped_pos || !frame->ped_vel)) return fail(h, FOT_ERR_INVALID, "frame: NULL pedestrian array");
+        const bool ready = frame->obs_last != nullptr;
+        if (ready && n > 0 && !frame->prepend) return fail(h, FOT_ERR_INVALID, "frame: prepend missing");
+        if (ready && (!(frame->rp.sim_dt > 0.0) || !(frame->rp.sgan_dt > 0.0) || frame->pred_len < 1 ||
+                      frame->pred_len > FOT_MAX_PRED_LEN))
+            return fail(h, FOT_ERR_INVALID, "frame: predictor parameters");
+        const int n_dense = ready ? resample_n_dense(frame->rp.sgan_dt, frame->rp.sim_dt, frame->rp.plan_horizon, frame->pred_len) : 1;
+        if (n_dense + 1 > FOT_MAX_NT) return fail(h, FOT_ERR_UNSUPPORTED, "more than FOT_MAX_NT time steps");
+        // pinned block: ego[n][4] | ped_off | pos | vel | obs_last (widened) | obs_prev (widened)
+        const size_t ego_b = align256(sizeof(double) * 4 * (size_t)std::max(n, 1));
+        const size_t off_b = align256(sizeof(int32_t) * ((size_t)n + 1));
+        const size_t ped_b = align256(sizeof(double) * 2 * std::max<size_t>(n_ped, 1));
+        HIP_TRY(h, L.hFrame.ensure(ego_b + off_b + 4 * ped_b));
+        char *p = (char *)L.hFrame.p;
+        double *p_ego = (double *)p;
+        int32_t *p_off = (int32_t *)(p + ego_b);
+        double *p_pos = (double *)(p + ego_b + off_b), *p_vel = (double *)((char *)p_pos + ped_b);
+        double *p_last = (double *)((char *)p_vel + ped_b), *p_prev = (double *)((char *)p_last + ped_b);
+        if (frame->ego) std::memcpy(p_ego, frame->ego, sizeof(double) * 4 * (size_t)n);
+        std::memcpy(p_off, frame->ped_off, sizeof(int32_t) * ((size_t)n + 1));
+        if (n_ped) {
+            std::memcpy(p_pos, frame->ped_pos, sizeof(double) * 2 * n_ped);
+            std::memcpy(p_vel, frame->ped_vel, sizeof(double) * 2 * n_ped);
+            if (ready) for (size_t i = 0; i < 2 * n_ped; ++i) p_last[i] = (double)frame->obs_last[i];   // (exact)
+            if (ready && frame->obs_prev) for (size_t i = 0; i < 2 * n_ped; ++i) p_prev[i] = (double)frame->obs_prev[i];
+        }
+        L.ped_off.assign(frame->ped_off, frame->ped_off + n + 1);
+        L.blk_off.assign((size_t)n + 1, 0);
+        L.t_len.assign((size_t)std::max(n, 1), 1);
+        for (int e = 0; e < n; ++e) {
+            L.t_len[e] = ready ? n_dense + (frame->prepend[e] ? 1 : 0) : 1;
+            L.blk_off[e + 1] = L.blk_off[e] + (int64_t)(L.ped_off[e + 1] - L.ped_off[e]) * L.t_len[e];
+        }
+        L.p_off = p_off; L.p_pos = p_pos; L.p_vel = p_vel;
+        L.ego_radius = frame->ego_radius; L.ped_radius = frame->ped_radius; L.use_footprint = frame->use_footprint;
+        L.dyn_ptr = p_pos;                                         // not ready: the current positions, read in place
+        if (ready && n_ped > 0) {
+            HIP_TRY(h, L.dDyn.ensure(sizeof(double) * 2 * (size_t)L.blk_off[n]));
+            L.dyn_ptr = L.dDyn.p;
+            // one launch per run of episodes that agree on the prepend (normally one run: the whole frame)
+            for (int e0 = 0; e0 < n;) {
+                int e1 = e0 + 1;
+                while (e1 < n && (frame->prepend[e1] != 0) == (frame->prepend[e0] != 0)) ++e1;
+                const int r0 = L.ped_off[e0], cnt = L.ped_off[e1] - r0, pre = frame->prepend[e0] ? 1 : 0;
+                if (cnt > 0)
+                    LAUNCH_TRY(h, launch_resample(frame->rp.sgan_dt, frame->rp.sim_dt, frame->staleness, 1, frame->pred_len,
+                                                  cnt, n_dense, 1, pre, 2, frame->obs_prev ? p_prev + 2 * (size_t)r0 : nullptr,
+                                                  FOT_F64, p_last + 2 * (size_t)r0, pre ? p_pos + 2 * (size_t)r0 : nullptr,
+                                                  L.dDyn.as<double>() + 2 * L.blk_off[e0], FOT_F64, 0, st));
+                e0 = e1;
+            }
+        }
+        if (frame->ego && safety_out && n > 0) {
+            HIP_TRY(h, L.hOut.ensure(sizeof(fot_safety) * (size_t)n));
+            LAUNCH_TRY(h, launch_safety(h->dP.as<DevParams>(), n, p_ego, p_off, p_pos, p_vel, L.ego_radius, L.ped_radius,
+                                        h->params.footprint_radius, L.use_footprint, (fot_safety *)L.hOut.p, st));
+            metrics = true;
+        }
+        L.have_frame = true;
+    }
+    const int n_ep = (int)L.ped_off.size() - 1;
+    if (n_req > 0) {
+        const int n_static = (int)(L.static_xy.size() / 2);
+        if (n_static > 0 && L.static_tiles < n_req) {              // (grows a few times in the life of a loop)
+            const int tiles = std::max(n_req, 2 * L.static_tiles);
+            std::vector<double> rep((size_t)tiles * L.static_xy.size());
+            for (int t = 0; t < tiles; ++t)
+                std::memcpy(rep.data() + (size_t)t * L.static_xy.size(), L.static_xy.data(), sizeof(double) * L.static_xy.size());
+            HIP_TRY(h, hipStreamSynchronize(st));
+            HIP_TRY(h, L.dStatic.ensure(sizeof(double) * rep.size()));
+            HIP_TRY(h, hipMemcpy(L.dStatic.p, rep.data(), sizeof(double) * rep.size(), hipMemcpyHostToDevice));
+            L.static_tiles = tiles;
+        }
+        std::vector<fot_ego> ego((size_t)n_req);
+        std::vector<fot_overrides> ov((size_t)n_req);
+        std::vector<double> tgt((size_t)n_req), stop((size_t)n_req);
+        std::vector<int32_t> s_off((size_t)n_req + 1), dims(4 * (size_t)n_req);
+        std::vector<int64_t> d_off((size_t)n_req);
+        bool any_dyn = false;
+        for (int j = 0; j < n_req; ++j) {
+            const int e = req[j].episode;
+            if (e < 0 || e >= n_ep) return fail(h, FOT_ERR_INVALID, "request: episode out of range");
+            ego[j] = req[j].ego; ov[j] = req[j].overrides; tgt[j] = req[j].target_speed; stop[j] = req[j].max_stop_distance;
+            s_off[j] = j * n_static;
+            const int P_e = L.ped_off[e + 1] - L.ped_off[e];
+            d_off[j] = L.blk_off[e];
+            dims[4 * j] = P_e > 0 ? FOT_DYN_SINGLE : FOT_DYN_NONE; dims[4 * j + 1] = 1; dims[4 * j + 2] = P_e; dims[4 * j + 3] = L.t_len[e];
+            any_dyn = any_dyn || P_e > 0;
+        }
+        s_off[n_req] = n_req * n_static;
+        fot_batch b = fot_batch();
+        b.n_inst = n_req; b.obstacle_dtype = FOT_F64;
+        b.ego = ego.data(); b.target_speed = tgt.data(); b.overrides = ov.data(); b.max_stop_distance = stop.data();
+        if (n_static > 0) { b.static_xy = L.dStatic.p; b.static_off = s_off.data(); }
+        if (any_dyn) { b.dyn_xy = L.dyn_ptr; b.dyn_off = d_off.data(); b.dyn_dims = dims.data(); }
+        HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * (size_t)n_req));
+        int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st);
+        if (rc != FOT_OK) return rc;
+    } else {
+        int r = order_end(h, st); if (r != FOT_OK) return r;
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (metrics) std::memcpy(safety_out, L.hOut.p, sizeof(fot_safety) * (size_t)n_ep);
+    if (records) *records = n_req > 0 ? (const fot_result *)L.hRec.p : nullptr;
+    return FOT_OK;
+}
+
+int fot_loop_observe_begin(fot_handle *h, int32_t n, const double *ego5, const double *prev_s)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
+    LoopState &L = h->loop;
+    L.observe_n = -1;
+    if (!L.have_frame) return fail(h, FOT_ERR_INVALID, "no frame: fot_loop_plan of this step comes first");
+    if (n != (int)L.ped_off.size() - 1) return fail(h, FOT_ERR_INVALID, "one ego per episode of the frame");
+    if (n <= 0) { L.observe_n = 0; return FOT_OK; }
+    if (!ego5) return fail(h, FOT_ERR_INVALID, "ego5 is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    { int r = order_begin(h, st); if (r != FOT_OK) return r; }
+    const size_t ego_b = align256(sizeof(double) * 4 * (size_t)n), desc_b = align256(sizeof(InstDesc) * (size_t)n);
+    const size_t saf_b = align256(sizeof(fot_safety) * (size_t)n);
+    HIP_TRY(h, L.hObserve.ensure(ego_b + desc_b));
+    HIP_TRY(h, L.hOut.ensure(saf_b + sizeof(InstState) * (size_t)n));
+    double *p_ego = (double *)L.hObserve.p;
+    InstDesc *p_desc = (InstDesc *)((char *)L.hObserve.p + ego_b);
+    for (int i = 0; i < n; ++i) {
+        const double *e = ego5 + 5 * (size_t)i;
+        p_ego[4 * i] = e[0]; p_ego[4 * i + 1] = e[1]; p_ego[4 * i + 2] = e[2]; p_ego[4 * i + 3] = e[3];
+        InstDesc d = InstDesc();
+        d.ego.x = e[0]; d.ego.y = e[1]; d.ego.yaw = e[2]; d.ego.v = e[3]; d.ego.a = e[4];
+        const bool cached = prev_s && !std::isnan(prev_s[i]);
+        d.ego.has_prev_s = cached ? 1 : 0;
+        d.ego.prev_s = cached ? prev_s[i] : 0.0;
+        p_desc[i] = d;
+    }
+    LAUNCH_TRY(h, launch_safety(h->dP.as<DevParams>(), n, p_ego, L.p_off, L.p_pos, L.p_vel, L.ego_radius, L.ped_radius,
+                                h->params.footprint_radius, L.use_footprint, (fot_safety *)L.hOut.p, st));
+    InstState *p_state = (InstState *)((char *)L.hOut.p + saf_b);
+    LAUNCH_TRY(h, launch_frenet_state(h->dP.as<DevParams>(), spline_view(h), p_desc, p_state, n, MetaImport(), NanScan(),
+                                      nullptr, st));
+    { int r = order_end(h, st); if (r != FOT_OK) return r; }
+    L.observe_n = n;
+    return FOT_OK;
+}
+
+int fot_loop_observe_end(fot_handle *h, fot_safety *safety_out, double *new_prev_s)
+{
+    if (!h) return FOT_ERR_INVALID;
+    LoopState &L = h->loop;
+    const int n = L.observe_n;
+    if (n < 0) return fail(h, FOT_ERR_INVALID, "no fot_loop_observe_begin to collect");
+    L.observe_n = -1;
+    if (n == 0) return FOT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (safety_out) std::memcpy(safety_out, L.hOut.p, sizeof(fot_safety) * (size_t)n);
+    const InstState *p_state = (const InstState *)((const char *)L.hOut.p + align256(sizeof(fot_safety) * (size_t)n));
+    if (new_prev_s) for (int i = 0; i < n; ++i) new_prev_s[i] = p_state[i].new_prev_s;
+    return FOT_OK;
+}
+
+int fot_loop_observe(fot_handle *h, int32_t n, const double *ego5, const double *prev_s,
+                     fot_safety *safety_out, double *new_prev_s)
+{
+    int rc = fot_loop_observe_begin(h, n, ego5, prev_s);
+    return rc != FOT_OK ? rc : fot_loop_observe_end(h, safety_out, new_prev_s);
+}
+
+int fot_gather_paths(const fot_result *records, int32_t n, const int32_t *index, int32_t kmax, double *out)
+{
+    if (n < 0 || kmax < 0 || kmax > FOT_MAX_NT) return FOT_ERR_INVALID;
+    if (n == 0 || kmax == 0) return FOT_OK;
+    if (!records || !index || !out) return FOT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (index[i] < 0) return FOT_ERR_INVALID;
+        const double *src = records[index[i]].t;                 // the 15 arrays lie back to back (static_assert below)
+        for (int f = 0; f < 15; ++f)
+            std::memcpy(out + ((size_t)f * n + i) * kmax, src + (size_t)f * FOT_MAX_NT, sizeof(double) * (size_t)kmax);
+    }
     return FOT_OK;
 }
 

@@ -1299,6 +1299,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     __shared__ LonQuartic s_linfo[CULL_PBOX];
     __shared__ uint8_t s_lext[CULL_PBOX];
     const DevParams &P = *Pp;
+    if (ablate & 32) return;                                     // (timing diagnostics: the launch alone)
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
     // dynamic LDS behind the spline, sized by the planner's horizons (launch_cull): the lateral extent per horizon /
     // brake-ladder entry and step, and the two extreme lateral quintics of every horizon
@@ -1333,6 +1334,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         lateral_extent_coeffs(P, S.frenet0, brake, brake ? P.brake[tid - P.n_ti] : P.ti[tid], s_latq + tid * 9);
     }
     __syncthreads();
+    if (ablate & 16) return;                                     // (timing diagnostics: launch + per-instance constants)
 
     const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
     const int n_dyn = dyn_on ? D.S * D.P : 0;
@@ -1412,7 +1414,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             }
         };
         constexpr int UNROLL = 4;                                 // gathers in flight per lane
-        if (D.n_static == 0) {
+        if (ablate & 64) {                                        // (timing diagnostics: no gathers)
+        } else if (D.n_static == 0) {
             // only the prediction tensor (the usual case): a lane's obstacles are a fixed number of bytes apart, so the
             // address is a running pointer instead of two 64-bit multiply-adds and a select per gather
             const char *p0 = (const char *)(dyn_xy + 2 * (D.dyn_off + (tmajor ? (int64_t)row_l * n_dyn + i_first

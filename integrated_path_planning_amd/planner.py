@@ -299,6 +299,111 @@ class BatchPlanner:
         _abi.check(self._h, f(self._h, n, _addr(ego), None, None, _addr(nps), None))
         return nps[:n]
 
+    # -- one closed-loop step in two calls (fot_loop_*): the prediction tensor stays in HBM -------------------------
+    LOOP_REQUEST_DT = np.dtype(_abi.LoopRequest)
+
+    def loop_set_static(self, points: Optional[np.ndarray]) -> None:
+        """The static obstacle points every request of the loop sees (``fot_loop_set_static``)."""
+        pts = np.ascontiguousarray(np.empty((0, 2)) if points is None else points, dtype=np.float64).reshape(-1, 2)
+        _abi.check(self._h, self._lib.fot_loop_set_static(self._h, len(pts), _addr(pts) if len(pts) else None))
+
+    def loop_plan(self, requests: np.ndarray, frame: Optional[dict] = None):
+        """``fot_loop_plan``: constant-velocity prediction of the frame's pedestrians into the handle's own tensor,
+        safety metrics of the current ego states, and the requests' plan() calls against that tensor -- one
+        synchronisation.  ``requests``: structured [r] of ``LOOP_REQUEST_DT``.  ``frame`` (None = the tensor of the
+        previous call): ped_off [n+1], ped_pos / ped_vel [sum P, 2], obs_last / obs_prev [sum P, 2] float32 or None
+        (predictor not ready), prepend [n] bool, ego [n, 4] (x, y, yaw, v) or None, staleness, pred_len, rp
+        (``_abi.ResampleParams``), ego_radius, ped_radius, use_footprint.
+        Returns (records, metrics): the records as a structured VIEW of the handle's pinned block (valid until the next
+        ``loop_plan``: copy what outlives it) and the metrics [n] of ``SAFETY_DT`` (None without a frame or egos)."""
+        req = np.ascontiguousarray(requests, dtype=self.LOOP_REQUEST_DT)
+        r = int(req.shape[0])
+        fr_addr, metrics, keep = None, None, []
+        if frame is not None:
+            f = _abi.LoopFrame()
+            off = np.ascontiguousarray(frame["ped_off"], dtype=np.int32)
+            n = len(off) - 1
+            f.n_episodes, f.pred_len = n, int(frame.get("pred_len", 1))
+            f.use_footprint = int(bool(frame.get("use_footprint", True)))
+            pos = np.ascontiguousarray(frame["ped_pos"], dtype=np.float64)
+            vel = np.ascontiguousarray(frame["ped_vel"], dtype=np.float64)
+            f.ped_off, f.ped_pos, f.ped_vel = _addr(off), _addr(pos) if pos.size else None, _addr(vel) if vel.size else None
+            keep += [off, pos, vel]
+            if frame.get("obs_last") is not None:
+                last = np.ascontiguousarray(frame["obs_last"], dtype=np.float32)
+                pre = np.ascontiguousarray(frame["prepend"], dtype=np.uint8)
+                f.obs_last, f.prepend = _addr(last), _addr(pre) if pre.size else None
+                keep += [last, pre]
+                if frame.get("obs_prev") is not None:
+                    prev = np.ascontiguousarray(frame["obs_prev"], dtype=np.float32)
+                    f.obs_prev = _addr(prev)
+                    keep.append(prev)
+                f.rp = frame["rp"]
+            if frame.get("ego") is not None:
+                ego = np.ascontiguousarray(frame["ego"], dtype=np.float64).reshape(n, 4)
+                f.ego = _addr(ego)
+                keep.append(ego)
+                metrics = np.zeros(max(n, 1), dtype=self.SAFETY_DT)
+            f.staleness = float(frame.get("staleness", 0.0))
+            f.ego_radius, f.ped_radius = float(frame["ego_radius"]), float(frame["ped_radius"])
+            fr_addr = C.addressof(f)
+        rec_ptr = C.c_void_p(0)
+        fn = _fast(self._lib, "fot_loop_plan", _vp, _vp, C.c_int32, _vp, _vp, _vp)
+        _abi.check(self._h, fn(self._h, fr_addr, r, _addr(req) if r else None,
+                               _addr(metrics) if metrics is not None else None, C.addressof(rec_ptr)))
+        if r and rec_ptr.value:
+            buf = (C.c_char * (r * _abi.RESULT_BYTES)).from_address(rec_ptr.value)
+            records = np.frombuffer(buf, dtype=self.RESULT_DT, count=r)
+        else:
+            records = np.zeros(0, dtype=self.RESULT_DT)
+        return records, (metrics[:n] if metrics is not None else None)
+
+    def gather_paths(self, records: np.ndarray, index: np.ndarray, kmax: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """The first ``kmax`` samples of the 15 path arrays of ``records[index]`` as one dense [15, n, kmax] block
+        (``fot_gather_paths``; ``_abi.PATH_FIELDS`` order), written into ``out`` (C-contiguous, that shape) if given."""
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        shape = (len(_abi.PATH_FIELDS), len(idx), int(kmax))
+        if out is None:
+            out = np.empty(shape)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float64 array of shape {shape}")
+        if out.size:
+            fn = _fast(self._lib, "fot_gather_paths", _vp, C.c_int32, _vp, C.c_int32, _vp)
+            rc = fn(_addr(records), len(idx), _addr(idx), int(kmax), _addr(out))
+            if rc != 0:
+                raise _abi.FotError(rc, "fot_gather_paths: bad index or length")
+        return out
+
+    def loop_observe(self, ego5: np.ndarray, prev_s: np.ndarray):
+        """``fot_loop_observe``: safety metrics of the new ego states [n, 5] (x, y, yaw, v, a; ego i = episode i of
+        the frame) against the frame's pedestrians, and the arc length of their nearest path point (prev_s NaN = no
+        cached arc length) -- one synchronisation.  Returns (metrics [n] of ``SAFETY_DT``, s [n])."""
+        ego = np.ascontiguousarray(ego5, dtype=np.float64).reshape(-1, 5)
+        n = ego.shape[0]
+        ps = np.ascontiguousarray(prev_s, dtype=np.float64)
+        metrics = np.zeros(max(n, 1), dtype=self.SAFETY_DT)
+        s = np.zeros(max(n, 1))
+        fn = _fast(self._lib, "fot_loop_observe", _vp, C.c_int32, _vp, _vp, _vp, _vp)
+        _abi.check(self._h, fn(self._h, n, _addr(ego), _addr(ps), _addr(metrics), _addr(s)))
+        return metrics[:n], s[:n]
+
+    def loop_observe_begin(self, ego5: np.ndarray, prev_s: np.ndarray):
+        """``loop_observe`` in two halves: enqueues the launches and returns a callable that waits for them and returns
+        (metrics, s) -- host work in between overlaps with the device.  No other call on this planner before it."""
+        ego = np.ascontiguousarray(ego5, dtype=np.float64).reshape(-1, 5)
+        n = ego.shape[0]
+        ps = np.ascontiguousarray(prev_s, dtype=np.float64)
+        fn = _fast(self._lib, "fot_loop_observe_begin", _vp, C.c_int32, _vp, _vp)
+        _abi.check(self._h, fn(self._h, n, _addr(ego), _addr(ps)))
+
+        def collect():
+            metrics = np.zeros(max(n, 1), dtype=self.SAFETY_DT)
+            s = np.zeros(max(n, 1))
+            fe = _fast(self._lib, "fot_loop_observe_end", _vp, _vp, _vp)
+            _abi.check(self._h, fe(self._h, _addr(metrics), _addr(s)))
+            return metrics[:n], s[:n]
+        return collect
+
     def synchronize(self):
         _abi.check(self._h, self._lib.fot_synchronize(self._h))
 

@@ -44,6 +44,11 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\n", offsetof(fot_result, cost), offsetof(fot_result, stats), offsetof(fot_result, frenet0),
          offsetof(fot_result, t), offsetof(fot_result, c));
   printf("%zu %zu %zu\n", offsetof(fot_batch, static_xy), offsetof(fot_batch, dyn_dims), offsetof(fot_params, footprint_offsets));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(fot_loop_frame), offsetof(fot_loop_frame, ped_off), offsetof(fot_loop_frame, prepend),
+         offsetof(fot_loop_frame, staleness), offsetof(fot_loop_frame, rp));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(fot_loop_request), offsetof(fot_loop_request, ego.has_prev_s),
+         offsetof(fot_loop_request, overrides), offsetof(fot_loop_request, target_speed),
+         offsetof(fot_loop_request, max_stop_distance), offsetof(fot_loop_request, episode));
   return 0; }''')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -53,7 +58,13 @@ int main(void) {
     want = [C.sizeof(P), C.sizeof(_abi.Ego), C.sizeof(_abi.Overrides), C.sizeof(R), C.sizeof(B),
             R.cost.offset, R.stats.offset, R.frenet0.offset, R.t.offset, R.c.offset,
             B.static_xy.offset, B.dyn_dims.offset, P.footprint_offsets.offset]
+    F, Q = _abi.LoopFrame, _abi.LoopRequest
+    want += [C.sizeof(F), F.ped_off.offset, F.prepend.offset, F.staleness.offset, F.rp.offset,
+             C.sizeof(Q), Q.ego.offset + _abi.Ego.has_prev_s.offset, Q.overrides.offset, Q.target_speed.offset,
+             Q.max_stop_distance.offset, Q.episode.offset]
     assert got == want
+    # closed_loop.py fills fot_loop_request column-wise through float64 / int32 views: 15 eight-byte slots
+    assert got[-6:] == [120, 56, 64, 96, 104, 112]
 
 
 def test_create_fails_loudly_without_gpu_or_succeeds_with_one():

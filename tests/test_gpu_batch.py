@@ -461,6 +461,37 @@ def test_device_wire_pack_equals_host_pack():
                                        rtol=2.0 ** -23, atol=2.0 ** -24 * 100.0 if f in ("s", "x", "y") else 1e-30, err_msg=f)
 
 
+def test_pack_on_the_handles_stream_waits_for_a_plan_on_a_caller_stream():
+    """fot_pack_records_device with stream NULL (the handle's own stream) right behind fot_plan_batch_device on a
+    caller's stream, no host synchronisation in between: the pack is ordered after the plan by the handle itself
+    (order_begin / order_end), so the wire records are those of a synchronised run -- five times over, with the
+    record buffer wiped before every plan so that a pack that ran early would ship zeros."""
+    import torch
+    from integrated_path_planning_amd.distributed import pack_records_host, wire_record_bytes
+    kw = syn.CONFIG3_PLANNER
+    bp = BatchPlanner(waypoints=WP, **kw)
+    n = 192
+    pb = PackedBatch([request_from_instance(syn.config3_instance(3000 + s)) for s in range(n)], np.float32)
+    host = bp.plan_packed(pb)
+    nt = bp.n_total_samples
+    want = pack_records_host(host.records, n, nt)
+    dev = torch.device("cuda", 0)
+    dyn = torch.from_numpy(pb.dyn_xy).to(dev)
+    struct = pb.with_device_obstacles(None, dyn.data_ptr())
+    rec_dev = torch.zeros(n * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    wire_dev = torch.zeros(n * wire_record_bytes(nt), dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize(dev)
+    for rep in range(5):
+        with torch.cuda.stream(st):
+            rec_dev.zero_()
+            wire_dev.zero_()
+        bp.plan_packed_device(struct, rec_dev.data_ptr(), st.cuda_stream)
+        bp.pack_records_device(n, rec_dev.data_ptr(), wire_dev.data_ptr(), None)
+        bp.synchronize()                                                     # the handle's stream: the pack
+        np.testing.assert_array_equal(wire_dev.cpu().numpy(), want, err_msg=f"repetition {rep}")
+
+
 def test_wire_records_far_from_the_origin_and_sharded_planner():
     """A map frame, not a test track: path and ego 10-20 km from the origin.  The wire form (float32 OFFSETS for s, x, y)
     still holds the north star's 1e-5 -- and ShardedPlanner (world size 1: the whole pipeline of a rank without a process

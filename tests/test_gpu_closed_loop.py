@@ -76,3 +76,59 @@ def test_distribution_aware_episodes_match_the_reference(name):
         for h, e in zip(hists, sim.episodes):
             assert_episode_matches(h, e.termination_reason, ep, name)
         assert [r.ego.x for r in hists[0]] == [r.ego.x for r in hists[1]]
+
+
+def _same_histories(ha, hb):
+    assert len(ha) == len(hb)
+    for a, b in zip(ha, hb):
+        assert len(a) == len(b)
+        for ra, rb in zip(a, b):
+            assert (ra.ego.x, ra.ego.y, ra.ego.yaw, ra.ego.v, ra.ego.a, ra.ego.jerk, ra.ego.state) == \
+                   (rb.ego.x, rb.ego.y, rb.ego.yaw, rb.ego.v, rb.ego.a, rb.ego.jerk, rb.ego.state)
+            assert ra.metrics == rb.metrics
+            assert (ra.planned_path is None) == (rb.planned_path is None)
+            if ra.planned_path is not None:
+                np.testing.assert_array_equal(ra.planned_path.x, rb.planned_path.x)
+                assert ra.planned_path.cost == rb.planned_path.cost
+            assert (ra.predicted_trajectories is None) == (rb.predicted_trajectories is None)
+            if ra.predicted_trajectories is not None:
+                np.testing.assert_array_equal(ra.predicted_trajectories, rb.predicted_trajectories)
+
+
+def test_two_calls_per_step_equal_five_calls_per_step(episodes):
+    """The fused step (fot_loop_plan + fot_loop_observe, prediction resident in HBM) and the step of five separate calls
+    (prediction through the host) are the same computation: the three reference episodes again, unfused, against the
+    reference AND record by record against the fused run -- ego states, metrics, selected paths, and the predictions the
+    fused run computes again when its history is read."""
+    cfg = scenario_config(episodes["meta"])
+    names = ("base", "fast", "shift")
+    tracks = [episodes[n + "_ped_traj"] for n in names]
+    with BatchedClosedLoop(cfg, tracks, fused=False) as plain:
+        assert not plain._fused
+        h_plain = plain.run()
+        for h, ep, n in zip(h_plain, plain.episodes, names):
+            assert_episode_matches(h, ep.termination_reason, episodes, n)
+        h_plain = [list(h) for h in h_plain]
+    with BatchedClosedLoop(cfg, tracks) as fused:
+        assert fused._fused
+        h_fused = [list(h) for h in fused.run()]
+    _same_histories(h_plain, h_fused)
+
+
+def test_fused_step_with_standing_and_walking_crowds(episodes):
+    """Episodes that disagree on the prepend rule in one frame (integrated_simulator.py:503-511): a crowd that stands
+    still (its prediction starts AT the current positions: nothing is prepended, T = n_dense), a walking crowd
+    (T = n_dense + 1), one without pedestrians, a standing one again -- the tensor then holds blocks of different
+    lengths, written by one launch per run of episodes.  Fused == unfused, record by record; histories are read after
+    the loop was closed (the predictions of the fused run are materialised on close)."""
+    cfg = scenario_config(episodes["meta"])
+    walk = episodes["base_ped_traj"][:140]
+    stand = np.repeat(walk[60:61], len(walk), axis=0)
+    none = np.zeros((len(walk), 0, 2))
+    tracks = [stand, walk, none, stand[:, :3], walk[:, ::2]]
+    runs = []
+    for fused in (False, True):
+        with BatchedClosedLoop(cfg, tracks, fused=fused) as sim:
+            hists = sim.run(60)
+        runs.append([list(h) for h in hists])
+    _same_histories(runs[0], runs[1])
