@@ -1313,8 +1313,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const int inst = xcd + 8 * (seq / groups), k0 = (seq % groups) * CULL_KG;
     if (inst >= n_inst) return;
     const InstDesc &D = desc[inst];
-    if (D.ent_cap == 0) return;
     const InstState &S = state[inst];
+    if (D.ent_cap == 0) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);   // this wave's time step inside the group
     const int nk = P.n_total - k0 < CULL_KG ? P.n_total - k0 : CULL_KG;
@@ -1361,30 +1361,36 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         const Raw *src = (const Raw *)(ic < D.n_static ? ps : pd);
         o = *src;
     };
-    // wave wv: box of time step k0 + wv over all longitudinal profiles of the instance
+    // Boxes of the group's time steps over all longitudinal profiles of the instance.  The (step, horizon) lateral
+    // extents and then the (step, profile) boxes are spread over ALL threads of the workgroup -- full waves of float64
+    // work instead of eight waves with a third of their lanes busy --, then wave wv merges the boxes of step k0 + wv.
+    if (!(ablate & 8)) {
+        for (int i = tid; i < nk * n_ext; i += CULL_KG * WAVE) {
+            const int ks = i / n_ext, e = i - ks * n_ext;
+            const bool brake = e >= P.n_ti;
+            const int n_eval = brake ? P.brake[e - P.n_ti].n_t : P.ti[e].n_t;
+            double *ext = s_ext + (ks * n_ext_cap + e) * 2;
+            lateral_extent_q(s_latq + e * 9, brake, k0 + ks, n_eval, P.dt, ext[0], ext[1]);
+        }
+        __syncthreads();
+        const int n_tab = n_prof < CULL_PBOX ? n_prof : CULL_PBOX;
+        for (int i = tid; i < nk * n_tab; i += CULL_KG * WAVE) {
+            const int ks = i / n_tab, w = i - ks * n_tab;
+            const double *ext = s_ext + (ks * n_ext_cap + s_lext[w]) * 2;
+            s_pbox[ks][w] = profile_box_from(s_linfo[w], D, sp, k0 + ks, P.dt, ext[0], ext[1]);   // read again below, per tile
+        }
+        __syncthreads();
+    }
     {
         Box32 bw = box_empty();
         if (wv < nk && !(ablate & 8)) {
-            // lateral extents first: one per horizon (shared by its terminal speeds) and per brake-ladder entry
-            for (int e = lane; e < n_ext; e += WAVE) {
-                const bool brake = e >= P.n_ti;
-                const int n_eval = brake ? P.brake[e - P.n_ti].n_t : P.ti[e].n_t;
-                double *ext = s_ext + (wv * n_ext_cap + e) * 2;
-                lateral_extent_q(s_latq + e * 9, brake, k0 + wv, n_eval, P.dt, ext[0], ext[1]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             for (int w = lane; w < n_prof; w += WAVE) {
-                Box32 o;
                 if (w < CULL_PBOX) {
-                    const double *ext = s_ext + (wv * n_ext_cap + s_lext[w]) * 2;
-                    o = profile_box_from(s_linfo[w], D, sp, k0 + wv, P.dt, ext[0], ext[1]);
-                    s_pbox[wv][w] = o;                              // read again below, per tile
+                    box_merge(bw, s_pbox[wv][w]);
                 } else {                                            // (more profiles than the table holds: on the spot)
                     const double *ext = s_ext + (wv * n_ext_cap + extent_index(P, D, w)) * 2;
-                    o = profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, ext[0], ext[1]);
+                    box_merge(bw, profile_box_at(P, D, S.frenet0, sp, w, k0 + wv, ext[0], ext[1]));
                 }
-                box_merge(bw, o);
             }
         }
         bw.x0 = wave_min_f32(bw.x0); bw.y0 = wave_min_f32(bw.y0);
