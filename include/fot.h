@@ -218,6 +218,17 @@ int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)
  * of segments for the handle's later plan calls, 0 restores the choice by batch size. */
 int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
 
+/* Test hook / experiment.  A synchronous plan call (fot_plan_batch, fot_loop_plan) can run as ONE launch: nearest
+ * point / Frenet state, broad phase and evaluation as three phases of one grid that meets at two grid-wide barriers
+ * (k_evaluate_fused) -- same device functions, same decisions, byte-identical records; the barrier polls a bounded
+ * number of times, and a call whose grid could not get onto the GPU together is planned again with the three kernels.
+ * It is OFF by default: a grid barrier needs the same L2 write-back and invalidate a kernel boundary performs, and
+ * measured it is slower than the three launches.  mode 0 = never, 1 = calls of one or two egos,
+ * 2 = every synchronous call whose grid fits (up to a few dozen egos).
+ * fot_debug_fused_counts: one-launch calls so far and how many of them had to be repeated. */
+int fot_debug_set_fused(fot_handle *h, int32_t mode);
+int fot_debug_fused_counts(const fot_handle *h, int64_t *launches, int64_t *retries);
+
 /* Test hook.  How the handle cuts a lattice into tiles (the unit of work of the evaluation kernel): 0 = chosen by
  * the lattice (default), 1 = per-wave rows (k_evaluate: every wave stages the rows of its own tile), 2 = groups
  * (k_evaluate_group: four tiles share one row table).  Same decisions, byte-identical records either way; the GPU
@@ -375,7 +386,7 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
  * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the
  * stream it is launched on.  fot_profile_read waits for the recorded work, then returns, per
  * kernel, the number of launches and the summed device time in ms since the last reset. */
-#define FOT_PROFILE_KERNELS 3
+#define FOT_PROFILE_KERNELS 4
 int fot_profile_enable(fot_handle *h, int on);
 int fot_profile_read(fot_handle *h, int reset, int32_t *launches, double *total_ms);
 const char *fot_profile_kernel_name(int index);

@@ -123,6 +123,15 @@ struct fot_handle {
     hipStream_t order_stream = nullptr;
     bool order_valid = false;
     int eval_segments = 0;               // fot_debug_set_eval_segments
+    // the one-launch pipeline of small synchronous calls (k_evaluate_fused; measured SLOWER than the three kernels, so
+    // off unless asked for): 0 = never, 1 = calls of one or two egos, 2 = every call whose grid fits
+    // (fot_debug_set_fused); its grid barrier's counter, the count it has reached, and the word in pinned memory a
+    // workgroup sets when it gave up waiting
+    int fused_mode = 0;
+    DevBuf dBarrier;
+    int32_t barrier_base = 0;
+    PinnedBuf hFusedErr;
+    int64_t fused_launches = 0, fused_retries = 0;
     int tile_cut = 0;                    // fot_debug_set_tile_cut (TILE_CUT_*)
     fot_params params;
     DevParams P;
@@ -233,7 +242,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // memory directly (fot_plan_batch, fot_safety_metrics_batch, fot_frenet_state_batch, the host path of the resampler).
 constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_evaluate_fused" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -275,8 +284,10 @@ struct ProfScope {
 // Stage descriptors, size the lane's workspace and enqueue the whole pipeline for the sub-batch `b` on `st`.
 // d_static / d_dyn are device pointers to the caller's obstacle coordinates (offsets in b are absolute),
 // d_out the device fot_result slot of the sub-batch's first instance.
+constexpr int FUSED_MAX_WG = 128;             // workgroups of k_evaluate_fused: all resident together on an idle GPU
+
 int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_static, const void *d_dyn,
-                 fot_result *d_out, hipStream_t st)
+                 fot_result *d_out, hipStream_t st, bool allow_fused = false)
 {
     BatchLayout &L = w.last;
     std::string err;
@@ -331,18 +342,32 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
     ea.sid = w.dEntSid.as<uint8_t>(); ea.rng = w.dWaveRng.as<TileStep>();
     ea.nan_flag = w.dNanFlag.as<uint8_t>();
+    MetaImport imp;
+    imp.h_desc = (const InstDesc *)stg;
+    imp.d_desc = (InstDesc *)w.dMeta.p;
+    // one scan block per 256 KB of an instance's tensor (few, fat blocks: each first reads its descriptor out of the
+    // pinned staging block, a PCIe round trip), at most 64 per instance
+    NanScan scan;
+    if (L.n_tracks > 0) {
+        scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
+        scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
+    }
+    // A synchronous call of a few egos: the three phases in one launch (the caller checks *hFusedErr after its wait)
+    const int64_t fused_wg = std::max<int64_t>((int64_t)L.n_inst * L.max_tiles,
+                                               (int64_t)L.n_inst * (1 + (L.n_tracks > 0 ? scan.blocks_per_inst : 0)));
+    if (allow_fused && h->fused_mode != 0 && L.n_tiles > 0 && h->eval_segments == 0 &&
+        (h->fused_mode == 2 ? fused_wg <= 4 * FUSED_MAX_WG : L.n_inst <= 2 && fused_wg <= FUSED_MAX_WG)) {
+        ProfScope ps(h, 3, st);
+        LAUNCH_TRY(h, launch_plan_fused(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, P.n_ti + P.n_brake, L.n_inst,
+                                        imp, scan, d_static, d_dyn, b.obstacle_dtype, L.any_obstacles, tt, ea, ca, d_out,
+                                        w.dDone.as<int32_t>(), h->dBarrier.as<int32_t>(), &h->barrier_base,
+                                        (int32_t *)h->hFusedErr.p, FUSED_MAX_WG, st));
+        HIP_TRY(h, hipEventRecord(w.staging_done, st));
+        ++h->fused_launches;
+        return FOT_OK;
+    }
     {
         ProfScope ps(h, 0, st);
-        MetaImport imp;
-        imp.h_desc = (const InstDesc *)stg;
-        imp.d_desc = (InstDesc *)w.dMeta.p;
-        // one scan block per 256 KB of an instance's tensor (few, fat blocks: each first reads its descriptor out of the
-        // pinned staging block, a PCIe round trip), at most 64 per instance
-        NanScan scan;
-        if (L.n_tracks > 0) {
-            scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
-            scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
-        }
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, scan, w.dDone.as<int32_t>(), st));
         HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
@@ -377,7 +402,7 @@ fot_batch sub_batch(const fot_batch &b, int i0, int n)
 // Enqueue one plan call behind everything already on `user`; small batches run on `user` itself, large ones
 // fork into the lanes' streams and join `user` again.
 int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
-                 hipStream_t user)
+                 hipStream_t user, bool allow_fused = false)
 {
     if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
     h->last_valid = false;
@@ -391,7 +416,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
 
     if (b.n_inst < FOT_SPLIT_MIN_INSTANCES * h->lanes_cfg / 2 || h->lanes_cfg <= 1) {
         h->ws[0].first_inst = 0;
-        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user);
+        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user, allow_fused);
         if (rc != FOT_OK) return rc;
         h->lanes_used = 1;
         h->last_valid = true;
@@ -418,6 +443,21 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     h->lanes_used = lanes;
     h->last_valid = true;
     return order_end(h, user);
+}
+
+// After the wait of a synchronous call that was allowed the one-launch pipeline: true when a workgroup of it gave up at
+// a grid barrier (its records are void).  The barrier is put back to zero; the caller plans the call again with the
+// three kernels.
+int fused_gave_up(fot_handle *h, bool *gave_up)
+{
+    volatile int32_t *err = (volatile int32_t *)h->hFusedErr.p;
+    *gave_up = *err != 0;
+    if (!*gave_up) return FOT_OK;
+    *err = 0;
+    HIP_TRY(h, hipMemset(h->dBarrier.p, 0, sizeof(int32_t)));
+    h->barrier_base = 0;
+    ++h->fused_retries;
+    return FOT_OK;
 }
 
 // lane and local index of global instance `inst` of the most recent plan call
@@ -482,6 +522,11 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     }
     if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemcpy(h->dP.p, &h->P, sizeof(DevParams), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    if ((e = h->dBarrier.ensure(sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(h->dBarrier.p, 0, sizeof(int32_t))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = h->hFusedErr.ensure(sizeof(int32_t))) != hipSuccess) return bail(e, "hipHostMalloc");
+    *(volatile int32_t *)h->hFusedErr.p = 0;
+    if (const char *ev = std::getenv("FOT_FUSED")) h->fused_mode = ev[0] == '1' ? 1 : ev[0] == '2' ? 2 : 0;   // diagnostics scripts
     {
         int cut = TILE_CUT_AUTO;                                 // FOT_TILE_CUT=wave|group: diagnostics scripts
         if (const char *ev = std::getenv("FOT_TILE_CUT")) cut = ev[0] == 'g' ? TILE_CUT_GROUP : ev[0] == 'w' ? TILE_CUT_WAVE : TILE_CUT_AUTO;
@@ -498,10 +543,11 @@ void fot_destroy(fot_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->order_valid) (void)hipEventSynchronize(h->order_done);   // work enqueued on a caller's stream
     for (Workspace &w : h->ws) if (w.stream) (void)hipStreamSynchronize(w.stream);
-    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dShapes, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD };
+    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dShapes, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD,
+                       &h->dBarrier };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
-    h->hSmallIn.release(); h->hSmallOut.release();
+    h->hSmallIn.release(); h->hSmallOut.release(); h->hFusedErr.release();
     h->loop.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -887,8 +933,15 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
         if (n_static > 0) { b.static_xy = L.dStatic.p; b.static_off = s_off.data(); }
         if (any_dyn) { b.dyn_xy = L.dyn_ptr; b.dyn_off = d_off.data(); b.dyn_dims = dims.data(); }
         HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * (size_t)n_req));
-        int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st);
-        if (rc != FOT_OK) return rc;
+        for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
+            int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st, attempt == 0);
+            if (rc != FOT_OK) return rc;
+            HIP_TRY(h, hipStreamSynchronize(st));
+            bool again = false;
+            rc = fused_gave_up(h, &again);
+            if (rc != FOT_OK) return rc;
+            if (!again) break;
+        }
     } else {
         int r = order_end(h, st); if (r != FOT_OK) return r;
     }
@@ -1037,9 +1090,15 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
         char *in = (char *)h->hSmallIn.p;
         if (st_bytes) std::memcpy(in, batch->static_xy, st_bytes);
         if (dy_bytes) std::memcpy(in + dy_off, batch->dyn_xy, dy_bytes);
-        rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream);
-        if (rc != FOT_OK) return rc;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
+            rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, attempt == 0);
+            if (rc != FOT_OK) return rc;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            bool again = false;
+            rc = fused_gave_up(h, &again);
+            if (rc != FOT_OK) return rc;
+            if (!again) break;
+        }
         std::memcpy(out, h->hSmallOut.p, out_bytes);
         return FOT_OK;
     }
@@ -1249,6 +1308,22 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg)
     if (!h) return FOT_ERR_INVALID;
     if (n_seg < 0 || n_seg > 4) return fail(h, FOT_ERR_INVALID, "fot_debug_set_eval_segments: 0 (automatic) .. 4");
     h->eval_segments = n_seg;
+    return FOT_OK;
+}
+
+int fot_debug_set_fused(fot_handle *h, int32_t mode)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (mode < 0 || mode > 2) return fail(h, FOT_ERR_INVALID, "fot_debug_set_fused: 0 (never), 1 (calls of one or two egos), 2 (whenever the grid fits)");
+    h->fused_mode = mode;
+    return FOT_OK;
+}
+
+int fot_debug_fused_counts(const fot_handle *h, int64_t *launches, int64_t *retries)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (launches) *launches = h->fused_launches;
+    if (retries) *retries = h->fused_retries;
     return FOT_OK;
 }
 

@@ -219,14 +219,15 @@ __device__ __forceinline__ ScanBest block_argmin(ScanBest b, ScanBest *s_best)
 }
 
 // One workgroup (4 waves) per instance: the sample scans are spread over all threads, the refinement and the Frenet
-// state are uniform values every wave computes alike.
-__global__ void __launch_bounds__(FRENET_WG)
-k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *desc,
-               InstState *__restrict__ state, int n_inst, MetaImport imp, NanScan scan, int32_t *__restrict__ inst_done)
+// state are uniform values every wave computes alike.  `block` is the workgroup's role: an instance, or (behind the
+// instances) one part of the NaN scan of an instance's tensor.  `sp`: the reference path, staged by the caller.
+__device__ __forceinline__ void frenet_state_block(const DevParams *__restrict__ Pp, const SplineView &sp, const InstDesc *desc,
+                                                   InstState *__restrict__ state, int n_inst, const MetaImport &imp,
+                                                   const NanScan &scan, int32_t *__restrict__ inst_done, int block)
 {
     __shared__ ScanBest s_best[FRENET_WG / WAVE];
     __shared__ InstDesc s_desc;                                   // the descriptor being worked on, read once
-    int inst = blockIdx.x;
+    int inst = block;
     if (inst >= n_inst) {
         // the blocks behind the nearest-point blocks: NaN scan of the dynamic tensors (memory-bound, on CUs whose
         // nearest-point block is a chain of dependent spline evaluations)
@@ -257,7 +258,6 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
         __syncthreads();
     }
     if (s_desc.ego.has_prev_s == FOT_PREV_S_CHAINED) return;      // handled by the head of its chain
-    const SplineView sp = stage_spline(sp_hbm, lds_knots);
     const DevParams &P = *Pp;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const double s_end = sp.s[sp.n - 1];
@@ -321,6 +321,15 @@ k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knot
         carry_prev_s = new_prev_s;
         chained = true;
     }
+}
+
+__global__ void __launch_bounds__(FRENET_WG)
+k_frenet_state(const DevParams *__restrict__ Pp, SplineView sp_hbm, int lds_knots, const InstDesc *desc,
+               InstState *__restrict__ state, int n_inst, MetaImport imp, NanScan scan, int32_t *__restrict__ inst_done)
+{
+    SplineView sp = sp_hbm;
+    if ((int)blockIdx.x < n_inst) sp = stage_spline(sp_hbm, lds_knots);       // (the scan blocks never look at the path)
+    frenet_state_block(Pp, sp, desc, state, n_inst, imp, scan, inst_done, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1272,52 +1281,45 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
 // grown by the collision radius, ordered by bin along the longer side of the box (counting sort through LDS
 // atomics), FAR32-padded to chunk pairs.  Then, per tile of the instance (k_evaluate's unit of work), the chunk range
 // its own profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
-constexpr int CULL_KG = 8;
+constexpr int CULL_KG = 8;              // time steps (= waves) of a group in k_cull; the fused small-batch kernel takes 4
 constexpr int CULL_LIST = 256;          // kept obstacles per time step remembered between the two passes
 constexpr int CULL_PBOX = 96;           // profiles per instance whose boxes are kept in LDS (more: recomputed)
 constexpr uint32_t CULL_IDX_MASK = 0xFFFFFu;   // obstacle index (< 2^20, fot_setup.hpp) | bin << 20
 
-template <typename T>
-__global__ void __launch_bounds__(CULL_KG * WAVE)
-k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
-       int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
-       int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
-       TileStep *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
-       const int32_t *__restrict__ tile_span, const uint8_t *__restrict__ nan_flag,
-       int ablate)
+// One group: KG waves, the KG consecutive time steps from k0 of instance `inst`.  `sp`: the reference path as the caller
+// staged it; `dyn_lds`: (n_ti + n_brake) * (KG * 2 + 9) doubles of dynamic LDS (launch_cull).
+template <typename T, int KG>
+__device__ __forceinline__ void
+cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+           const SplineView &sp, double *dyn_lds, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
+           int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
+           TileStep *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+           const int32_t *__restrict__ tile_span, const uint8_t *__restrict__ nan_flag, int ablate, int inst, int k0)
 {
-    __shared__ int s_cnt[CULL_KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
-    __shared__ int s_start[CULL_KG][CULL_BINS + 1];
-    __shared__ int s_nin[CULL_KG];
-    __shared__ uint32_t s_list[CULL_KG][CULL_LIST];              // kept obstacles of each step: index | bin << 20
-    __shared__ Box32 s_box[CULL_KG];                             // per-step constants
-    __shared__ BinMap s_bm[CULL_KG];
-    __shared__ float s_margin[CULL_KG];
-    __shared__ Box32 s_pbox[CULL_KG][CULL_PBOX];                 // boxes of the instance's profiles at the group's steps
+    __shared__ int s_cnt[KG][CULL_BINS + 1];                // pass 1: entries per bin; pass 2: write cursors
+    __shared__ int s_start[KG][CULL_BINS + 1];
+    __shared__ int s_nin[KG];
+    __shared__ uint32_t s_list[KG][CULL_LIST];              // kept obstacles of each step: index | bin << 20
+    __shared__ Box32 s_box[KG];                             // per-step constants
+    __shared__ BinMap s_bm[KG];
+    __shared__ float s_margin[KG];
+    __shared__ Box32 s_pbox[KG][CULL_PBOX];                 // boxes of the instance's profiles at the group's steps
     // what the boxes need of the instance that does not depend on the step, solved once per workgroup: the quartic of
     // every profile (and its horizon's index), the quintics of the two extreme lateral targets of every horizon
     __shared__ LonQuartic s_linfo[CULL_PBOX];
     __shared__ uint8_t s_lext[CULL_PBOX];
     const DevParams &P = *Pp;
-    if (ablate & 32) return;                                     // (timing diagnostics: the launch alone)
-    const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
-    // dynamic LDS behind the spline, sized by the planner's horizons (launch_cull): the lateral extent per horizon /
-    // brake-ladder entry and step, and the two extreme lateral quintics of every horizon
+    // dynamic LDS, sized by the planner's horizons (launch_cull): the lateral extent per horizon / brake-ladder entry
+    // and step, and the two extreme lateral quintics of every horizon
     const int n_ext_cap = P.n_ti + P.n_brake;
-    double *s_ext = s_spl + 9 * lds_knots;                       // [CULL_KG][n_ext_cap][2]
-    double *s_latq = s_ext + CULL_KG * n_ext_cap * 2;            // [n_ext_cap][9]
-    const int groups = (P.n_total + CULL_KG - 1) / CULL_KG;
-    // workgroups go round-robin over the 8 XCDs: all groups of instance i run back to back on XCD i mod 8, so the
-    // 64-byte runs that neighbouring groups cut out of the same cache lines of the prediction tensor meet in one L2
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int inst = xcd + 8 * (seq / groups), k0 = (seq % groups) * CULL_KG;
-    if (inst >= n_inst) return;
+    double *s_ext = dyn_lds;                                     // [KG][n_ext_cap][2]
+    double *s_latq = s_ext + KG * n_ext_cap * 2;                 // [n_ext_cap][9]
     const InstDesc &D = desc[inst];
     const InstState &S = state[inst];
     if (D.ent_cap == 0) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);   // this wave's time step inside the group
-    const int nk = P.n_total - k0 < CULL_KG ? P.n_total - k0 : CULL_KG;
+    const int nk = P.n_total - k0 < KG ? P.n_total - k0 : KG;
     const int n_grid_lon = P.n_ti * D.n_tv;
     const int n_prof = S.c2f_ok ? n_grid_lon + S.n_brake : 0;
     const double sq_dyn = D.dyn_mode == FOT_DYN_SINGLE ? P.sq_r_dyn : P.sq_r;
@@ -1325,7 +1327,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const FilterConst fc = filter_const(sq_max, sq_dyn < P.sq_r ? sq_dyn : P.sq_r);
     const float slack = box_footprint_slack(P);
     const int n_ext = P.n_ti + (S.c2f_ok ? S.n_brake : 0);
-    for (int w = tid; w < n_prof && w < CULL_PBOX; w += CULL_KG * WAVE) {
+    for (int w = tid; w < n_prof && w < CULL_PBOX; w += KG * WAVE) {
         s_linfo[w] = lon_quartic(profile_info(P, D, S.frenet0, w, false));
         s_lext[w] = (uint8_t)extent_index(P, D, w);
     }
@@ -1345,8 +1347,8 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     // consecutive samples, a contiguous 64-byte run of the [S][P][T][2] tensor, so a wave-wide load touches 8 such runs
     // instead of 64 scattered cache lines; the group's 8 waves share the obstacles.  T-major layout: the obstacles of
     // one time row are contiguous, so wave w takes step k0 + w alone and its lanes read 64 consecutive obstacles.
-    const int kl = tmajor ? wv : (lane & (CULL_KG - 1));          // this lane's step inside the group
-    const int i_first = tmajor ? lane : wv * (WAVE / CULL_KG) + lane / CULL_KG;
+    const int kl = tmajor ? wv : (lane & (KG - 1));          // this lane's step inside the group
+    const int i_first = tmajor ? lane : wv * (WAVE / KG) + lane / KG;
     constexpr int STRIDE = WAVE;                                  // obstacles between two of a lane's loads
     const int row_l = k0 + kl < D.T - 1 ? k0 + kl : D.T - 1;
     struct Raw { T x, y; };                                       // as stored: widened only when it is classified
@@ -1365,7 +1367,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     // extents and then the (step, profile) boxes are spread over ALL threads of the workgroup -- full waves of float64
     // work instead of eight waves with a third of their lanes busy --, then wave wv merges the boxes of step k0 + wv.
     if (!(ablate & 8)) {
-        for (int i = tid; i < nk * n_ext; i += CULL_KG * WAVE) {
+        for (int i = tid; i < nk * n_ext; i += KG * WAVE) {
             const int ks = i / n_ext, e = i - ks * n_ext;
             const bool brake = e >= P.n_ti;
             const int n_eval = brake ? P.brake[e - P.n_ti].n_t : P.ti[e].n_t;
@@ -1374,7 +1376,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
         }
         __syncthreads();
         const int n_tab = n_prof < CULL_PBOX ? n_prof : CULL_PBOX;
-        for (int i = tid; i < nk * n_tab; i += CULL_KG * WAVE) {
+        for (int i = tid; i < nk * n_tab; i += KG * WAVE) {
             const int ks = i / n_tab, w = i - ks * n_tab;
             const double *ext = s_ext + (ks * n_ext_cap + s_lext[w]) * 2;
             s_pbox[ks][w] = profile_box_from(s_linfo[w], D, sp, k0 + ks, P.dt, ext[0], ext[1]);   // read again below, per tile
@@ -1539,6 +1541,148 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
             box_thresholds(fc, wb, wm, r.thr, r.thr_sure);
         }
         rng[(int64_t)w * P.n_total] = r;
+    }
+}
+
+// One workgroup of CULL_KG waves per (instance, group of CULL_KG consecutive time steps).
+template <typename T>
+__global__ void __launch_bounds__(CULL_KG * WAVE)
+k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, const InstState *__restrict__ state,
+       int n_inst, SplineView sp_hbm, int lds_knots, const T *__restrict__ static_xy, const T *__restrict__ dyn_xy,
+       int32_t *__restrict__ ent_cnt, f2 *__restrict__ ent32, d2 *__restrict__ ent64, uint8_t *__restrict__ ent_sid,
+       TileStep *__restrict__ wave_rng, const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
+       const int32_t *__restrict__ tile_span, const uint8_t *__restrict__ nan_flag,
+       int ablate)
+{
+    if (ablate & 32) return;                                     // (timing diagnostics: the launch alone)
+    const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
+    const int groups = (Pp->n_total + CULL_KG - 1) / CULL_KG;
+    // workgroups go round-robin over the 8 XCDs: all groups of instance i run back to back on XCD i mod 8, so the
+    // 64-byte runs that neighbouring groups cut out of the same cache lines of the prediction tensor meet in one L2
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int inst = xcd + 8 * (seq / groups), k0 = (seq % groups) * CULL_KG;
+    if (inst >= n_inst) return;
+    cull_group<T, CULL_KG>(Pp, desc, state, sp, s_spl + 9 * lds_knots, static_xy, dyn_xy, ent_cnt, ent32, ent64, ent_sid,
+                           wave_rng, tile_cand0, tile_n, tile_span, nan_flag, ablate, inst, k0);
+}
+
+// ---------------------------------------------------------------------------
+// the whole plan call of a few egos in ONE launch
+// ---------------------------------------------------------------------------
+
+// A plan call of one or two egos is three short dependent kernels; what it waits for is mostly the launch machinery
+// between them (profiles/r03_latency_anatomy.json: of 68 us on the device clock, the work inside the kernels is about
+// 40).  k_evaluate_fused runs the three phases in one grid of FUSED_WG-thread workgroups that meet at two grid-wide
+// barriers: (A) nearest point + Frenet state of every instance, NaN scan of the tensors; (B) the entry lists, groups of
+// FUSED_KG time steps; (C) the tiles, each cut into FUSED_KG time segments as in k_evaluate_split, and the selection by
+// the wave that finishes an instance's last tile.  The phases are the very device functions of the three kernels.
+//
+// The barrier is a counter in HBM that only ever grows (launch n waits for base_n + G and base_n + 2 G): every wave
+// releases its writes at agent scope, one thread adds and polls with a BOUNDED number of sleeps, every wave then
+// acquires (vector and scalar caches).  The launcher keeps the grid small enough for all workgroups to be resident
+// together on an otherwise idle GPU; should they not be (other work holds the CUs), the poll runs out, the workgroup
+// sets *error and leaves -- every wave of the grid reaches the end of the kernel whatever happens -- and the host
+// plans that call again with the three kernels.
+constexpr int FUSED_KG = 4, FUSED_WG = FUSED_KG * WAVE;
+static_assert(FUSED_WG == FRENET_WG && FUSED_KG == SEG_MAX, "one workgroup shape for the three phases");
+constexpr int FUSED_POLLS = 40000;                                   // x (sleep + one L2 round trip): tens of milliseconds
+
+struct FusedArgs {
+    MetaImport imp; NanScan scan; int n_scan_blocks;
+    const void *static_xy, *dyn_xy;
+    int32_t *ent_cnt; d2 *ent64; uint8_t *ent_sid; const int32_t *tile_span; const uint8_t *nan_flag;
+    f2 *ent32_w; TileStep *rng_w; InstState *state_w;                // the buffers phase C reads, as phase A / B write them
+    SplineView sp_hbm; int lds_knots_ab; int do_cull;
+    int32_t *barrier; int32_t base; int32_t *error;
+};
+
+__device__ __forceinline__ bool grid_barrier(int32_t *counter, int32_t target, int32_t *error)
+{
+    __shared__ int s_pass;
+    // every wave's global stores have reached L2 (the vector cache writes through) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < WAVE) {
+        // ... ONE wave then writes the L2's dirty lines back (agent-scope release), counts the workgroup in, polls, and
+        // drops the stale lines of the vector cache and of the L2 (agent-scope acquire): one write-back and one invalidate
+        // per workgroup, not per wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        int pass = 0;
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int poll = 0; poll < FUSED_POLLS; ++poll) {
+                if ((int32_t)(ld_agent(counter) - target) >= 0) { pass = 1; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!pass) st_agent(error, (int32_t)1);
+            s_pass = pass;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // (the scalar cache: what the next phase reads with s_load)
+    return s_pass != 0;
+}
+
+template <typename P>
+__device__ __forceinline__ const P *const_view(const P *p)
+{
+    asm volatile("" : "+s"(p) : : "memory");
+    const uint64_t v = (uint64_t)p;                               // (an asm result counts as divergent: make it uniform again)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const P *)(const __attribute__((address_space(4))) P *)(((uint64_t)hi << 32) | lo);
+}
+
+// (same leading arguments as the other evaluation kernels: FusedSink reads EvalKernArgs out of the argument segment;
+//  desc / state / wave_rng / ent32 are NOT declared no-alias here -- this kernel writes them)
+template <typename T>
+__global__ void __launch_bounds__(FUSED_WG)
+k_evaluate_fused(const DevParams *__restrict__ Pp, const InstDesc *desc, const InstState *state,
+                 const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n, const TileStep *wave_rng,
+                 const f2 *ent32, const EvalKernArgs a, const FusedArgs f)
+{
+    const int n_inst = a.n_inst, G = (int)gridDim.x, b = (int)blockIdx.x;
+    {
+        // ---- A: Frenet states and NaN scan
+        const SplineView sp = stage_spline(f.sp_hbm, f.lds_knots_ab);
+        for (int blk = b; blk < n_inst + f.n_scan_blocks; blk += G) {
+            if (blk != b) __syncthreads();
+            frenet_state_block(Pp, sp, desc, f.state_w, n_inst, f.imp, f.scan, a.inst_done, blk);
+        }
+        if (!grid_barrier(f.barrier, f.base + G, f.error)) return;
+        // ---- B: entry lists
+        if (f.do_cull) {
+            const int groups = (Pp->n_total + FUSED_KG - 1) / FUSED_KG;
+            for (int item = b; item < n_inst * groups; item += G) {
+                if (item != b) __syncthreads();
+                cull_group<T, FUSED_KG>(Pp, desc, state, sp, s_spl + 9 * f.lds_knots_ab, (const T *)f.static_xy,
+                                        (const T *)f.dyn_xy, f.ent_cnt, f.ent32_w, f.ent64, f.ent_sid, f.rng_w, tile_cand0,
+                                        tile_n, f.tile_span, f.nan_flag, 0, item / groups, (item % groups) * FUSED_KG);
+            }
+        }
+        if (!grid_barrier(f.barrier, f.base + 2 * G, f.error)) return;
+    }
+    // ---- C: tiles and selection.  What the phases above wrote is read-only from here on, and the compiler is told so:
+    // the pointers come out of an opaque statement BEHIND the barrier (no load through them can move above it) as
+    // pointers into constant memory -- uniform loads through them run on the scalar unit as in k_evaluate_split
+    // (the barrier has just invalidated the scalar cache).
+    desc = const_view(desc); state = const_view(state); wave_rng = const_view(wave_rng); ent32 = const_view(ent32);
+    const int wave_doubles = eval_wave_doubles(a.row_budget);
+    double *s_part = s_lon + wave_doubles;
+    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_part + (SEG_MAX - 1) * SEG_DOUBLES);
+    const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int q = b; q < n_inst * a.max_tiles; q += G) {
+        if (q != b) __syncthreads();
+        const int pos = q / n_inst, inst = q - pos * n_inst;
+        const int n_tiles = desc[inst].n_tiles;
+        if (pos >= n_tiles) continue;
+        const int tile = n_tiles - 1 - pos;
+        TilePart tp = tile_part_empty();
+        evaluate_tile<TILE_SPLIT>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile, lane,
+                                  inst & (N_XCD - 1), tp, seg, FUSED_KG, s_part);
+        if (seg == 0) tile_done(inst, tile, lane, tp);
     }
 }
 
@@ -1931,6 +2075,46 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     } else {
         k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     }
+    FOT_LAUNCH_CHECK();
+    return 0;
+}
+
+// The whole plan call in one launch (k_evaluate_fused).  max_wg: the largest grid the caller lets it take.
+int launch_plan_fused(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_total, int n_ext,
+                      int n_inst, MetaImport imp, NanScan scan, const void *static_xy, const void *dyn_xy, int dtype,
+                      bool do_cull, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
+                      int32_t *barrier, int32_t *barrier_base, int32_t *error, int max_wg, hipStream_t st)
+{
+    if (n_inst <= 0 || tiles.n_tiles <= 0) return (int)hipErrorInvalidValue;
+    const int groups = (n_total + FUSED_KG - 1) / FUSED_KG;
+    const int n_scan = scan.flag ? n_inst * scan.blocks_per_inst : 0;
+    int grid = n_inst * tiles.max_tiles;
+    if (do_cull && n_inst * groups > grid) grid = n_inst * groups;
+    if (n_inst + n_scan > grid) grid = n_inst + n_scan;
+    if (grid > max_wg) grid = max_wg;
+    EvalKernArgs a;
+    a.Pp = P; a.sp = sp; a.desc = desc; a.state = state;
+    a.row_budget = tiles.row_budget; a.lds_knots = sp.n <= 28 ? sp.n : 0; a.ablate = 0;
+    a.n_inst = n_inst; a.max_tiles = tiles.max_tiles;
+    a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
+    a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
+    a.cand_cost = c.cost; a.cand_status = c.status; a.cand_keep = c.keep; a.parts = c.parts;
+    a.out = out; a.inst_done = inst_done;
+    FusedArgs f;
+    f.imp = imp; f.scan = scan; f.n_scan_blocks = n_scan;
+    f.static_xy = static_xy; f.dyn_xy = dyn_xy;
+    f.ent_cnt = e.cnt; f.ent64 = e.e64; f.ent_sid = e.sid; f.tile_span = tiles.span; f.nan_flag = e.nan_flag;
+    f.ent32_w = e.e32; f.rng_w = e.rng; f.state_w = state;
+    f.sp_hbm = sp; f.lds_knots_ab = sp.n <= 64 ? sp.n : 0; f.do_cull = do_cull ? 1 : 0;
+    f.barrier = barrier; f.base = *barrier_base; f.error = error;
+    *barrier_base += 2 * grid;                                     // (wraps with the counter: compared as a difference)
+    const size_t lds_ab = 9 * (size_t)f.lds_knots_ab + (size_t)n_ext * (FUSED_KG * 2 + 9);
+    const size_t lds_c = (size_t)eval_wave_doubles(tiles.row_budget) + (size_t)(SEG_MAX - 1) * SEG_DOUBLES + 9 * (size_t)a.lds_knots;
+    const size_t lds = sizeof(double) * (lds_ab > lds_c ? lds_ab : lds_c);
+    if (dtype == FOT_F32)
+        k_evaluate_fused<float><<<(unsigned)grid, FUSED_WG, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a, f);
+    else
+        k_evaluate_fused<double><<<(unsigned)grid, FUSED_WG, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a, f);
     FOT_LAUNCH_CHECK();
     return 0;
 }

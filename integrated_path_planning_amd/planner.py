@@ -454,6 +454,18 @@ class BatchPlanner:
         cut = {"auto": 0, "wave": 1, "group": 2}.get(cut, cut)
         _abi.check(self._h, self._lib.fot_debug_set_tile_cut(self._h, int(cut)))
 
+    def set_fused(self, mode) -> None:
+        """Test hook (``fot_debug_set_fused``): 0 / "off" (default), 1 / "small" (synchronous calls of one or two egos
+        run as one launch), 2 / "force" (every synchronous call whose grid fits)."""
+        mode = {"off": 0, "small": 1, "force": 2}.get(mode, mode)
+        _abi.check(self._h, self._lib.fot_debug_set_fused(self._h, int(mode)))
+
+    def fused_counts(self):
+        """(one-launch plan calls so far, how many of them were repeated with the three kernels)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _abi.check(self._h, self._lib.fot_debug_fused_counts(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def time_info(self, time: float):
         """(n_t, quartic inverse [2, 2], quintic inverse [3, 3]) the library solves a horizon of ``time`` seconds with
         (``fot_debug_time_info``)."""

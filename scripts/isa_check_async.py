@@ -171,7 +171,7 @@ def main(argv):
         if not allow_scratch and (md.get('vspill', 0) or md.get('scratch', 0)):
             print(f"   {m.group(1)} spills vector registers / uses scratch memory: not a build to ship")
             bad_total += 1
-    if n_kernels < 3:
+    if n_kernels < 5:                                            # k_evaluate, _split, _group, _fused<float>, _fused<double>
         print(f"only {n_kernels} evaluation kernels found in {path}")
         bad_total += 1
     return 1 if bad_total else 0

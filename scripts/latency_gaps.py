@@ -17,7 +17,8 @@ with open(f) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"])))
 rows.sort()
-short = lambda n: "frenet" if "k_frenet_state" in n else "cull" if "k_cull" in n else "evaluate" if "k_evaluate" in n else None
+short = lambda n: ("frenet" if "k_frenet_state" in n else "cull" if "k_cull" in n else "fused" if "k_evaluate_fused" in n
+                   else "evaluate" if "k_evaluate" in n else None)
 seq = [(s, e, short(n), g) for s, e, n, g in rows if short(n)]
 calls = []
 i = 0
@@ -28,15 +29,20 @@ while i + 2 < len(seq):
         i += 3
     else:
         i += 1
-calls = np.array(calls, dtype=float) / 1e3                      # us (grid size column aside)
+calls = np.array(calls, dtype=float).reshape(-1, 7) / 1e3       # us (grid size column aside)
 out = {}
-for grid in sorted(set(calls[:, 6])):                           # config 2 and config 3 differ in the evaluation grid
-    sel = calls[calls[:, 6] == grid][50:]                       # (the first calls of a handle: warm-up)
+# latency_loop.py runs config 2, then config 3, the same number of calls each: first and second half of the trace
+for name, sel in (("config2", calls[: len(calls) // 2]), ("config3", calls[len(calls) // 2:])):
+    sel = sel[30:]                                              # (the first calls of a handle: warm-up)
     if len(sel) < 20:
         continue
     med = np.median(sel, axis=0)
-    out["evaluate_grid_%d" % int(grid * 1e3)] = {
-        "calls": int(len(sel)), "k_frenet_state_us": med[0], "gap_1_us": med[1], "k_cull_us": med[2], "gap_2_us": med[3],
-        "k_evaluate_us": med[4], "first_start_to_last_end_us": med[5], "kernels_sum_us": med[0] + med[2] + med[4],
-        "gaps_sum_us": med[1] + med[3]}
+    out[name] = {"calls": int(len(sel)), "k_frenet_state_us": med[0], "gap_1_us": med[1], "k_cull_us": med[2],
+                 "gap_2_us": med[3], "k_evaluate_us": med[4], "first_start_to_last_end_us": med[5],
+                 "kernels_sum_us": med[0] + med[2] + med[4]}
+fused = np.array([(e - s_) / 1e3 for s_, e, n, g in seq if n == "fused"])
+if len(fused) > 100:
+    for name, sel in (("config2", fused[: len(fused) // 2]), ("config3", fused[len(fused) // 2:])):
+        out[name + "_k_evaluate_fused_us"] = {"calls": int(len(sel) - 30), "median": float(np.median(sel[30:])),
+                                              "p5": float(np.percentile(sel[30:], 5)), "p95": float(np.percentile(sel[30:], 95))}
 print(json.dumps(out, indent=1))

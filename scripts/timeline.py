@@ -16,7 +16,7 @@ from integrated_path_planning_amd import _abi, synthetic as syn            # noq
 from integrated_path_planning_amd.batch import PackedBatch                 # noqa: E402
 from integrated_path_planning_amd.planner import BatchPlanner              # noqa: E402
 
-N_INST, WPB, SLOTS = 256, int(os.environ.get("FOT_TIMELINE_WPB", "4")), int(os.environ.get("FOT_TIMELINE_SLOTS", "4096"))                       # 256 CUs x 4 SIMDs x 3 waves (VGPR-limited)
+N_INST, WPB, SLOTS = int(os.environ.get("FOT_TIMELINE_INST", "256")), int(os.environ.get("FOT_TIMELINE_WPB", "4")), int(os.environ.get("FOT_TIMELINE_SLOTS", "4096"))                       # 256 CUs x 4 SIMDs x 3 waves (VGPR-limited)
 
 
 def list_schedule(durations, slots):
@@ -77,6 +77,10 @@ def main():
             print("per tile [us]: entry -> spline staged " + us((ph[:, 1] - ph[:, 0])[okp]) + "; -> tile start " + us((t[:, 0] - ph[:, 1])[okp])
                   + "; -> summaries " + us((ph[:, 2] - t[:, 0])[okp]) + "; -> rows built " + us((t[:, 1] - ph[:, 2])[okp])
                   + "; loop " + us((ph[:, 3] - t[:, 1])[okp]) + "; epilogue " + us((t[:, 2] - ph[:, 3])[okp]))
+    if N_INST < 16:                                                         # a few egos: the phases above are the answer
+        okw = t[:, 2] > 0
+        print(f"waves {int(okw.sum())}; first entry -> last end {(t[okw, 2].max() - t[okw, 0].min()) / 100.0:.1f} us")
+        return
     n_waves = int(np.nonzero(t[:, 2])[0].max()) + 1
     n_waves = (n_waves + WPB - 1) // WPB * WPB
     t = t[:n_waves]
