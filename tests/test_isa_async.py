@@ -44,7 +44,7 @@ def synthetic(loop_body, scratch=0, vspill=0, callee="\ts_mov_b32 s4, 0\n\ts_set
 def run_guard(text, tmp_path, *args):
     p = tmp_path / "k.s"
     p.write_text(text)
-    r = subprocess.run([sys.executable, GUARD, str(p), *args], capture_output=True, text=True, timeout=60)
+    r = subprocess.run([sys.executable, GUARD, str(p), "--min-kernels", "3", *args], capture_output=True, text=True, timeout=60)
     return r.returncode, r.stdout + r.stderr
 
 
