@@ -224,7 +224,9 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
  * number of times, and a call whose grid could not get onto the GPU together is planned again with the three kernels.
  * It is OFF by default: a grid barrier needs the same L2 write-back and invalidate a kernel boundary performs, and
  * measured it is slower than the three launches.  mode 0 = never, 1 = calls of one or two egos,
- * 2 = every synchronous call whose grid fits (up to a few dozen egos).
+ * 2 = every synchronous call whose grid fits (up to a few dozen egos); 3 = as 2, and the NEXT such call waits at a
+ * barrier that cannot be passed (the tests' proof that every workgroup then runs out of polls, reports, leaves, and that
+ * the call is planned again with the three kernels).
  * fot_debug_fused_counts: one-launch calls so far and how many of them had to be repeated. */
 int fot_debug_set_fused(fot_handle *h, int32_t mode);
 int fot_debug_fused_counts(const fot_handle *h, int64_t *launches, int64_t *retries);

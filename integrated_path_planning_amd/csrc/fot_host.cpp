@@ -356,8 +356,12 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     const int64_t fused_wg = std::max<int64_t>((int64_t)L.n_inst * L.max_tiles,
                                                (int64_t)L.n_inst * (1 + (L.n_tracks > 0 ? scan.blocks_per_inst : 0)));
     if (allow_fused && h->fused_mode != 0 && L.n_tiles > 0 && h->eval_segments == 0 &&
-        (h->fused_mode == 2 ? fused_wg <= 4 * FUSED_MAX_WG : L.n_inst <= 2 && fused_wg <= FUSED_MAX_WG)) {
+        (h->fused_mode >= 2 ? fused_wg <= 4 * FUSED_MAX_WG : L.n_inst <= 2 && fused_wg <= FUSED_MAX_WG)) {
         ProfScope ps(h, 3, st);
+        if (h->fused_mode == 3) {                                // (test hook: a barrier nobody can pass -- every workgroup
+            h->barrier_base += 1 << 28;                          //  must run out of polls, report and leave)
+            h->fused_mode = 2;
+        }
         LAUNCH_TRY(h, launch_plan_fused(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, P.n_ti + P.n_brake, L.n_inst,
                                         imp, scan, d_static, d_dyn, b.obstacle_dtype, L.any_obstacles, tt, ea, ca, d_out,
                                         w.dDone.as<int32_t>(), h->dBarrier.as<int32_t>(), &h->barrier_base,
@@ -454,7 +458,7 @@ int fused_gave_up(fot_handle *h, bool *gave_up)
     *gave_up = *err != 0;
     if (!*gave_up) return FOT_OK;
     *err = 0;
-    HIP_TRY(h, hipMemset(h->dBarrier.p, 0, sizeof(int32_t)));
+    HIP_TRY(h, hipMemsetAsync(h->dBarrier.p, 0, sizeof(int32_t), h->stream));   // (ordered before the next launch on that stream)
     h->barrier_base = 0;
     ++h->fused_retries;
     return FOT_OK;
@@ -827,6 +831,10 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
     if (!frame && !L.have_frame) return fail(h, FOT_ERR_INVALID, "no frame: the first fot_loop_plan of a step carries one");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
+    if (L.observe_n > 0) {                                       // a fot_loop_observe_begin nobody collected: its launches
+        HIP_TRY(h, hipStreamSynchronize(st));                    // still read the frame's pinned block
+        L.observe_n = -1;
+    }
     { int r = order_begin(h, st); if (r != FOT_OK) return r; }
     bool metrics = false;
     if (frame) {
@@ -1314,7 +1322,9 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg)
 int fot_debug_set_fused(fot_handle *h, int32_t mode)
 {
     if (!h) return FOT_ERR_INVALID;
-    if (mode < 0 || mode > 2) return fail(h, FOT_ERR_INVALID, "fot_debug_set_fused: 0 (never), 1 (calls of one or two egos), 2 (whenever the grid fits)");
+    if (mode < 0 || mode > 3)
+        return fail(h, FOT_ERR_INVALID, "fot_debug_set_fused: 0 (never), 1 (calls of one or two egos), 2 (whenever the grid fits), "
+                                        "3 (as 2, the next call with a barrier that cannot be passed)");
     h->fused_mode = mode;
     return FOT_OK;
 }

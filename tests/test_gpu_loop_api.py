@@ -123,3 +123,23 @@ def test_loop_argument_checks():
     with pytest.raises(_abi.FotError):
         bp.gather_paths(rec, np.array([-1]), 4)
     bp.close()
+
+
+def test_one_launch_pipeline_gives_up_and_the_call_is_repeated():
+    """The grid barrier of k_evaluate_fused polls a bounded number of times: with a barrier target nobody can reach
+    (fot_debug_set_fused mode 3) every workgroup reports and leaves -- the kernel ENDS --, the library plans the call
+    again with the three kernels, and the caller sees the same records as ever; the next one-launch call works again."""
+    import integrated_path_planning_amd.synthetic as syn
+    from integrated_path_planning_amd.batch import PackedBatch, request_from_instance
+    bp = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), **syn.CONFIG3_PLANNER)
+    pb = PackedBatch([request_from_instance(syn.config3_instance(s)) for s in (3, 4)], np.float32)
+    want = bytes(bp.plan_packed(pb).records)
+    assert bp.fused_counts() == (0, 0)
+    bp.set_fused(3)
+    got = bytes(bp.plan_packed(pb).records)
+    assert bp.fused_counts() == (1, 1)
+    assert got == want
+    got = bytes(bp.plan_packed(pb).records)                        # mode 2 from here on: one launch, no repetition
+    assert bp.fused_counts() == (2, 1)
+    assert got == want
+    bp.close()
