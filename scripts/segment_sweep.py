@@ -12,7 +12,7 @@ from integrated_path_planning_amd.batch import PackedBatch, request_from_instanc
 from integrated_path_planning_amd.planner import BatchPlanner                               # noqa: E402
 
 bp = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), device=0, **syn.CONFIG3_PLANNER)
-for n in (1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64):
+for n in [int(v) for v in os.environ.get("FOT_SWEEP_N", "1 2 4 6 8 12 16 24 32 48 64").split()]:
     pbs = [PackedBatch([request_from_instance(syn.config3_instance(100 * r + s)) for s in range(n)], np.float32)
            for r in range(4)]
     row = []
