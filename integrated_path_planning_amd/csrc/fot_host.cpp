@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -62,10 +64,15 @@ struct PinnedBuf {
 // with the wide kernels of the other half instead of leaving the GPU idle between them.
 struct Workspace {
     hipStream_t stream = nullptr;            // internal stream of this lane
-    hipEvent_t staging_done = nullptr;       // the pinned staging buffer may be overwritten after this
+    // The descriptors of a call are staged in a pinned block that the call's first kernel reads.  Two blocks take turns,
+    // each with the event recorded BEHIND the last kernel of the call that used it: an event between two kernels costs
+    // the second one about 6 us (profiles/r03_latency_anatomy.json: the gap behind k_frenet_state), and with two blocks
+    // the host only ever waits for the call before the previous one.
+    hipEvent_t staging_done[2] = { nullptr, nullptr };
     hipEvent_t done = nullptr;               // this lane's part of the current call has been enqueued up to here
-    bool staging_pending = false;
-    PinnedBuf staging;
+    bool staging_pending[2] = { false, false };
+    int staging_slot = 0;
+    PinnedBuf staging[2];
     DevBuf dMeta;                            // InstDesc[]
     DevBuf dState;
     DevBuf dCost, dStatus, dKeep, dParts;
@@ -79,8 +86,10 @@ struct Workspace {
         DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dParts, &dStatus, &dKeep,
                            &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag, &dDone };
         for (DevBuf *b : bufs) b->release();
-        staging.release();
-        if (staging_done) (void)hipEventDestroy(staging_done);
+        for (int i = 0; i < 2; ++i) {
+            staging[i].release();
+            if (staging_done[i]) (void)hipEventDestroy(staging_done[i]);
+        }
         if (done) (void)hipEventDestroy(done);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -132,6 +141,13 @@ struct fot_handle {
     int32_t barrier_base = 0;
     PinnedBuf hFusedErr;
     int64_t fused_launches = 0, fused_retries = 0;
+    // Completion of a synchronous small call without a stream synchronisation: the wave that writes a record (into
+    // pinned memory) raises that record's flag to the call's sequence number behind a system-scope release; the host
+    // polls the flags.  hipStreamSynchronize returns some 10 us after the last kernel ended on this platform -- a sixth
+    // of a one-ego plan call.
+    PinnedBuf hDone;
+    int32_t done_seq = 0;
+    bool done_seq_armed = false;             // the call being enqueued wants the flags
     int tile_cut = 0;                    // fot_debug_set_tile_cut (TILE_CUT_*)
     fot_params params;
     DevParams P;
@@ -287,7 +303,7 @@ struct ProfScope {
 constexpr int FUSED_MAX_WG = 128;             // workgroups of k_evaluate_fused: all resident together on an idle GPU
 
 int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_static, const void *d_dyn,
-                 fot_result *d_out, hipStream_t st, bool allow_fused = false)
+                 fot_result *d_out, hipStream_t st, bool sync_caller = false)
 {
     BatchLayout &L = w.last;
     std::string err;
@@ -298,9 +314,10 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     // --- staging: the descriptors in a pinned block (k_frenet_state pulls them into HBM)
     const size_t desc_bytes = align256(sizeof(InstDesc) * (size_t)L.n_inst);
     const size_t meta_bytes = desc_bytes;
-    if (w.staging_pending) { HIP_TRY(h, hipEventSynchronize(w.staging_done)); w.staging_pending = false; }
-    HIP_TRY(h, w.staging.ensure(desc_bytes));
-    char *stg = (char *)w.staging.p;
+    const int slot = (w.staging_slot ^= 1);
+    if (w.staging_pending[slot]) { HIP_TRY(h, hipEventSynchronize(w.staging_done[slot])); w.staging_pending[slot] = false; }
+    HIP_TRY(h, w.staging[slot].ensure(desc_bytes));
+    char *stg = (char *)w.staging[slot].p;
     std::memcpy(stg, L.desc.data(), sizeof(InstDesc) * (size_t)L.n_inst);
 
     // --- workspace (grow-only; a growing hipFree/hipMalloc synchronises, steady state does not)
@@ -322,7 +339,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dDone.ensure(sizeof(int32_t) * (size_t)L.n_inst));
 
     // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
-    w.staging_pending = true;
+    w.staging_pending[slot] = true;
 
     const InstDesc *d_desc = (const InstDesc *)w.dMeta.p;
     TileTable tt;
@@ -337,6 +354,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     CandArrays ca;
     ca.cost = w.dCost.as<double>(); ca.parts = w.dParts.as<TilePart>();
     ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
+    if (sync_caller && h->done_seq_armed) { ca.done_flag = (int32_t *)h->hDone.p; ca.done_seq = h->done_seq; }
 
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
@@ -355,7 +373,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     // A synchronous call of a few egos: the three phases in one launch (the caller checks *hFusedErr after its wait)
     const int64_t fused_wg = std::max<int64_t>((int64_t)L.n_inst * L.max_tiles,
                                                (int64_t)L.n_inst * (1 + (L.n_tracks > 0 ? scan.blocks_per_inst : 0)));
-    if (allow_fused && h->fused_mode != 0 && L.n_tiles > 0 && h->eval_segments == 0 &&
+    if (sync_caller && h->fused_mode != 0 && L.n_tiles > 0 && h->eval_segments == 0 &&
         (h->fused_mode >= 2 ? fused_wg <= 4 * FUSED_MAX_WG : L.n_inst <= 2 && fused_wg <= FUSED_MAX_WG)) {
         ProfScope ps(h, 3, st);
         if (h->fused_mode == 3) {                                // (test hook: a barrier nobody can pass -- every workgroup
@@ -366,14 +384,13 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
                                         imp, scan, d_static, d_dyn, b.obstacle_dtype, L.any_obstacles, tt, ea, ca, d_out,
                                         w.dDone.as<int32_t>(), h->dBarrier.as<int32_t>(), &h->barrier_base,
                                         (int32_t *)h->hFusedErr.p, FUSED_MAX_WG, st));
-        HIP_TRY(h, hipEventRecord(w.staging_done, st));
+        HIP_TRY(h, hipEventRecord(w.staging_done[slot], st));
         ++h->fused_launches;
         return FOT_OK;
     }
     {
         ProfScope ps(h, 0, st);
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, scan, w.dDone.as<int32_t>(), st));
-        HIP_TRY(h, hipEventRecord(w.staging_done, st));         // the staging block is free once this kernel is done
     }
     if (L.any_obstacles) {
         ProfScope ps(h, 1, st);
@@ -385,6 +402,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
         LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, L.n_inst, tt, ea, ca, d_out,
                                       w.dDone.as<int32_t>(), st));
     }
+    HIP_TRY(h, hipEventRecord(w.staging_done[slot], st));        // (behind the call: see Workspace::staging_done)
     return FOT_OK;
 }
 
@@ -405,8 +423,11 @@ fot_batch sub_batch(const fot_batch &b, int i0, int n)
 
 // Enqueue one plan call behind everything already on `user`; small batches run on `user` itself, large ones
 // fork into the lanes' streams and join `user` again.
+// sync_caller: the caller waits for the records right behind this call (the synchronous entry points): the selecting
+// waves then raise a flag per record in pinned memory (wait_records), and a call of one or two egos may take the
+// one-launch pipeline if that is switched on.
 int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
-                 hipStream_t user, bool allow_fused = false)
+                 hipStream_t user, bool sync_caller = false)
 {
     if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
     h->last_valid = false;
@@ -420,7 +441,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
 
     if (b.n_inst < FOT_SPLIT_MIN_INSTANCES * h->lanes_cfg / 2 || h->lanes_cfg <= 1) {
         h->ws[0].first_inst = 0;
-        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user, allow_fused);
+        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user, sync_caller);
         if (rc != FOT_OK) return rc;
         h->lanes_used = 1;
         h->last_valid = true;
@@ -447,6 +468,47 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
     h->lanes_used = lanes;
     h->last_valid = true;
     return order_end(h, user);
+}
+
+// Arms the record flags for the next synchronous call of n records (false: this call waits on the stream instead).
+bool arm_records(fot_handle *h, int n)
+{
+    h->done_seq_armed = false;
+    static const bool off = std::getenv("FOT_NO_RECORD_FLAGS") != nullptr;       // diagnostics scripts
+    if (off || h->fused_mode != 0 || h->prof_on || n <= 0 || n > 64) return false;
+    if (h->hDone.ensure(sizeof(int32_t) * 64) != hipSuccess) return false;
+    if (++h->done_seq == 0) {                                    // (wrapped: no stale flag may equal the new number)
+        std::memset(h->hDone.p, 0, sizeof(int32_t) * 64);
+        h->done_seq = 1;
+    }
+    h->done_seq_armed = true;
+    return true;
+}
+
+// Waits until the n records of the call armed above are in pinned memory; after 20 ms without them (a kernel that
+// faulted, a path that raises no flags) the stream is synchronised instead -- never a hang here that the stream
+// synchronisation would not have been.
+int wait_records(fot_handle *h, int n, hipStream_t st)
+{
+    const bool armed = h->done_seq_armed;
+    h->done_seq_armed = false;
+    if (armed) {
+        volatile const int32_t *flag = (volatile const int32_t *)h->hDone.p;
+        const auto t0 = std::chrono::steady_clock::now();
+        int i = 0, spins = 0;
+        while (i < n) {
+            if (flag[i] == h->done_seq) { ++i; continue; }
+            __builtin_ia32_pause();
+            if ((++spins & 1023) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) break;
+        }
+        if (i == n) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return FOT_OK;
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return FOT_OK;
 }
 
 // After the wait of a synchronous call that was allowed the one-launch pipeline: true when a workgroup of it gave up at
@@ -521,7 +583,8 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
         if (h->lanes_cfg > 1 && l < h->lanes_cfg &&
             (e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
         if (l >= h->lanes_cfg) continue;
-        if ((e = hipEventCreateWithFlags(&w.staging_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        for (int i = 0; i < 2; ++i)
+            if ((e = hipEventCreateWithFlags(&w.staging_done[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
     if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
@@ -551,7 +614,7 @@ void fot_destroy(fot_handle *h)
                        &h->dBarrier };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
-    h->hSmallIn.release(); h->hSmallOut.release(); h->hFusedErr.release();
+    h->hSmallIn.release(); h->hSmallOut.release(); h->hFusedErr.release(); h->hDone.release();
     h->loop.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -1099,9 +1162,11 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
         if (st_bytes) std::memcpy(in, batch->static_xy, st_bytes);
         if (dy_bytes) std::memcpy(in + dy_off, batch->dyn_xy, dy_bytes);
         for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
+            if (attempt == 0) arm_records(h, batch->n_inst);
             rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, attempt == 0);
+            if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
+            rc = wait_records(h, batch->n_inst, h->stream);
             if (rc != FOT_OK) return rc;
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
             bool again = false;
             rc = fused_gave_up(h, &again);
             if (rc != FOT_OK) return rc;

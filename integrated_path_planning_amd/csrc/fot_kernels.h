@@ -19,6 +19,8 @@ struct CandArrays {
     double *cost;                       // per candidate, for fot_debug_candidates: cost, final status, kept samples
     uint8_t *status, *keep;
     TilePart *parts;                    // [n_tiles of the batch]
+    int32_t *done_flag = nullptr;       // pinned, one per instance, or nullptr: raised to done_seq behind the instance's record
+    int32_t done_seq = 0;
 };
 
 // What k_cull leaves per (tile, time step) for k_evaluate: the chunk range the tile's own profiles can reach

@@ -414,6 +414,7 @@ struct EvalKernArgs {
     double *cand_cost; uint8_t *cand_status, *cand_keep;      // per candidate: for fot_debug_candidates only
     TilePart *parts;                                 // per tile: what its wave found (tile_done)
     fot_result *out; int32_t *inst_done;             // selection by the wave that finishes an instance's last tile
+    int32_t *done_flag; int32_t done_seq;            // host-visible flag per record (CandArrays::done_flag)
 };
 // k_evaluate's argument segment: EVAL_LEAD_PTRS read-only pointers (passed on their own so that they carry
 // `__restrict__`: only no-alias inputs are certain to keep their loads on the scalar unit), then this struct
@@ -1133,6 +1134,16 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
     }
 }
 
+// The record of `inst` is complete: tell a host that polls for it (a synchronous small call, fot_host.cpp wait_records).
+// The release is at system scope -- the record lies in pinned host memory --, the flag follows it.
+__device__ __forceinline__ void record_written(int inst, int lane)
+{
+    const EvalKernArgs &KA = eval_kernargs();
+    if (!KA.done_flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(KA.done_flag + inst, KA.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // A wave is done with tile `tile` of instance `inst`: it leaves what it found (tp; empty for a tile without candidates)
 // and counts itself.  Every tile of the instance arrives exactly once; the wave that completes the count selects.
 // k_frenet_state zeroes the counters.  The partial results travel as agent-coherent stores / loads (st_agent,
@@ -1154,6 +1165,7 @@ __device__ __forceinline__ void tile_done(int inst, int tile, int lane, const Ti
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
     select_instance_wave(inst, lane);
+    record_written(inst, lane);
 }
 
 // the degenerate launch: a batch without a single tile (no horizons, no brake ladder) still gets its records
@@ -1162,7 +1174,10 @@ k_select_only(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ des
               const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
               const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32, const EvalKernArgs a)
 {
-    if ((int)blockIdx.x < a.n_inst) select_instance_wave((int)blockIdx.x, (int)threadIdx.x);
+    if ((int)blockIdx.x < a.n_inst) {
+        select_instance_wave((int)blockIdx.x, (int)threadIdx.x);
+        record_written((int)blockIdx.x, (int)threadIdx.x);
+    }
 }
 
 // One wave per tile.  The grid deals the tiles out position-major and XCD-aligned: workgroup b serves the instances
@@ -2061,7 +2076,7 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_status = c.status; a.cand_keep = c.keep; a.parts = c.parts;
-    a.out = out; a.inst_done = inst_done;
+    a.out = out; a.inst_done = inst_done; a.done_flag = c.done_flag; a.done_seq = c.done_seq;
     if (tiles.n_tiles <= 0) {
         k_select_only<<<(unsigned)n_inst, WAVE, 0, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     } else if (n_seg > 1) {
@@ -2099,7 +2114,7 @@ int launch_plan_fused(const DevParams *P, SplineView sp, const InstDesc *desc, I
     a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_status = c.status; a.cand_keep = c.keep; a.parts = c.parts;
-    a.out = out; a.inst_done = inst_done;
+    a.out = out; a.inst_done = inst_done; a.done_flag = c.done_flag; a.done_seq = c.done_seq;
     FusedArgs f;
     f.imp = imp; f.scan = scan; f.n_scan_blocks = n_scan;
     f.static_xy = static_xy; f.dyn_xy = dyn_xy;
