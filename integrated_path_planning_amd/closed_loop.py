@@ -276,6 +276,23 @@ def footprint_from_config(config) -> Optional[EgoFootprint]:
                                      int(_cfg(config, "ego_footprint_n_circles")))
 
 
+def emergency_stop(x, y, yaw, v, clearance_ahead, dt, max_accel, emergency_decel=None):
+    """``IntegratedSimulator._apply_emergency_stop`` (integrated_simulator.py:749-802) for arrays of egos: the position
+    integrates along the heading at the OLD speed, the deceleration is what stopping 0.2 m short of the nearest
+    pedestrian ahead needs (v^2 / (2 max(clearance - 0.2, 0.05))), bounded to [max_accel, emergency_decel]
+    (``None`` = 2 x max_accel); with nothing ahead (non-finite clearance) the cap itself.  Returns the new x, y, v, a
+    (a = 0 once the vehicle stands)."""
+    x, y, yaw, v = (np.asarray(q, dtype=float) for q in (x, y, yaw, v))
+    clr = np.asarray(clearance_ahead, dtype=float)
+    cap = max_accel * 2.0 if emergency_decel is None else emergency_decel
+    fin = np.isfinite(clr)
+    required = np.where(fin, v ** 2 / (2.0 * np.maximum(np.where(fin, clr, 1.0) - 0.2, 0.05)), cap)
+    max_dec = np.clip(required, max_accel, cap)
+    nv = np.maximum(0.0, v - max_dec * dt)
+    na = np.where(nv > 0, -max_dec, 0.0)
+    return x + v * np.cos(yaw) * dt, y + v * np.sin(yaw) * dt, nv, na
+
+
 class BatchedClosedLoop:
     """N episodes of the reference's closed loop in lock-step.
 
@@ -705,17 +722,9 @@ class BatchedClosedLoop:
         brake = ~follow
         if brake.any():
             x, y, yaw, v = (self.ego[sel, k][brake] for k in range(4))
-            cap = getattr(c, "ego_emergency_decel", None)
-            if cap is None:
-                cap = c.ego_max_accel * 2.0
-            clr = self.last_clearance[sel][brake]
-            fin = np.isfinite(clr)
-            required = np.where(fin, v ** 2 / (2.0 * np.maximum(np.where(fin, clr, 1.0) - 0.2, 0.05)), cap)
-            max_dec = np.clip(required, c.ego_max_accel, cap)
-            nv = np.maximum(0.0, v - max_dec * c.dt)
-            na = np.where(nv > 0, -max_dec, 0.0)
-            new_ego[brake, 0] = x + v * np.cos(yaw) * c.dt
-            new_ego[brake, 1] = y + v * np.sin(yaw) * c.dt
+            nx, ny, nv, na = emergency_stop(x, y, yaw, v, self.last_clearance[sel][brake], c.dt, c.ego_max_accel,
+                                            getattr(c, "ego_emergency_decel", None))
+            new_ego[brake, 0], new_ego[brake, 1] = nx, ny
             new_ego[brake, 3], new_ego[brake, 4] = nv, na
             jerk[brake] = (na - old_a[brake]) / c.dt
             self.last_kappa[sel[brake]] = 0.0                         # planner.reset_ego_curvature()

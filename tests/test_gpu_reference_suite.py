@@ -597,3 +597,66 @@ def test_polynomial_builder_views_match_the_reference(tag, dt):             # fr
             np.testing.assert_allclose(np.stack([p.d, p.d_d, p.d_dd, p.d_ddd]), z[key + "_lat"][i], rtol=1e-9, atol=1e-9)
     # tests/test_frenet_conventions.py:118-123
     assert len(pl._build_time_cache(4.0).t) == (41 if dt == 0.1 else 81)
+
+
+# ---------------------------------------------------------------- further reference tests (round 3)
+
+def test_path_generation(planner):                                           # tests/test_frenet_planner.py:100-114
+    from integrated_path_planning_amd.data_structures import FrenetState
+    paths = planner._generate_frenet_paths(FrenetState(s=0, s_d=5, s_dd=0, d=0, d_d=0, d_dd=0), 6.0)
+    assert len(paths) > 0
+    fp = paths[0]
+    assert len(fp.t) > 0 and len(fp.s) == len(fp.t) and len(fp.d) == len(fp.t)
+
+
+def test_default_inflation_preserves_geometry(planner):                      # tests/test_frenet_planner.py:456-470
+    fp = FrenetPath()
+    fp.x = [10.0, 11.0]; fp.y = [0.0, 0.0]; fp.t = [0.0, 0.1]
+    default_geom = planner._path_collision_geometry(fp)
+    explicit_geom = planner._path_collision_geometry(fp, 1.0)
+    for a, b in zip(default_geom, explicit_geom):
+        assert np.array_equal(a, b)
+    path_points, _, path_min, path_max, sq_rubicon, sq_rubicon_dyn = default_geom
+    radius = max(planner.robot_radius + planner.obstacle_radius, 1e-6)
+    assert sq_rubicon == radius ** 2 and sq_rubicon_dyn == sq_rubicon
+    assert np.array_equal(path_min, np.min(path_points, axis=0) - radius)
+    assert np.array_equal(path_max, np.max(path_points, axis=0) + radius)
+
+
+def test_lateral_grid_values_symmetric_and_bounded():                        # tests/test_frenet_conventions.py:107-116
+    """The grid the LIBRARY generates for d_road_w = 0.3, max_road_width = 7.0 (the configuration whose legacy arange
+    was lopsided): terminal lateral offsets of the candidates of one profile."""
+    from integrated_path_planning_amd.data_structures import FrenetState
+    pl = make_straight_planner(d_road_w=0.3, max_road_width=7.0)
+    paths = pl._generate_frenet_paths(FrenetState(s=20.0, s_d=5.0, s_dd=0.0, d=0.0, d_d=0.0, d_dd=0.0), 5.0)
+    n_side = int(7.0 / 0.3 + 1e-9)
+    di = np.array([fp.d[-1] for fp in paths[: 2 * n_side + 1]])            # candidate order: Ti -> tv -> di
+    np.testing.assert_allclose(di, np.arange(-n_side, n_side + 1) * 0.3, atol=1e-9)
+    assert np.any(np.abs(di) < 1e-12)
+    np.testing.assert_allclose(di, -di[::-1], atol=1e-9)
+    assert np.max(np.abs(di)) <= 7.0 + 1e-9
+
+
+def test_straight_reference_unaffected():                                    # tests/test_planner_guards.py:135-148
+    """kappa = 0: the singularity guard must never trigger on a straight road."""
+    xs = np.linspace(0, 50, 20)
+    pl = FrenetPlanner(CubicSpline2D(xs.tolist(), [0.0] * 20), max_speed=13.9, max_accel=8.0, max_curvature=10.0, dt=0.1,
+                       d_road_w=0.5, max_road_width=7.0, robot_radius=1.0, min_t=4.0, max_t=5.0, d_t_s=1.39, n_s_sample=1)
+    path = pl.plan(EgoVehicleState(x=5.0, y=0.0, yaw=0.0, v=5.0, a=0.0), np.empty((0, 2)), np.empty((0, 0, 2)),
+                   target_speed=5.0)
+    assert path is not None and len(path.x) > 1
+    _, status, keep, nt = pl.candidate_table()
+    assert np.all(keep == nt)                                                # nothing truncated, nothing dropped
+    assert not np.any(status == _abi.ST_DROPPED)
+
+
+def test_footprint_cover_and_heading():                                      # tests/test_footprint.py:31-50
+    m = EgoFootprint.multi_circle(4.5, 2.0, 3)
+    assert len(m.offsets) == 3
+    # the cover contains the rectangle's corners: each within `radius` of the nearest circle centre
+    for cx in (-2.25, 2.25):
+        for cy in (-1.0, 1.0):
+            assert min(np.hypot(cx - o, cy) for o in m.offsets) <= m.radius + 1e-12
+    centers = m.circle_centers(1.0, 2.0, np.pi / 2)                          # heading +y: centres stacked along y
+    np.testing.assert_allclose(centers[:, 0], 1.0, atol=1e-12)
+    np.testing.assert_allclose(centers[:, 1], 2.0 + np.asarray(m.offsets), atol=1e-12)
