@@ -62,11 +62,16 @@ class ReplayPedestrians:
             self.velocities = vel
         self.goals = np.asarray(goals, dtype=float) if goals is not None else traj[-1].copy()
 
-    def step(self, n: int = 1) -> None:
+    def step(self, ego_state=None, n: int = 1) -> None:
+        """Advance n frames (the position holds at the last frame, the clock keeps running; the ego is ignored:
+        replayed pedestrians do not react, replay_source.py:86-99)."""
         for _ in range(n):
             if self._idx < self.n_frames - 1:
                 self._idx += 1
             self.time += self.dt
+
+    def reset(self) -> None:
+        self._idx, self.time = 0, 0.0
 
     @property
     def positions(self) -> np.ndarray:
@@ -75,6 +80,11 @@ class ReplayPedestrians:
     @property
     def current_velocities(self) -> np.ndarray:
         return self.velocities[self._idx]
+
+    def get_state(self) -> Dict[str, Any]:
+        """positions / velocities / goals / timestamp of the current frame (PedestrianState's fields)."""
+        return dict(positions=self.positions.copy(), velocities=self.current_velocities.copy(), goals=self.goals.copy(),
+                    timestamp=self.time, n_peds=self.n_peds)
 
 
 class Observer:
@@ -95,6 +105,11 @@ class Observer:
             self.history.append(positions.copy())
             self.timestamps.append(timestamp)
             self.accumulated_time = max(self.accumulated_time - self.sgan_dt, 0.0)
+
+    def reset(self) -> None:
+        self.history.clear(); self.timestamps.clear()
+        self.accumulated_time = 0.0
+        self._last_update_timestamp = None
 
     @property
     def is_ready(self) -> bool:

@@ -83,7 +83,7 @@ def test_replay_velocities_and_clamp():
     tr = np.cumsum(np.ones((5, 1, 2)), axis=0)
     p = ReplayPedestrians(tr, dt=0.5)
     np.testing.assert_allclose(p.velocities[:, 0, 0], 2.0)
-    p.step(10)
+    p.step(n=10)
     assert p._idx == 4 and abs(p.time - 5.0) < 1e-12
     np.testing.assert_allclose(p.goals, tr[-1])
 
