@@ -660,3 +660,13 @@ def test_footprint_cover_and_heading():                                      # t
     centers = m.circle_centers(1.0, 2.0, np.pi / 2)                          # heading +y: centres stacked along y
     np.testing.assert_allclose(centers[:, 0], 1.0, atol=1e-12)
     np.testing.assert_allclose(centers[:, 1], 2.0 + np.asarray(m.offsets), atol=1e-12)
+
+
+def test_cubic_spline_creation():                                            # tests/test_coordinate_converter.py:23-37
+    x, y = [0.0, 10.0, 20.0, 30.0], [0.0, 5.0, 0.0, -5.0]
+    csp = CubicSpline2D(x, y)
+    px, py = csp.calc_position(0.0)
+    assert px == x[0] and py == y[0]
+    assert np.isfinite(csp.calc_yaw(0.0))
+    ex, ey = csp.calc_position(csp.s[-1])                                    # (and the far end of the domain)
+    np.testing.assert_allclose([ex, ey], [x[-1], y[-1]], atol=1e-9)
