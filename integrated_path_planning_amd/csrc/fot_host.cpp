@@ -302,8 +302,10 @@ struct ProfScope {
 // d_out the device fot_result slot of the sub-batch's first instance.
 constexpr int FUSED_MAX_WG = 128;             // workgroups of k_evaluate_fused: all resident together on an idle GPU
 
+// d_dyn_stage: HBM block the NaN-scan blocks copy the dynamic tensors into as they read them (a small call's tensors
+// lie in pinned host memory: the later kernels then read the copy instead of crossing PCIe again), or nullptr.
 int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_static, const void *d_dyn,
-                 fot_result *d_out, hipStream_t st, bool sync_caller = false)
+                 fot_result *d_out, hipStream_t st, bool sync_caller = false, void *d_dyn_stage = nullptr)
 {
     BatchLayout &L = w.last;
     std::string err;
@@ -369,6 +371,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     if (L.n_tracks > 0) {
         scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
         scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
+        if (d_dyn_stage) { scan.stage = d_dyn_stage; d_dyn = d_dyn_stage; }      // (cull and the rest read the copy)
     }
     // A synchronous call of a few egos: the three phases in one launch (the caller checks *hFusedErr after its wait)
     const int64_t fused_wg = std::max<int64_t>((int64_t)L.n_inst * L.max_tiles,
@@ -427,7 +430,7 @@ fot_batch sub_batch(const fot_batch &b, int i0, int n)
 // waves then raise a flag per record in pinned memory (wait_records), and a call of one or two egos may take the
 // one-launch pipeline if that is switched on.
 int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
-                 hipStream_t user, bool sync_caller = false)
+                 hipStream_t user, bool sync_caller = false, void *d_dyn_stage = nullptr)
 {
     if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
     h->last_valid = false;
@@ -441,7 +444,7 @@ int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const 
 
     if (b.n_inst < FOT_SPLIT_MIN_INSTANCES * h->lanes_cfg / 2 || h->lanes_cfg <= 1) {
         h->ws[0].first_inst = 0;
-        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user, sync_caller);
+        int rc = enqueue_lane(h, h->ws[0], b, d_static, d_dyn, d_out, user, sync_caller, d_dyn_stage);
         if (rc != FOT_OK) return rc;
         h->lanes_used = 1;
         h->last_valid = true;
@@ -1161,9 +1164,13 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
         char *in = (char *)h->hSmallIn.p;
         if (st_bytes) std::memcpy(in, batch->static_xy, st_bytes);
         if (dy_bytes) std::memcpy(in + dy_off, batch->dyn_xy, dy_bytes);
+        // the dynamic tensors cross PCIe once: the scan blocks of the first launch leave a copy in HBM for the others
+        static const bool no_stage = std::getenv("FOT_NO_SCAN_STAGE") != nullptr;        // diagnostics scripts
+        void *stage = nullptr;
+        if (dy_bytes && !no_stage) { HIP_TRY(h, h->dUserDyn.ensure(dy_bytes + 256)); stage = h->dUserDyn.p; }
         for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
             if (attempt == 0) arm_records(h, batch->n_inst);
-            rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, attempt == 0);
+            rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, attempt == 0, stage);
             if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
             rc = wait_records(h, batch->n_inst, h->stream);
             if (rc != FOT_OK) return rc;

@@ -52,6 +52,9 @@ struct NanScan {
     int dtype = 0;
     uint8_t *flag = nullptr;            // [n_tracks] 1: the track holds a NaN
     int blocks_per_inst = 0;
+    void *stage = nullptr;              // HBM copy of the tensors, written as they are scanned (same offsets), or nullptr:
+                                        // a small call's tensors lie in pinned host memory -- one pass over PCIe instead
+                                        // of three (scan, classification, scatter)
 };
 
 // descriptors still in pinned host memory, to be moved into HBM by k_frenet_state (h_desc == nullptr: already there)

@@ -139,7 +139,7 @@ constexpr int FRENET_WG = 256;
 // its track's flag (plain byte stores of the same value: no ordering between them is needed).
 template <typename T>
 __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__restrict__ dyn_xy, uint8_t *__restrict__ flag,
-                                                int part, int parts)
+                                                int part, int parts, T *__restrict__ stage)
 {
     if (D.dyn_mode == FOT_DYN_NONE) return;
     const int n_tracks = D.S * D.P;
@@ -151,6 +151,7 @@ __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__re
     __syncthreads();
     struct Pt { T x, y; };
     const Pt *base = (const Pt *)dyn_xy + D.dyn_off;
+    Pt *out = stage ? (Pt *)stage + D.dyn_off : nullptr;          // (NanScan::stage: what is read is also copied into HBM)
     if (D.dyn_tmajor) {                                          // [T][S][P]: thread = track, rows n_tracks apart
         constexpr int TU = 8;                                     // rows in flight per thread (neighbouring threads read
         for (int j = j0 + (int)threadIdx.x; j < j1; j += FRENET_WG) {   // neighbouring points of a row)
@@ -161,6 +162,10 @@ __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__re
                 for (int u = 0; u < TU; ++u) p[u] = base[(int64_t)(t0 + u < D.T ? t0 + u : D.T - 1) * n_tracks + j];
 #pragma unroll
                 for (int u = 0; u < TU; ++u) bad |= (p[u].x != p[u].x) | (p[u].y != p[u].y);
+                if (out) {
+#pragma unroll
+                    for (int u = 0; u < TU; ++u) if (t0 + u < D.T) out[(int64_t)(t0 + u) * n_tracks + j] = p[u];
+                }
             }
             if (bad) f[j] = 1;
         }
@@ -174,11 +179,16 @@ __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__re
         // head: points in front of the first 16-byte boundary (at most one, float only)
         int64_t a0 = i0;
         if (PER == 2 && ((uintptr_t)(base + i0) & 15)) {             // (global loads need dword alignment only; speed)
-            if (threadIdx.x == 0) { const Pt p = base[i0]; if ((p.x != p.x) | (p.y != p.y)) f[(int)(i0 / D.T)] = 1; }
+            if (threadIdx.x == 0) {
+                const Pt p = base[i0];
+                if ((p.x != p.x) | (p.y != p.y)) f[(int)(i0 / D.T)] = 1;
+                if (out) out[i0] = p;
+            }
             a0 = i0 + 1;
         }
         const int64_t n_vec = (i1 - a0) / PER;
         const V *vb = (const V *)(base + a0);
+        V *vo = out ? (V *)(out + a0) : nullptr;
         for (int64_t vbase = threadIdx.x; vbase < n_vec; vbase += (int64_t)UNROLL * FRENET_WG) {
             V v[UNROLL];
 #pragma unroll
@@ -190,6 +200,7 @@ __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__re
             for (int u = 0; u < UNROLL; ++u) {
                 const int64_t vi = vbase + (int64_t)u * FRENET_WG;
                 if (vi >= n_vec) continue;
+                if (vo) vo[vi] = v[u];
                 bool b0 = (v[u][0] != v[u][0]) | (v[u][1] != v[u][1]);
                 if (PER == 2) {
                     const bool b1 = (v[u][2 % (2 * PER)] != v[u][2 % (2 * PER)]) | (v[u][3 % (2 * PER)] != v[u][3 % (2 * PER)]);
@@ -202,6 +213,7 @@ __device__ __forceinline__ void scan_nan_tracks(const InstDesc &D, const T *__re
         if (PER == 2 && threadIdx.x == 0 && a0 + n_vec * PER < i1) {
             const Pt p = base[i1 - 1];
             if ((p.x != p.x) | (p.y != p.y)) f[(int)((i1 - 1) / D.T)] = 1;
+            if (out) out[i1 - 1] = p;
         }
     }
 }
@@ -234,8 +246,10 @@ __device__ __forceinline__ void frenet_state_block(const DevParams *__restrict__
         const int b = inst - n_inst, si = b / scan.blocks_per_inst, part = b - si * scan.blocks_per_inst;
         if (si >= n_inst) return;
         const InstDesc &D = (imp.h_desc ? imp.h_desc : desc)[si];
-        if (scan.dtype == FOT_F32) scan_nan_tracks(D, (const float *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst);
-        else scan_nan_tracks(D, (const double *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst);
+        if (scan.dtype == FOT_F32)
+            scan_nan_tracks(D, (const float *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst, (float *)scan.stage);
+        else
+            scan_nan_tracks(D, (const double *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst, (double *)scan.stage);
         return;
     }
     constexpr int DESC_WORDS = (int)(sizeof(InstDesc) / sizeof(unsigned long long));
