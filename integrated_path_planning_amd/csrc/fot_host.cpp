@@ -371,7 +371,12 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     if (L.n_tracks > 0) {
         scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
         scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
-        if (d_dyn_stage) { scan.stage = d_dyn_stage; d_dyn = d_dyn_stage; }      // (cull and the rest read the copy)
+        if (d_dyn_stage) {                                       // (cull and the rest read the copy)
+            scan.stage = d_dyn_stage; d_dyn = d_dyn_stage;
+            // across PCIe a block moves 64 KB per round trip: one block per 64 KB, so that the copy is done well inside
+            // the nearest-point chain it runs beside
+            scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 65535) / 65536));
+        }
     }
     // A synchronous call of a few egos: the three phases in one launch (the caller checks *hFusedErr after its wait)
     const int64_t fused_wg = std::max<int64_t>((int64_t)L.n_inst * L.max_tiles,
