@@ -297,11 +297,12 @@ struct ProfScope {
     ~ProfScope() { if (active) (void)hipEventRecord(stop, st); }
 };
 
+constexpr int FUSED_MAX_WG = 128;             // workgroups of k_evaluate_fused: all resident together on an idle GPU
+
 // Stage descriptors, size the lane's workspace and enqueue the whole pipeline for the sub-batch `b` on `st`.
 // d_static / d_dyn are device pointers to the caller's obstacle coordinates (offsets in b are absolute),
 // d_out the device fot_result slot of the sub-batch's first instance.
-constexpr int FUSED_MAX_WG = 128;             // workgroups of k_evaluate_fused: all resident together on an idle GPU
-
+// sync_caller: see enqueue_plan.
 // d_dyn_stage: HBM block the NaN-scan blocks copy the dynamic tensors into as they read them (a small call's tensors
 // lie in pinned host memory: the later kernels then read the copy instead of crossing PCIe again), or nullptr.
 int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_static, const void *d_dyn,
