@@ -1014,9 +1014,13 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
         if (any_dyn) { b.dyn_xy = L.dyn_ptr; b.dyn_off = d_off.data(); b.dyn_dims = dims.data(); }
         HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * (size_t)n_req));
         for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
+            // the records' flags instead of the stream (wait_records): the metrics' kernel ran ahead of the plan kernels on
+            // this stream and wrote host memory directly, so its results are there once a record behind it is
+            if (attempt == 0) arm_records(h, n_req);
             int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st, attempt == 0);
+            if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
+            rc = wait_records(h, n_req, st);
             if (rc != FOT_OK) return rc;
-            HIP_TRY(h, hipStreamSynchronize(st));
             bool again = false;
             rc = fused_gave_up(h, &again);
             if (rc != FOT_OK) return rc;
@@ -1024,8 +1028,8 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
         }
     } else {
         int r = order_end(h, st); if (r != FOT_OK) return r;
+        HIP_TRY(h, hipStreamSynchronize(st));
     }
-    HIP_TRY(h, hipStreamSynchronize(st));
     if (metrics) std::memcpy(safety_out, L.hOut.p, sizeof(fot_safety) * (size_t)n_ep);
     if (records) *records = n_req > 0 ? (const fot_result *)L.hRec.p : nullptr;
     return FOT_OK;
