@@ -1164,9 +1164,10 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
     const size_t out_bytes = sizeof(fot_result) * (size_t)batch->n_inst;
     // A plan step for one or a few egos is latency, not bandwidth: its obstacle points and its records (written once,
     // by the selecting wave) then travel straight between the kernels and pinned host memory -- two copy operations and
-    // their synchronisation less per call.  The points cross the bus up to three times that way (the NaN scan, k_cull's
-    // classification, k_cull's scatter of the few kept ones); up to the 2 MiB below that is still cheaper than a
-    // staging copy plus its wait (scripts/size_sweep.py), beyond it the tensors are staged in HBM.
+    // their synchronisation less per call.  The dynamic tensors cross the bus ONCE: the NaN-scan blocks of the first
+    // launch read them out of the pinned block and leave a copy in HBM for k_cull (NanScan::stage); the few static points
+    // are read in place.  Up to the 2 MiB below that beats a staging copy plus its wait (scripts/size_sweep.py), beyond
+    // it the tensors are staged in HBM with copy operations.
     if (st_bytes + dy_bytes <= 2 * SMALL_CALL_BYTES && out_bytes <= 8 * SMALL_CALL_BYTES) {   // (records stream out as instances finish)
         const size_t dy_off = align256(st_bytes);
         HIP_TRY(h, h->hSmallIn.ensure(dy_off + dy_bytes + 256));
