@@ -25,8 +25,34 @@ def oracle_plan_for_request(orc, params, spline, req, table=False):
                     static=req.static, dyn=req.dyn, dist=req.dist, table=table)
 
 
+# The two places where the reference's own formulas amplify float64 rounding above TIGHT (measured on 90 000 random
+# instances, tests/test_gpu_fuzz.py: two instances each; everything else agrees to 1e-8 and mostly to 1e-13):
+#  * nearest point (coordinate_converter.py:202-308): the refinement compares the distances of three probes; when two of
+#    them tie at rounding level, the library's and the oracle's last-bit difference in hypot() picks different probes and
+#    the arc length s0 ends one refinement step apart (0.2 * 2^-k, e.g. 3.05e-6 m at k = 16) -- and with it everything
+#    derived from the start state.  Recognised by s0 itself; such an instance is held to the north star's tolerance.
+#  * curvature at a crawl (coordinate_converter.py:128-158, frenet_planner.py:792-799): d' = d_d / s_d and d'' divide by
+#    s_d and s_d^2; just above the EPS_S_DOT = 1e-3 gate that is a factor 1e6 on the last bit.  The curvature sample is
+#    held to tol + CRAWL_C_TOL / s_d^2.
+NEAREST_POINT_TIE = 1e-9          # |s0 - oracle's s0| above this: a tie in the nearest-point refinement
+NEAREST_POINT_STEP_MAX = 0.2 / 1024.0
+CRAWL_C_TOL = 1e-13
+tolerance_stats = {"nearest_point_ties": 0, "crawl_curvature_samples": 0, "records": 0}
+
+
+def nearest_point_tie(rec, want):
+    """True when the record's start state sits one (late) refinement step of the nearest-point search away from the
+    oracle's -- see above."""
+    ds = abs(rec.frenet0[0] - want.frenet0[0])
+    return bool(np.isfinite(ds) and NEAREST_POINT_TIE < ds <= NEAREST_POINT_STEP_MAX)
+
+
 def assert_record_matches_oracle(rec, want, tol=TIGHT, label=""):
-    """fot_result record vs oracle PlanOutput."""
+    """fot_result record vs oracle PlanOutput (values at `tol`; the two documented amplifications above at theirs)."""
+    tolerance_stats["records"] += 1
+    if nearest_point_tie(rec, want) and tol < NORTH_STAR_TOL:
+        tolerance_stats["nearest_point_ties"] += 1
+        tol = NORTH_STAR_TOL
     assert rec.status == want.status, f"{label} status {rec.status} != {want.status}"
     assert rec.best_index == want.best_index, f"{label} best_index {rec.best_index} != {want.best_index}"
     assert rec.n_cand == want.n_cand, label
@@ -45,6 +71,13 @@ def assert_record_matches_oracle(rec, want, tol=TIGHT, label=""):
         assert len(exp) == n, f"{label} len({f})"
         if f == "yaw":
             np.testing.assert_allclose(wrap_angle(got - exp), 0.0, atol=tol, err_msg=f"{label} {f}")
+        elif f == "c":
+            sd = np.asarray(want.path["s_d"], dtype=float)
+            loose = CRAWL_C_TOL / np.maximum(sd * sd, 1e-12)
+            err = np.abs(got - exp)
+            ok = err <= tol + tol * np.abs(exp) + loose
+            tolerance_stats["crawl_curvature_samples"] += int(np.sum(ok & (err > tol + tol * np.abs(exp))))
+            assert np.all(ok), f"{label} c: max error {err.max():.3e} at sample {int(err.argmax())} (s_d {sd[int(err.argmax())]:.3e})"
         else:
             np.testing.assert_allclose(got, exp, rtol=tol, atol=tol, err_msg=f"{label} {f}")
     np.testing.assert_allclose(rec.new_last_kappa, want.new_last_kappa, rtol=tol, atol=tol, err_msg=label)

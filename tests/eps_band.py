@@ -45,7 +45,8 @@ def check_status_table(bp, inst, got, want, label):
 def report():
     if not _stats["instances"]:
         return None
-    return {"eps_band": EPS_BAND, **_stats,
+    from oracle.check import tolerance_stats
+    return {"eps_band": EPS_BAND, **_stats, "value_tolerances": dict(tolerance_stats),
             "min_relative_margin": {k: {"margin": v[0], "where": v[1]} for k, v in _min.items()}}
 
 
@@ -65,3 +66,6 @@ def dump(root):
         print(f"  {k:12s} {v['margin']:.3e}   {v['where']}")
     print(f"  instances {r['instances']}, candidates {r['candidates']}, status differences {r['status_differences']}"
           f" (inside the {EPS_BAND:g} band: {r['differences_inside_band']})")
+    t = r["value_tolerances"]
+    print(f"  records compared {t['records']}: nearest-point ties (held to the north star's 1e-5) {t['nearest_point_ties']}, "
+          f"curvature samples at a crawl beyond 1e-8 {t['crawl_curvature_samples']}")
