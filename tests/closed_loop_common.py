@@ -38,7 +38,14 @@ class OracleEngine:
 
     def __init__(self, cfg):
         c = SimpleNamespace(**cfg)
+        fp_kw = {}
+        if cfg.get("ego_footprint", "circle") == "multi_circle":          # footprint_from_config (src/core/footprint.py)
+            from integrated_path_planning_amd.footprint import EgoFootprint
+            fp = EgoFootprint.multi_circle(cfg.get("vehicle_length", 4.5), cfg.get("vehicle_width", 2.0),
+                                           int(cfg.get("ego_footprint_n_circles", 3)))
+            fp_kw = dict(footprint_offsets=list(fp.offsets), footprint_radius=fp.radius)
         self.params = orc.make_params(
+            **fp_kw,
             max_speed=c.ego_max_speed, max_accel=c.ego_max_accel, max_curvature=c.ego_max_curvature,
             max_lat_accel=cfg.get("ego_max_lat_accel", 3.0), dt=c.dt, d_road_w=c.d_road_w, max_road_width=c.max_road_width,
             robot_radius=cfg.get("ego_radius", 1.0), obstacle_radius=c.obstacle_radius, min_t=cfg.get("min_t", 4.0),

@@ -21,7 +21,12 @@ STATES = {"NORMAL": 0, "CAUTION": 1, "EMERGENCY": 2}
 VARIANTS = {"base": dict(scenario="scenario_01", speed=1.0, dy=0.0), "fast": dict(scenario="scenario_01", speed=1.3, dy=0.0),
             "shift": dict(scenario="scenario_01", speed=1.0, dy=1.0),
             "walls": dict(scenario="scenario_02", speed=1.0, dy=0.0),        # static obstacle rectangles either side
-            "turn": dict(scenario="scenario_03", speed=1.0, dy=0.0)}         # curved reference path
+            "turn": dict(scenario="scenario_03", speed=1.0, dy=0.0),         # curved reference path
+            # the multi-circle ego footprint (planner collision geometry AND safety metrics, footprint.py) in the loop
+            "footprint": dict(scenario="scenario_01", speed=1.0, dy=0.5,
+                              cfg=dict(ego_footprint="multi_circle", ego_footprint_n_circles=3)),
+            # the planner's single-sample dynamic margin inflated (frenet_planner.py:1126-1179), metrics unaffected
+            "inflate": dict(scenario="scenario_01", speed=1.15, dy=-0.5, cfg=dict(collision_margin_inflation=1.2))}
 
 
 def main():
@@ -51,6 +56,7 @@ def main():
         cfg = dict(raw)
         cfg.update(ped_initial_states=[], ped_groups=[], sgan_model_path=None, prediction_method="cv",
                    visualization_enabled=False)
+        cfg.update(var.get("cfg", {}))
         config = SimulationConfig(**cfg)
         sim = simmod.IntegratedSimulator(config)
         peds = peds0.copy()
@@ -103,7 +109,8 @@ def main():
         resolved = {k: v for k, v in resolved.items() if isinstance(v, (int, float, str, bool, list)) or v is None}
         meta["variants"][name] = dict(steps=n, termination=sim.termination_reason, npz_keys=keys, config=resolved,
                                       ego_radius=float(sim.ego_radius), ped_radius=float(sim.ped_radius),
-                                      n_static_points=int(len(sim.static_obstacle_points)), **var)
+                                      n_static_points=int(len(sim.static_obstacle_points)),
+                                      **{k: v for k, v in var.items() if k != "cfg"})
         print(name, n, "steps,", sim.termination_reason, "states", np.bincount(out[pre + "state"], minlength=3).tolist(),
               "no path", int((plen == 0).sum()))
     meta["config"] = meta["variants"]["base"]["config"]          # scenario_01, kept for the callers that read it here
