@@ -57,6 +57,8 @@ def import_reference(ref_root):
 
 
 def waypoints(name):
+    if isinstance(name, dict):                       # a random case carries its own waypoints
+        return np.asarray(name["wx"], float), np.asarray(name["wy"], float)
     if name == "straight":
         return syn.STRAIGHT_WX, syn.STRAIGHT_WY
     if name == "curved":
@@ -226,6 +228,36 @@ def build_cases():
     return cases
 
 
+def build_random_cases(n, seed0=7000):
+    """Random configurations drawn by the generators of the GPU fuzz test (tests/test_gpu_fuzz.py: random path, planner
+    arguments, ego, overrides, stop directive, static points, single-sample / distribution tensors) -- so that the
+    ORACLE, which that fuzz compares the library with, is itself pinned to the reference on configurations of the same
+    kind, not only on the hand-made cases above."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as fz
+    from oracle import oracle as orc                                       # (samples points along the path, nothing else)
+    cases = []
+    k = 0
+    while len(cases) < n:
+        rng = np.random.default_rng(seed0 + k)
+        k += 1
+        wx, wy = fz.random_path(rng)
+        kw = fz.random_planner_kwargs(rng)
+        fp = kw.pop("footprint", None)
+        if fp is not None:                                                  # (redrawn in the reference's own terms)
+            fp = dict(length=float(rng.uniform(3.5, 5)), width=float(rng.uniform(1.6, 2.1)), n=int(rng.integers(1, 6)))
+        rq = fz.random_request(rng, orc.Spline(wx, wy), kw, dense=bool(rng.random() < 0.15))
+        for arr in (rq.static, rq.dyn, rq.dist):
+            if arr is not None and np.isnan(arr).any():
+                np.nan_to_num(arr, copy=False, nan=1.0e3)                   # (NaN tracks have their own cases)
+        cases.append(dict(name=f"rnd_{len(cases):03d}", path=dict(wx=[float(v) for v in wx], wy=[float(v) for v in wy]),
+                          planner=kw, ego=[rq.x, rq.y, rq.yaw, rq.v, rq.a], target_speed=rq.target_speed,
+                          overrides=rq.overrides, max_stop=rq.max_stop_distance, prev_s=rq.prev_s,
+                          last_kappa=rq.last_kappa, footprint=fp,
+                          static=np.empty((0, 2)) if rq.static is None else rq.static, dyn=rq.dyn, dist=rq.dist))
+    return cases
+
+
 def run_case(ref, case, out_dir):
     FrenetPlanner, CubicSpline2D, EgoVehicleState, EgoFootprint = ref
     wx, wy = waypoints(case["path"])
@@ -254,6 +286,9 @@ def run_case(ref, case, out_dir):
     # --- the stages of plan() (frenet_planner.py:259-304), run one by one to capture per-candidate data
     planner.last_check_stats = None
     fs = planner._cartesian_to_frenet_state(ego)
+    if fs is None and case["name"].startswith("rnd_"):
+        print(case["name"], "skipped: the conversion to the Frenet frame fails")
+        return
     assert fs is not None
     out["frenet0"] = np.array([fs.s, fs.s_d, fs.s_dd, fs.d, fs.d_d, fs.d_dd])
     out["prev_s_after"] = np.array(planner.converter._prev_s)
@@ -357,10 +392,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--random", type=int, default=40, help="with --only rnd: how many random cases")
     args = ap.parse_args()
     ref = import_reference(args.ref)
     if args.only == "time_cache":
         run_time_cache(ref, HERE)
+        return
+    if args.only == "rnd":                           # the random block alone (--random N of them)
+        for case in build_random_cases(args.random):
+            run_case(ref, case, HERE)
         return
     for case in build_cases():
         if args.only and args.only not in case["name"]:
