@@ -27,6 +27,11 @@ VARIANTS = {"base": dict(scenario="scenario_01", speed=1.0, dy=0.0), "fast": dic
                               cfg=dict(ego_footprint="multi_circle", ego_footprint_n_circles=3)),
             # the planner's single-sample dynamic margin inflated (frenet_planner.py:1126-1179), metrics unaffected
             "inflate": dict(scenario="scenario_01", speed=1.15, dy=-0.5, cfg=dict(collision_margin_inflation=1.2))}
+# random pedestrian scripts: every pedestrian's start jittered by N(0, 0.7 m), its velocity scaled by U(0.7, 1.4) and
+# turned by N(0, 0.15 rad), the whole crowd shifted -- seeds fixed here so that the fixture can be regenerated
+for _k, (_sc, _seed) in enumerate([("scenario_01", 11), ("scenario_01", 12), ("scenario_03", 13), ("scenario_02", 14),
+                                   ("scenario_03", 15), ("scenario_01", 16)]):
+    VARIANTS[f"rnd{_k}"] = dict(scenario=_sc, speed=1.0, dy=0.0, jitter_seed=_seed)
 
 
 def main():
@@ -62,6 +67,14 @@ def main():
         peds = peds0.copy()
         peds[:, 2:4] *= var["speed"]
         peds[:, 1] += var["dy"]
+        if "jitter_seed" in var and len(peds):
+            rng = np.random.default_rng(var["jitter_seed"])
+            peds[:, 0:2] += rng.normal(0.0, 0.7, (len(peds), 2)) + rng.uniform(-1.5, 1.5, 2)
+            ang = rng.normal(0.0, 0.15, len(peds))
+            vx, vy = peds[:, 2].copy(), peds[:, 3].copy()
+            sc = rng.uniform(0.7, 1.4, len(peds))
+            peds[:, 2] = sc * (np.cos(ang) * vx - np.sin(ang) * vy)
+            peds[:, 3] = sc * (np.sin(ang) * vx + np.cos(ang) * vy)
         n_frames = int(config.total_time / config.dt) + 64
         t = np.arange(n_frames) * config.dt
         traj = peds[None, :, 0:2] + peds[None, :, 2:4] * t[:, None, None]

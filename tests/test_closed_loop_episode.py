@@ -14,11 +14,13 @@ def episodes():
     return load_episodes()
 
 
-@pytest.mark.parametrize("name", ["fast", "shift", "base", "walls", "turn", "footprint", "inflate"])
+@pytest.mark.parametrize("name", ["fast", "shift", "base", "walls", "turn", "footprint", "inflate",
+                                  "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_episodes_free_running(episodes, name):
     """scenario_01 in three pedestrian scripts, scenario_02 (static obstacle rectangles), scenario_03 (curved path),
     scenario_01 with the three-circle ego footprint (planner geometry and safety metrics) and with the planner's dynamic
-    margin inflated by 1.2 (39 EMERGENCY steps, 34 steps without a path)."""
+    margin inflated by 1.2 (39 EMERGENCY steps, 34 steps without a path); six random pedestrian scripts on the three
+    scenarios (796 steps together, 39 of them without a path)."""
     cfg = scenario_config(episodes["meta"], name)
     sim = BatchedClosedLoop(cfg, [episodes[name + "_ped_traj"]], engine=OracleEngine(cfg), resampler=OracleResampler(cfg))
     hist = sim.run()[0]

@@ -38,10 +38,11 @@ def test_three_episodes_in_lock_step_match_the_reference(episodes, tmp_path):
     print(f"3 episodes, {sum(len(h) for h in hists)} episode-steps in {wall:.2f} s")
 
 
-@pytest.mark.parametrize("name", ["walls", "turn", "footprint", "inflate"])
+@pytest.mark.parametrize("name", ["walls", "turn", "footprint", "inflate", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_other_scenarios_match_the_reference(episodes, name):
     """scenario_02: corridor of static obstacle rectangles (expanded to boundary points); scenario_03: right turn;
-    scenario_01 with the three-circle ego footprint; scenario_01 with the dynamic collision margin inflated by 1.2."""
+    scenario_01 with the three-circle ego footprint; scenario_01 with the dynamic collision margin inflated by 1.2; six
+    random pedestrian scripts (jittered starts, scaled and turned velocities) on the three scenarios."""
     cfg = scenario_config(episodes["meta"], name)
     with BatchedClosedLoop(cfg, [episodes[name + "_ped_traj"]] * 2) as sim:
         hists = sim.run()
