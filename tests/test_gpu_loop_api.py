@@ -143,3 +143,82 @@ def test_one_launch_pipeline_gives_up_and_the_call_is_repeated():
     assert bp.fused_counts() == (2, 1)
     assert got == want
     bp.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOT_LOOP_FUZZ_SEEDS", "12"))))
+def test_loop_calls_equal_the_separate_calls_on_random_frames(seed):
+    """Random frames: 1 - 9 episodes with 0 - 12 pedestrians each, random prepend flags, staleness and footprint use,
+    a predictor that is sometimes not ready, 0 - 40 static points, requests that revisit episodes (retries) with random
+    targets / overrides / stop directives / cached arc lengths -- fot_loop_plan + fot_loop_observe against prediction,
+    metrics, plan and nearest point through the separate entry points, field by field."""
+    rng = np.random.default_rng(9000 + seed)
+    fp = None
+    if rng.random() < 0.4:
+        from integrated_path_planning_amd.footprint import EgoFootprint
+        fp = EgoFootprint.multi_circle(4.5, 2.0, int(rng.integers(2, 5)))
+    bp = BatchPlanner(waypoints=WP, dt=float(rng.choice([0.1, 0.2])), robot_radius=1.0, obstacle_radius=0.3, footprint=fp,
+                      max_accel=float(rng.uniform(2, 6)))
+    rs = PredictionResampler(bp, pred_len=12, sgan_dt=0.4, sim_dt=bp.params.dt, plan_horizon=5.0)
+    n_static = int(rng.integers(0, 40)) if rng.random() < 0.6 else 0
+    static = np.column_stack([rng.uniform(5, 70, n_static), rng.uniform(-9, 9, n_static)]) if n_static else np.empty((0, 2))
+    bp.loop_set_static(static)
+    n_ep = int(rng.integers(1, 10))
+    counts = rng.integers(0, 13, n_ep)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    pos = np.column_stack([rng.uniform(0, 75, off[-1]), rng.uniform(-6, 6, off[-1])])
+    vel = rng.normal(0, 1.2, (off[-1], 2))
+    obs = np.stack([pos - 0.4 * vel, pos + rng.normal(0, 0.02, pos.shape)]).astype(np.float32)
+    ready = rng.random() < 0.8
+    prepend = rng.random(n_ep) < 0.6
+    stale = float(rng.choice([0.0, 0.1, 0.2, 0.3]))
+    egos = np.column_stack([rng.uniform(0, 50, n_ep), rng.normal(0, 0.5, n_ep), rng.normal(0, 0.1, n_ep),
+                            rng.uniform(0, 9, n_ep), rng.uniform(-1, 1, n_ep)])
+    use_fp = bool(rng.random() < 0.5)
+    frame = dict(ped_off=off, ped_pos=pos, ped_vel=vel, ego=egos[:, :4], ego_radius=1.0, ped_radius=0.3,
+                 use_footprint=use_fp)
+    if ready:
+        frame.update(obs_last=obs[1], obs_prev=obs[0], prepend=prepend, staleness=stale, pred_len=rs.pred_len, rp=rs.params)
+    n_req = int(rng.integers(1, 2 * n_ep + 1))
+    ep_of = np.concatenate([np.arange(n_ep), rng.integers(0, n_ep, max(n_req - n_ep, 0))])[:n_req]
+    targets = np.where(rng.random(n_req) < 0.2, 0.0, rng.uniform(1, 9, n_req))
+    req = _requests(bp, egos[ep_of], ep_of, targets)
+    ov = np.where(rng.random((n_req, 4)) < 0.2, rng.uniform(1.5, 12.0, (n_req, 4)), np.nan)
+    for j, f in enumerate(("max_speed", "max_accel", "max_curvature", "max_lat_accel")):
+        req["overrides"][f] = ov[:, j]
+    stop = np.where(rng.random(n_req) < 0.2, rng.uniform(0.1, 10.0, n_req), np.nan)
+    req["max_stop_distance"] = stop
+    prev_s = np.where(rng.random(n_req) < 0.5, np.clip(egos[ep_of, 0] + rng.normal(0, 1.5, n_req), 0, 79), np.nan)
+    req["ego"]["has_prev_s"] = ~np.isnan(prev_s)
+    req["ego"]["prev_s"] = np.where(np.isnan(prev_s), 0.0, prev_s)
+    req["ego"]["last_kappa"] = rng.normal(0, 0.02, n_req)
+    rec, m = bp.loop_plan(req, frame)
+    rec = rec.copy()
+    # --- the separate entry points
+    dyn, d_off, dims, cursor = [], np.zeros(n_ep, np.int64), np.zeros((n_ep, 4), np.int64), 0
+    for e in range(n_ep):
+        lo, hi = off[e], off[e + 1]
+        d_off[e] = cursor
+        if hi == lo:
+            dims[e] = (0, 1, 0, 1)
+            continue
+        if ready:
+            p = rs.predict_cv(obs[:, lo:hi], staleness=stale, float32_observations=True,
+                              current=pos[lo:hi] if prepend[e] else None)
+        else:
+            p = pos[lo:hi, None, :]
+        dyn.append(p.reshape(-1, 2)); dims[e] = (1, 1, hi - lo, p.shape[1]); cursor += p.shape[0] * p.shape[1]
+    ego = np.zeros(n_req, dtype=bp.EGO_DT)
+    for col, f in enumerate(("x", "y", "yaw", "v", "a")):
+        ego[f] = egos[ep_of, col]
+    ego["last_kappa"], ego["has_prev_s"], ego["prev_s"] = req["ego"]["last_kappa"], req["ego"]["has_prev_s"], req["ego"]["prev_s"]
+    want = bp.plan_arrays(ego, targets, ov, stop, np.tile(static, (n_req, 1)) if n_static else None,
+                          np.arange(n_req + 1) * n_static if n_static else None,
+                          np.concatenate(dyn) if dyn else None, d_off[ep_of] if dyn else None, dims[ep_of] if dyn else None)
+    _same(rec, want)
+    _same(m, bp.safety_metrics_cat(egos[:, :4], off, pos, vel, 1.0, 0.3, use_footprint=use_fp))
+    new = egos + rng.normal(0, 0.3, egos.shape) * np.array([1, 0.1, 0.02, 0.2, 0.1])
+    gps = np.where(rng.random(n_ep) < 0.5, np.clip(new[:, 0], 0, 79), np.nan)
+    am, s_now = bp.loop_observe(new, gps)
+    _same(am, bp.safety_metrics_cat(new[:, :4], off, pos, vel, 1.0, 0.3, use_footprint=use_fp))
+    np.testing.assert_array_equal(s_now, bp.nearest_s_arrays(new[:, 0], new[:, 1], new[:, 2], new[:, 3], new[:, 4], gps))
+    bp.close()
