@@ -11,7 +11,7 @@ import pytest
 import eps_band
 from helpers import EVAL_PATHS, NORTH_STAR_TOL, TIGHT, assert_record_matches_oracle, oracle_plan_for_request, set_eval_path
 from oracle.check import nearest_point_tie
-from integrated_path_planning_amd.batch import PlanRequest
+from integrated_path_planning_amd.batch import PackedBatch, PlanRequest
 from integrated_path_planning_amd.footprint import EgoFootprint
 from integrated_path_planning_amd.planner import BatchPlanner
 from oracle import oracle as orc
@@ -158,6 +158,14 @@ def run_seed(seed, n_inst, dense):
             tol = NORTH_STAR_TOL if nearest_point_tie(res.records[i], want) else TIGHT
             np.testing.assert_allclose(cost, want.cand_cost, rtol=tol, atol=tol, err_msg=label)
             assert_record_matches_oracle(res.records[i], want, label=label)
+        if path == "auto":
+            # the same tensors handed over time-major ([T][S][P][2], what the device resampler can write) and as float32:
+            # time-major float64 gives the very same records; float32 tensors the records of the float32-rounded inputs
+            tsp = bp.plan_packed(PackedBatch(reqs, np.float64, dyn_layout_tsp=True))
+            assert bytes(tsp.records) == bytes(res.records), f"seed {seed}: time-major layout changes the records"
+            f32 = bp.plan_packed(PackedBatch(reqs, np.float32))
+            f32t = bp.plan_packed(PackedBatch(reqs, np.float32, dyn_layout_tsp=True))
+            assert bytes(f32t.records) == bytes(f32.records), f"seed {seed}: time-major float32 layout changes the records"
 
 
 @pytest.mark.parametrize("seed,dense", [(s, False) for s in range(900, 912)] + [(500900 + s, True) for s in range(4)])
