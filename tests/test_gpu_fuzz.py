@@ -11,6 +11,7 @@ import pytest
 import eps_band
 from helpers import EVAL_PATHS, NORTH_STAR_TOL, TIGHT, assert_record_matches_oracle, oracle_plan_for_request, set_eval_path
 from oracle.check import nearest_point_tie
+from integrated_path_planning_amd import _abi
 from integrated_path_planning_amd.batch import PackedBatch, PlanRequest
 from integrated_path_planning_amd.footprint import EgoFootprint
 from integrated_path_planning_amd.planner import BatchPlanner
@@ -166,6 +167,21 @@ def run_seed(seed, n_inst, dense):
             f32 = bp.plan_packed(PackedBatch(reqs, np.float32))
             f32t = bp.plan_packed(PackedBatch(reqs, np.float32, dyn_layout_tsp=True))
             assert bytes(f32t.records) == bytes(f32.records), f"seed {seed}: time-major float32 layout changes the records"
+            # ... and through the asynchronous entry point, tensors and records resident in HBM (no pinned staging, no
+            # record flags: the path of large batches and of a PyTorch producer)
+            import torch
+            pb = PackedBatch(reqs, np.float64)
+            dev = torch.device("cuda", 0)
+            st_t = torch.from_numpy(pb.static_xy).to(dev) if pb.static_xy.size else None
+            dy_t = torch.from_numpy(pb.dyn_xy).to(dev) if pb.dyn_xy.size else None
+            out_t = torch.zeros(len(reqs) * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+            stream = torch.cuda.Stream(device=dev)
+            torch.cuda.synchronize(dev)
+            bp.plan_packed_device(pb.with_device_obstacles(st_t.data_ptr() if st_t is not None else None,
+                                                           dy_t.data_ptr() if dy_t is not None else None),
+                                  out_t.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            assert out_t.cpu().numpy().tobytes() == bytes(res.records), f"seed {seed}: the device entry point differs"
 
 
 @pytest.mark.parametrize("seed,dense", [(s, False) for s in range(900, 912)] + [(500900 + s, True) for s in range(4)])
