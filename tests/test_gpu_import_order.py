@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r"""
-import re, sys
+import faulthandler, re, sys
+faulthandler.dump_traceback_later(150, exit=True)              # a hang shows where, and ends the child
 import numpy as np
 assert "torch" not in sys.modules
 from integrated_path_planning_amd import _abi, synthetic as syn
@@ -43,6 +44,13 @@ print("ONE_RUNTIME_OK", _abi.hip_runtime_path)
 
 def test_planner_before_torch_shares_one_hip_runtime():
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    p = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(2):
+        p = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+        # A second process on the card while this one holds its handles and a torch context: once in some fifty runs of
+        # the whole suite on the shared pool the child did not come back (in isolation: never, tens of runs).  The child
+        # ends itself after 150 s with its Python stack; one more attempt then, and the stack is shown either way.
+        if p.returncode == 0 or "Timeout" not in p.stderr:
+            break
+        print("child timed out, stack:\n" + p.stderr[-3000:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "ONE_RUNTIME_OK" in p.stdout
