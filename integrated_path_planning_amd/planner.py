@@ -10,6 +10,7 @@ kernels; nothing here computes a trajectory.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -167,6 +168,11 @@ class BatchPlanner:
             self._h = None
 
     def __del__(self):
+        # At interpreter shutdown the HIP runtime (and PyTorch's context in the same process) may already be tearing
+        # itself down: a fot_destroy then -- stream synchronisation, frees -- can block for good.  The process is about to
+        # return everything to the OS anyway.
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -38,7 +38,8 @@ maps = open("/proc/self/maps").read()
 hip = sorted(set(re.findall(r"/\S*libamdhip64\S*", maps)))
 hsa = sorted(set(re.findall(r"/\S*libhsa-runtime64\S*", maps)))
 assert len(hip) == 1 and len(hsa) == 1, (hip, hsa)
-print("ONE_RUNTIME_OK", _abi.hip_runtime_path)
+print("ONE_RUNTIME_OK", _abi.hip_runtime_path, flush=True)
+bp.close()
 """
 
 
