@@ -157,9 +157,26 @@ typedef struct fot_handle fot_handle;
 
 const char *fot_version(void);
 
+/* What the library was BUILT with, for a binding to check before its first real call: a binding whose structure layouts
+ * or array capacities differ from the library's corrupts memory instead of failing (round 3: an older libfot.so with
+ * four profile slots under a binding that allocated three aborted the process at exit with "double free or
+ * corruption").  out[i], i < cap: FOT_ABI_VERSION, sizeof of fot_params, fot_ego, fot_overrides, fot_result, fot_batch,
+ * fot_resample_params, fot_safety, fot_loop_frame, fot_loop_request, fot_wire_header, then FOT_MAX_NT, FOT_MAX_CIRCLES,
+ * FOT_MAX_TI, FOT_MAX_TV, FOT_MAX_BRAKE, FOT_MAX_SAMPLES, FOT_MAX_PRED_LEN, FOT_PROFILE_KERNELS, FOT_MARGIN_GROUPS.
+ * Returns the number of words the library knows (FOT_ABI_INFO_WORDS of ITS header). */
+#define FOT_ABI_VERSION 4
+#define FOT_ABI_INFO_WORDS 20
+int32_t fot_abi_info(int32_t cap, int32_t *out);
+
 /* FrenetPlanner.__init__ (frenet_planner.py:149-225).  device < 0: current device. */
 int fot_create(const fot_params *params, int device, fot_handle **out);
+/* Frees the handle.  Idempotent (a pointer fot_create did not return, or one already destroyed, is ignored) and
+ * bounded: the handle's streams and the event behind its last enqueue are polled for at most FOT_DESTROY_TIMEOUT_MS
+ * (default 5000); if they do not drain, or the HIP runtime is already shutting down, device and pinned memory are left
+ * to the process teardown instead of being freed under running work.  Never blocks on a caller's stream. */
 void fot_destroy(fot_handle *h);
+/* handles created and not yet destroyed in this process (what a binding's exit hook still has to close) */
+int32_t fot_live_handles(void);
 const char *fot_last_error(const fot_handle *h);   /* h may be NULL: error of the last failed fot_create */
 
 /* reference_path: CubicSpline2D(waypoints) (cubic_spline.py:190-213) built natively ... */
@@ -217,19 +234,6 @@ int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)
  * _path_is_collision_free merges associatively); large batches walk it in one piece.  n_seg = 1..4 forces the number
  * of segments for the handle's later plan calls, 0 restores the choice by batch size. */
 int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
-
-/* Test hook / experiment.  A synchronous plan call (fot_plan_batch, fot_loop_plan) can run as ONE launch: nearest
- * point / Frenet state, broad phase and evaluation as three phases of one grid that meets at two grid-wide barriers
- * (k_evaluate_fused) -- same device functions, same decisions, byte-identical records; the barrier polls a bounded
- * number of times, and a call whose grid could not get onto the GPU together is planned again with the three kernels.
- * It is OFF by default: a grid barrier needs the same L2 write-back and invalidate a kernel boundary performs, and
- * measured it is slower than the three launches.  mode 0 = never, 1 = calls of one or two egos,
- * 2 = every synchronous call whose grid fits (up to a few dozen egos); 3 = as 2, and the NEXT such call waits at a
- * barrier that cannot be passed (the tests' proof that every workgroup then runs out of polls, reports, leaves, and that
- * the call is planned again with the three kernels).
- * fot_debug_fused_counts: one-launch calls so far and how many of them had to be repeated. */
-int fot_debug_set_fused(fot_handle *h, int32_t mode);
-int fot_debug_fused_counts(const fot_handle *h, int64_t *launches, int64_t *retries);
 
 /* Test hook.  How the handle cuts a lattice into tiles (the unit of work of the evaluation kernel): 0 = chosen by
  * the lattice (default), 1 = per-wave rows (k_evaluate: every wave stages the rows of its own tile), 2 = groups
@@ -390,7 +394,9 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
  * kernel, the number of launches and the summed device time in ms since the last reset. */
 #define FOT_PROFILE_KERNELS 4
 int fot_profile_enable(fot_handle *h, int on);
-int fot_profile_read(fot_handle *h, int reset, int32_t *launches, double *total_ms);
+/* launches / total_ms: arrays of `cap` entries (entries past cap are not written); returns FOT_PROFILE_KERNELS of the
+ * library, or a negative error */
+int fot_profile_read(fot_handle *h, int reset, int32_t cap, int32_t *launches, double *total_ms);
 const char *fot_profile_kernel_name(int index);
 
 #ifdef __cplusplus

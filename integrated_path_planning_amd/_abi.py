@@ -5,8 +5,10 @@ raises -- there is no Python or CPU fallback.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import weakref
 
 MAX_NT = 128
 MAX_CIRCLES = 8
@@ -109,18 +111,85 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfot.so")
 
 # every symbol include/fot.h declares
-SYMBOLS = ["fot_version", "fot_create", "fot_destroy", "fot_last_error", "fot_set_path_waypoints",
+SYMBOLS = ["fot_version", "fot_abi_info", "fot_create", "fot_destroy", "fot_live_handles", "fot_last_error", "fot_set_path_waypoints",
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
-           "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_set_fused", "fot_debug_fused_counts", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
+           "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
            "fot_predict_cv", "fot_safety_metrics_batch", "fot_loop_set_static", "fot_loop_plan", "fot_loop_observe", "fot_loop_observe_begin", "fot_loop_observe_end", "fot_gather_paths", "fot_wire_n_total", "fot_wire_record_bytes",
            "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 4                      # FOT_PROFILE_KERNELS (include/fot.h)
+ABI_VERSION = 4                          # FOT_ABI_VERSION
+MAX_TI, MAX_TV, MAX_BRAKE, MAX_PRED_LEN = 64, 32, 32, 32
 EGO_IS_FRENET = 3                        # FOT_EGO_IS_FRENET (fot_ego.has_prev_s)
 MARGIN_GROUPS = 8                        # FOT_MARGIN_GROUPS
 MARGIN_NAMES = ["speed", "accel", "curvature", "lat_accel", "road", "collision", "stop_filter", "structural"]
 
 _lib = None
+
+
+def abi_expectation():
+    """What fot_abi_info() must report for THIS binding: version, structure sizes, array capacities (include/fot.h)."""
+    return [ABI_VERSION, C.sizeof(Params), C.sizeof(Ego), C.sizeof(Overrides), C.sizeof(Result), C.sizeof(Batch),
+            C.sizeof(ResampleParams), C.sizeof(Safety), C.sizeof(LoopFrame), C.sizeof(LoopRequest), C.sizeof(WireHeader),
+            MAX_NT, MAX_CIRCLES, MAX_TI, MAX_TV, MAX_BRAKE, MAX_SAMPLES, MAX_PRED_LEN, PROFILE_KERNELS, MARGIN_GROUPS]
+
+
+ABI_WORD_NAMES = ["FOT_ABI_VERSION", "sizeof(fot_params)", "sizeof(fot_ego)", "sizeof(fot_overrides)", "sizeof(fot_result)",
+                  "sizeof(fot_batch)", "sizeof(fot_resample_params)", "sizeof(fot_safety)", "sizeof(fot_loop_frame)",
+                  "sizeof(fot_loop_request)", "sizeof(fot_wire_header)", "FOT_MAX_NT", "FOT_MAX_CIRCLES", "FOT_MAX_TI",
+                  "FOT_MAX_TV", "FOT_MAX_BRAKE", "FOT_MAX_SAMPLES", "FOT_MAX_PRED_LEN", "FOT_PROFILE_KERNELS",
+                  "FOT_MARGIN_GROUPS"]
+
+
+def _check_abi(L, path):
+    """Refuse a library whose layouts differ from this binding's: an old libfot.so under new ctypes structures (or the
+    other way round) writes past the caller's arrays instead of failing -- round 3's "double free or corruption" at
+    process exit was exactly that (a library with four profile slots filling arrays of three)."""
+    try:
+        f = L.fot_abi_info
+    except AttributeError:
+        raise ImportError(f"{path} predates fot_abi_info (ABI {ABI_VERSION}): rebuild it with `make -C "
+                          f"{os.path.join(_HERE, 'csrc')}`") from None
+    f.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
+    f.restype = C.c_int32
+    want = abi_expectation()
+    got = (C.c_int32 * len(want))()
+    n = f(len(want), got)
+    bad = [f"{ABI_WORD_NAMES[i]}: library {got[i]}, binding {want[i]}" for i in range(min(n, len(want))) if got[i] != want[i]]
+    if n != len(want):
+        bad.append(f"the library reports {n} ABI words, the binding knows {len(want)}")
+    if bad:
+        raise ImportError(f"{path} does not match this binding (include/fot.h changed since it was built?): "
+                          + "; ".join(bad))
+
+
+# ---- handle lifetime: every owner of a libfot handle registers itself here; whatever is still open when the interpreter
+# exits is closed by the atexit hook -- BEFORE module teardown and before the HIP runtime's own exit handlers, while
+# streams, events and the context are intact.  (Round 3 let __del__ run fot_destroy during finalisation, or leaked the
+# handle there; neither is deterministic.)
+_live_owners = weakref.WeakSet()
+
+
+def register_owner(obj):
+    """``obj.close()`` will be called at interpreter exit unless it was closed (and unregistered) before."""
+    _live_owners.add(obj)
+
+
+def unregister_owner(obj):
+    _live_owners.discard(obj)
+
+
+def close_all():
+    """Close every registered owner that is still open (the atexit hook; also callable from tests)."""
+    for obj in list(_live_owners):
+        try:
+            obj.close()
+        except Exception:
+            pass
+    _live_owners.clear()
+
+
+atexit.register(close_all)
 
 
 class FotError(RuntimeError):
@@ -213,6 +282,7 @@ def lib():
             "(hipcc, gfx950). There is no CPU fallback.")
     _bind_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    _check_abi(L, LIB_PATH)
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int32)
     vp = C.c_void_p
@@ -222,6 +292,8 @@ def lib():
     L.fot_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp)]
     L.fot_destroy.argtypes = [vp]
     L.fot_destroy.restype = None
+    L.fot_live_handles.argtypes = []
+    L.fot_live_handles.restype = C.c_int32
     L.fot_set_path_waypoints.argtypes = [vp, C.c_int32, dp, dp]
     L.fot_set_path_coeffs.argtypes = [vp, C.c_int32] + [dp] * 9
     L.fot_get_path_coeffs.argtypes = [vp, ip] + [dp] * 9
@@ -237,8 +309,6 @@ def lib():
     L.fot_debug_margins.argtypes = [vp, C.c_int32, C.c_int32, dp]
     L.fot_debug_set_eval_segments.argtypes = [vp, C.c_int32]
     L.fot_debug_set_tile_cut.argtypes = [vp, C.c_int32]
-    L.fot_debug_set_fused.argtypes = [vp, C.c_int32]
-    L.fot_debug_fused_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.fot_debug_time_info.argtypes = [vp, C.c_double, ip, dp, dp]
     L.fot_check_paths.argtypes = [vp, C.c_int32, ip, ip] + [dp] * 9 + [C.POINTER(Overrides), C.c_double, C.c_int32, dp,
                                                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip]
@@ -260,7 +330,7 @@ def lib():
     L.fot_pack_records_host.argtypes = [C.c_int32, C.c_int32, vp, vp]
     L.fot_unpack_records.argtypes = [C.c_int32, C.c_int32, vp, vp]
     L.fot_profile_enable.argtypes = [vp, C.c_int]
-    L.fot_profile_read.argtypes = [vp, C.c_int, ip, dp]
+    L.fot_profile_read.argtypes = [vp, C.c_int, C.c_int32, ip, dp]
     L.fot_profile_kernel_name.argtypes = [C.c_int]
     L.fot_profile_kernel_name.restype = C.c_char_p
     _lib = L

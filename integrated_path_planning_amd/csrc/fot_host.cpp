@@ -9,8 +9,11 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "fot_kernels.h"
@@ -49,7 +52,9 @@ struct PinnedBuf {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        // fine-grained (coherent) whatever HIP_HOST_COHERENT says: kernels write records and their flags into these
+        // blocks while the host polls them (wait_records)
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
         return hipSuccess;
@@ -132,15 +137,6 @@ struct fot_handle {
     hipStream_t order_stream = nullptr;
     bool order_valid = false;
     int eval_segments = 0;               // fot_debug_set_eval_segments
-    // the one-launch pipeline of small synchronous calls (k_evaluate_fused; measured SLOWER than the three kernels, so
-    // off unless asked for): 0 = never, 1 = calls of one or two egos, 2 = every call whose grid fits
-    // (fot_debug_set_fused); its grid barrier's counter, the count it has reached, and the word in pinned memory a
-    // workgroup sets when it gave up waiting
-    int fused_mode = 0;
-    DevBuf dBarrier;
-    int32_t barrier_base = 0;
-    PinnedBuf hFusedErr;
-    int64_t fused_launches = 0, fused_retries = 0;
     // Completion of a synchronous small call without a stream synchronisation: the wave that writes a record (into
     // pinned memory) raises that record's flag to the call's sequence number behind a system-scope release; the host
     // polls the flags.  hipStreamSynchronize returns some 10 us after the last kernel ended on this platform -- a sixth
@@ -176,6 +172,41 @@ struct fot_handle {
 };
 
 namespace {
+
+// Every handle fot_create returned and fot_destroy has not taken back: fot_destroy of anything else (a second destroy,
+// a stale pointer) is a no-op instead of a double free, and a binding can ask how many it still owns (fot_live_handles).
+std::mutex g_live_mu;
+std::unordered_set<fot_handle *> &live_handles()
+{
+    static std::unordered_set<fot_handle *> *s = new std::unordered_set<fot_handle *>();   // (never destroyed: no static
+    return *s;                                                                            //  destructor order to lose)
+}
+
+// Teardown never blocks for good.  Work the handle enqueued may sit on a CALLER's stream (fot_plan_batch_device on a
+// PyTorch stream) whose owner is free to have destroyed it, and a destroy may run while the process is exiting: the
+// handle's streams and its ordering event are POLLED (hipStreamQuery / hipEventQuery) for a bounded time; if they do
+// not drain, or the runtime answers with an error, the device and pinned memory is left to the process teardown
+// instead of being freed under work that may still touch it.
+double destroy_timeout_s()
+{
+    if (const char *ev = std::getenv("FOT_DESTROY_TIMEOUT_MS")) { const double v = std::atof(ev); if (v >= 0.0) return v * 1e-3; }
+    return 5.0;
+}
+
+void destroy_handle(fot_handle *h);           // (below fot_create: frees what a handle owns, registered or not)
+
+template <class Query>
+bool drained(const Query &query, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return false; }   // stream / context gone: nothing to wait for, nothing to free
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
 
 int fail(fot_handle *h, int code, const std::string &msg)
 {
@@ -258,7 +289,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // memory directly (fot_plan_batch, fot_safety_metrics_batch, fot_frenet_state_batch, the host path of the resampler).
 constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_evaluate_fused" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_certify" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -296,8 +327,6 @@ struct ProfScope {
     }
     ~ProfScope() { if (active) (void)hipEventRecord(stop, st); }
 };
-
-constexpr int FUSED_MAX_WG = 128;             // workgroups of k_evaluate_fused: all resident together on an idle GPU
 
 // Stage descriptors, size the lane's workspace and enqueue the whole pipeline for the sub-batch `b` on `st`.
 // d_static / d_dyn are device pointers to the caller's obstacle coordinates (offsets in b are absolute),
@@ -379,24 +408,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
             scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 65535) / 65536));
         }
     }
-    // A synchronous call of a few egos: the three phases in one launch (the caller checks *hFusedErr after its wait)
-    const int64_t fused_wg = std::max<int64_t>((int64_t)L.n_inst * L.max_tiles,
-                                               (int64_t)L.n_inst * (1 + (L.n_tracks > 0 ? scan.blocks_per_inst : 0)));
-    if (sync_caller && h->fused_mode != 0 && L.n_tiles > 0 && h->eval_segments == 0 &&
-        (h->fused_mode >= 2 ? fused_wg <= 4 * FUSED_MAX_WG : L.n_inst <= 2 && fused_wg <= FUSED_MAX_WG)) {
-        ProfScope ps(h, 3, st);
-        if (h->fused_mode == 3) {                                // (test hook: a barrier nobody can pass -- every workgroup
-            h->barrier_base += 1 << 28;                          //  must run out of polls, report and leave)
-            h->fused_mode = 2;
-        }
-        LAUNCH_TRY(h, launch_plan_fused(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, P.n_ti + P.n_brake, L.n_inst,
-                                        imp, scan, d_static, d_dyn, b.obstacle_dtype, L.any_obstacles, tt, ea, ca, d_out,
-                                        w.dDone.as<int32_t>(), h->dBarrier.as<int32_t>(), &h->barrier_base,
-                                        (int32_t *)h->hFusedErr.p, FUSED_MAX_WG, st));
-        HIP_TRY(h, hipEventRecord(w.staging_done[slot], st));
-        ++h->fused_launches;
-        return FOT_OK;
-    }
     {
         ProfScope ps(h, 0, st);
         LAUNCH_TRY(h, launch_frenet_state(dP, sv, d_desc, w.dState.as<InstState>(), L.n_inst, imp, scan, w.dDone.as<int32_t>(), st));
@@ -433,8 +444,7 @@ fot_batch sub_batch(const fot_batch &b, int i0, int n)
 // Enqueue one plan call behind everything already on `user`; small batches run on `user` itself, large ones
 // fork into the lanes' streams and join `user` again.
 // sync_caller: the caller waits for the records right behind this call (the synchronous entry points): the selecting
-// waves then raise a flag per record in pinned memory (wait_records), and a call of one or two egos may take the
-// one-launch pipeline if that is switched on.
+// waves then raise a flag per record in pinned memory (wait_records).
 int enqueue_plan(fot_handle *h, const fot_batch &b, const void *d_static, const void *d_dyn, fot_result *d_out,
                  hipStream_t user, bool sync_caller = false, void *d_dyn_stage = nullptr)
 {
@@ -484,7 +494,10 @@ bool arm_records(fot_handle *h, int n)
 {
     h->done_seq_armed = false;
     static const bool off = std::getenv("FOT_NO_RECORD_FLAGS") != nullptr;       // diagnostics scripts
-    if (off || h->fused_mode != 0 || h->prof_on || n <= 0 || n > 64) return false;
+    if (off || h->prof_on || n <= 0 || n > 64) return false;
+    // only the single-lane path hands the flags to its kernels (the predicate of enqueue_plan): a call the lanes split
+    // would raise none, and wait_records would spin out its 20 ms before falling back to the stream
+    if (h->lanes_cfg > 1 && n >= FOT_SPLIT_MIN_INSTANCES * h->lanes_cfg / 2) return false;
     if (h->hDone.ensure(sizeof(int32_t) * 64) != hipSuccess) return false;
     if (++h->done_seq == 0) {                                    // (wrapped: no stale flag may equal the new number)
         std::memset(h->hDone.p, 0, sizeof(int32_t) * 64);
@@ -520,21 +533,6 @@ int wait_records(fot_handle *h, int n, hipStream_t st)
     return FOT_OK;
 }
 
-// After the wait of a synchronous call that was allowed the one-launch pipeline: true when a workgroup of it gave up at
-// a grid barrier (its records are void).  The barrier is put back to zero; the caller plans the call again with the
-// three kernels.
-int fused_gave_up(fot_handle *h, bool *gave_up)
-{
-    volatile int32_t *err = (volatile int32_t *)h->hFusedErr.p;
-    *gave_up = *err != 0;
-    if (!*gave_up) return FOT_OK;
-    *err = 0;
-    HIP_TRY(h, hipMemsetAsync(h->dBarrier.p, 0, sizeof(int32_t), h->stream));   // (ordered before the next launch on that stream)
-    h->barrier_base = 0;
-    ++h->fused_retries;
-    return FOT_OK;
-}
-
 // lane and local index of global instance `inst` of the most recent plan call
 Workspace *lane_of(fot_handle *h, int inst, int *local)
 {
@@ -550,7 +548,21 @@ Workspace *lane_of(fot_handle *h, int inst, int *local)
 
 extern "C" {
 
-const char *fot_version(void) { return "libfot 0.1 (gfx950, float64 lattice)"; }
+const char *fot_version(void) { return "libfot 0.2 (gfx950, float64 lattice)"; }
+
+int32_t fot_abi_info(int32_t cap, int32_t *out)
+{
+    const int32_t v[FOT_ABI_INFO_WORDS] = {
+        FOT_ABI_VERSION,
+        (int32_t)sizeof(fot_params), (int32_t)sizeof(fot_ego), (int32_t)sizeof(fot_overrides), (int32_t)sizeof(fot_result),
+        (int32_t)sizeof(fot_batch), (int32_t)sizeof(fot_resample_params), (int32_t)sizeof(fot_safety),
+        (int32_t)sizeof(fot_loop_frame), (int32_t)sizeof(fot_loop_request), (int32_t)sizeof(fot_wire_header),
+        FOT_MAX_NT, FOT_MAX_CIRCLES, FOT_MAX_TI, FOT_MAX_TV, FOT_MAX_BRAKE, FOT_MAX_SAMPLES, FOT_MAX_PRED_LEN,
+        FOT_PROFILE_KERNELS, FOT_MARGIN_GROUPS,
+    };
+    for (int i = 0; i < FOT_ABI_INFO_WORDS && i < cap && out; ++i) out[i] = v[i];
+    return FOT_ABI_INFO_WORDS;
+}
 
 const char *fot_last_error(const fot_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -579,7 +591,7 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     h->P = P;
     auto bail = [&](hipError_t ee, const char *what) {
         int r = hip_fail(nullptr, ee, what);
-        fot_destroy(h);
+        destroy_handle(h);
         return r;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
@@ -598,32 +610,60 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
     }
     if ((e = h->dP.ensure(sizeof(DevParams))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemcpy(h->dP.p, &h->P, sizeof(DevParams), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
-    if ((e = h->dBarrier.ensure(sizeof(int32_t))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(h->dBarrier.p, 0, sizeof(int32_t))) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = h->hFusedErr.ensure(sizeof(int32_t))) != hipSuccess) return bail(e, "hipHostMalloc");
-    *(volatile int32_t *)h->hFusedErr.p = 0;
-    if (const char *ev = std::getenv("FOT_FUSED")) h->fused_mode = ev[0] == '1' ? 1 : ev[0] == '2' ? 2 : 0;   // diagnostics scripts
     {
         int cut = TILE_CUT_AUTO;                                 // FOT_TILE_CUT=wave|group: diagnostics scripts
         if (const char *ev = std::getenv("FOT_TILE_CUT")) cut = ev[0] == 'g' ? TILE_CUT_GROUP : ev[0] == 'w' ? TILE_CUT_WAVE : TILE_CUT_AUTO;
-        if (upload_tile_shapes(h, cut) != FOT_OK) { std::string m = h->err; fot_destroy(h); return fail(nullptr, FOT_ERR_HIP, m); }
+        if (upload_tile_shapes(h, cut) != FOT_OK) { std::string m = h->err; destroy_handle(h); return fail(nullptr, FOT_ERR_HIP, m); }
     }
+    { std::lock_guard<std::mutex> lk(g_live_mu); live_handles().insert(h); }
     *out = h;
     return FOT_OK;
+}
+
+int32_t fot_live_handles(void)
+{
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return (int32_t)live_handles().size();
 }
 
 void fot_destroy(fot_handle *h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->order_valid) (void)hipEventSynchronize(h->order_done);   // work enqueued on a caller's stream
-    for (Workspace &w : h->ws) if (w.stream) (void)hipStreamSynchronize(w.stream);
-    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dShapes, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD,
-                       &h->dBarrier };
+    {   // idempotent: only a handle fot_create handed out and nobody has destroyed yet (the pointer is not even read else)
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        auto &live = live_handles();
+        auto it = live.find(h);
+        if (it == live.end()) return;
+        live.erase(it);
+    }
+    destroy_handle(h);
+}
+
+}  // extern "C"
+
+namespace {
+
+void destroy_handle(fot_handle *h)
+{
+    const double budget = destroy_timeout_s();
+    bool quiet = hipSetDevice(h->device) == hipSuccess;
+    // the handle's own stream, the lanes' streams, and the event behind its last enqueue (which may be on a caller's
+    // stream): polled, never waited on
+    if (quiet && h->stream) quiet = drained([&] { return hipStreamQuery(h->stream); }, budget);
+    if (quiet && h->order_valid) quiet = drained([&] { return hipEventQuery(h->order_done); }, budget);
+    for (Workspace &w : h->ws) if (quiet && w.stream) quiet = drained([&] { return hipStreamQuery(w.stream); }, budget);
+    if (!quiet) {
+        // something is still running (or the runtime is already gone): the host-side struct goes, everything the device
+        // may still touch stays until the process ends
+        (void)hipGetLastError();
+        delete h;
+        return;
+    }
+    DevBuf *bufs[] = { &h->dP, &h->dSpline, &h->dShapes, &h->dUserStatic, &h->dUserDyn, &h->dOut, &h->dTmpA, &h->dTmpB, &h->dTmpC, &h->dTmpD
+                     };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
-    h->hSmallIn.release(); h->hSmallOut.release(); h->hFusedErr.release(); h->hDone.release();
+    h->hSmallIn.release(); h->hSmallOut.release(); h->hDone.release();
     h->loop.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -631,6 +671,10 @@ void fot_destroy(fot_handle *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
+
+}  // namespace
+
+extern "C" {
 
 int fot_set_path_waypoints(fot_handle *h, int32_t n, const double *wx, const double *wy)
 {
@@ -1013,18 +1057,14 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
         if (n_static > 0) { b.static_xy = L.dStatic.p; b.static_off = s_off.data(); }
         if (any_dyn) { b.dyn_xy = L.dyn_ptr; b.dyn_off = d_off.data(); b.dyn_dims = dims.data(); }
         HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * (size_t)n_req));
-        for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
+        {
             // the records' flags instead of the stream (wait_records): the metrics' kernel ran ahead of the plan kernels on
             // this stream and wrote host memory directly, so its results are there once a record behind it is
-            if (attempt == 0) arm_records(h, n_req);
-            int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st, attempt == 0);
+            arm_records(h, n_req);
+            int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st, true);
             if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
             rc = wait_records(h, n_req, st);
             if (rc != FOT_OK) return rc;
-            bool again = false;
-            rc = fused_gave_up(h, &again);
-            if (rc != FOT_OK) return rc;
-            if (!again) break;
         }
     } else {
         int r = order_end(h, st); if (r != FOT_OK) return r;
@@ -1119,18 +1159,21 @@ int fot_profile_enable(fot_handle *h, int on)
     return FOT_OK;
 }
 
-int fot_profile_read(fot_handle *h, int reset, int32_t *launches, double *total_ms)
+int fot_profile_read(fot_handle *h, int reset, int32_t cap, int32_t *launches, double *total_ms)
 {
     if (!h) return FOT_ERR_INVALID;
+    if (cap < 0) return fail(h, FOT_ERR_INVALID, "fot_profile_read: cap < 0");
     HIP_TRY(h, hipSetDevice(h->device));
     int r = prof_drain(h);
     if (r != FOT_OK) return r;
     for (int k = 0; k < FOT_PROFILE_KERNELS; ++k) {
-        if (launches) launches[k] = h->prof_launches[k];
-        if (total_ms) total_ms[k] = h->prof_ms[k];
+        if (k < cap) {                                           // (never past the caller's arrays, whatever header it was built with)
+            if (launches) launches[k] = h->prof_launches[k];
+            if (total_ms) total_ms[k] = h->prof_ms[k];
+        }
         if (reset) { h->prof_launches[k] = 0; h->prof_ms[k] = 0.0; }
     }
-    return FOT_OK;
+    return FOT_PROFILE_KERNELS;
 }
 
 const char *fot_profile_kernel_name(int index)
@@ -1179,17 +1222,11 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
         static const bool no_stage = std::getenv("FOT_NO_SCAN_STAGE") != nullptr;        // diagnostics scripts
         void *stage = nullptr;
         if (dy_bytes && !no_stage) { HIP_TRY(h, h->dUserDyn.ensure(dy_bytes + 256)); stage = h->dUserDyn.p; }
-        for (int attempt = 0; attempt < 2; ++attempt) {             // (second attempt: the one-launch pipeline gave up)
-            if (attempt == 0) arm_records(h, batch->n_inst);
-            rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, attempt == 0, stage);
-            if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
-            rc = wait_records(h, batch->n_inst, h->stream);
-            if (rc != FOT_OK) return rc;
-            bool again = false;
-            rc = fused_gave_up(h, &again);
-            if (rc != FOT_OK) return rc;
-            if (!again) break;
-        }
+        arm_records(h, batch->n_inst);
+        rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, true, stage);
+        if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
+        rc = wait_records(h, batch->n_inst, h->stream);
+        if (rc != FOT_OK) return rc;
         std::memcpy(out, h->hSmallOut.p, out_bytes);
         return FOT_OK;
     }
@@ -1399,24 +1436,6 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg)
     if (!h) return FOT_ERR_INVALID;
     if (n_seg < 0 || n_seg > 4) return fail(h, FOT_ERR_INVALID, "fot_debug_set_eval_segments: 0 (automatic) .. 4");
     h->eval_segments = n_seg;
-    return FOT_OK;
-}
-
-int fot_debug_set_fused(fot_handle *h, int32_t mode)
-{
-    if (!h) return FOT_ERR_INVALID;
-    if (mode < 0 || mode > 3)
-        return fail(h, FOT_ERR_INVALID, "fot_debug_set_fused: 0 (never), 1 (calls of one or two egos), 2 (whenever the grid fits), "
-                                        "3 (as 2, the next call with a barrier that cannot be passed)");
-    h->fused_mode = mode;
-    return FOT_OK;
-}
-
-int fot_debug_fused_counts(const fot_handle *h, int64_t *launches, int64_t *retries)
-{
-    if (!h) return FOT_ERR_INVALID;
-    if (launches) *launches = h->fused_launches;
-    if (retries) *retries = h->fused_retries;
     return FOT_OK;
 }
 

@@ -98,11 +98,6 @@ int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_d
 int launch_safety(const DevParams *P, int n, const double *ego, const int32_t *ped_off, const double *ped_pos,
                   const double *ped_vel, double ego_radius, double ped_radius, double footprint_radius, int use_fp,
                   fot_safety *out, hipStream_t st);
-// the whole plan call of a few egos in one launch (k_evaluate_fused); *barrier_base: the handle's running barrier count
-int launch_plan_fused(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_total, int n_ext,
-                      int n_inst, MetaImport imp, NanScan scan, const void *static_xy, const void *dyn_xy, int dtype,
-                      bool do_cull, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
-                      int32_t *barrier, int32_t *barrier_base, int32_t *error, int max_wg, hipStream_t st);
 int launch_check_ext(const DevParams *P, const InstDesc *desc, int n_paths, int mode, const int32_t *len,
                      const int32_t *flags, const double *arrays, const double *static_xy, const double *dyn_xy,
                      int32_t *status_out, hipStream_t st);

@@ -502,53 +502,20 @@ struct FusedSink {
     // end of the time step, reached by every lane: the warm-up loads have landed, pf may be reused
     __device__ __forceinline__ void row_end(int) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf) : : "memory"); }
 
-    __device__ __forceinline__ void put(int k, int, double px, double py, bool alive)
+    __device__ __forceinline__ void put(int k, int ci, double px, double py, bool alive)
     {
-        if (n_chunks == 0) return;                                // wave-uniform
-        if (!alive || hit) return;                                // lanes whose collision outcome is already settled
-        float fx = (float)px, fy = (float)py;                     // (the rows are instance-local: evaluate_tile)
-        bool sure = false;                                        // some obstacle is certainly within its radius
-        const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
-        for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
-            const int nb = n_chunks - c0 < 32 ? n_chunks - c0 : 32;   // (may be odd: the last pair then tests one chunk)
-            const f2x8 *cp = row + c0;
-            uint32_t near_bits = 0;                               // chunk c0+i within the threshold -> bit nb-1-i
-            // Branch-free loop over two chunk buffers filled by hand-issued scalar loads.  SMEM returns out of
-            // order, so a compiler-placed wait for the chunk in use would also wait for the prefetch behind it;
-            // the loads are therefore inline asm (invisible to the waitcnt pass) and each buffer is waited for
-            // right before its own use, one chunk of arithmetic after its load was issued.  The last pair
-            // prefetches one chunk past the list (allocated slack, never used).
-            f16 ca, cb;
-            sload_chunk<0>(ca, cp);
-            swait_chunk(ca);
-            for (int c = 0; c < nb; c += 2) {
-                sload_chunk_ahead<64>(cb, cp, fx);
-                const float ma = min_sqdist32_f16(ca, fx, fy);
-                near_bits = (near_bits << 1) | (uint32_t)(ma <= thr);
-                sure |= ma <= thr_fatal;
-                swait_chunk(cb);
-                sload_chunk_ahead<128>(ca, cp, fx);
-                if (c + 1 < nb) {                                     // wave-uniform
-                    const float mb = min_sqdist32_f16(cb, fx, fy);
-                    near_bits = (near_bits << 1) | (uint32_t)(mb <= thr);
-                    sure |= mb <= thr_fatal;
-                }
-                swait_chunk(ca);
-                cp += 2;
-            }
-            // a single violation is fatal (no chance constraint budget): a certain float32 hit settles the candidate
-            if (sure) { hit = true; return; }
-            if (near_bits != 0) exact(k, c0, nb, near_bits, px, py, fx, fy);
-        }
+        // (the rows are instance-local: evaluate_tile) -- the point itself is its own exact form
+        put32(k, ci, (float)px, (float)py, alive, [&](double &ex, double &ey) { ex = px; ey = py; });
     }
 
-    // (-DFOT_TIER) the point in the instance-local float32 frame; get_exact(px, py) yields its float64 coordinates, asked for only
-    // by the lanes whose float32 distance to some entry lies between the two thresholds
+    // the point in the instance-local float32 frame; get_exact(px, py) yields its float64 coordinates, asked for only by
+    // the lanes whose float32 distance to some entry lies between the two thresholds
     template <class GetExact>
-    __device__ __forceinline__ void put32(int k, int, float fx, float fy, bool alive, const GetExact &get_exact)
+    __device__ __forceinline__ void put32(int k, int, float fx_in, float fy, bool alive, const GetExact &get_exact)
     {
         if (n_chunks == 0) return;                                // wave-uniform
         if (!alive || hit) return;                                // lanes whose collision outcome is already settled
+        float fx = fx_in;                                         // (tied into the hand-issued loads below)
         bool sure = false;                                        // some obstacle is certainly within its radius
         const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
         for (int c0 = 0; c0 < n_chunks; c0 += 32) {               // 32 chunks per pass: one bit per chunk and lane
@@ -611,7 +578,6 @@ struct FusedSink {
     }
 
     __device__ __forceinline__ bool collided() const { return hit; }
-    __device__ __forceinline__ void restart() { hit_mask = 0; viol = 0; hit = false; }   // (the second, float64 walk)
 };
 
 // Longitudinal rows of a tile's profiles in the wave's own slice of LDS: the 64 candidates of a tile share two or
@@ -675,64 +641,6 @@ struct StagedTab {
         return s_;
     }
 };
-
-#ifdef FOT_TIER2
-// Rows of the float32 walk (tier2_walk, fot_math.hpp), same 72 bytes: nine float32 fields, then the float64 reference
-// point and tangent the exact collision point is rebuilt from.
-struct TierRow { float sd, sdd, rx, ry, cos_r, sin_r, kr, dkr, inv_sd, pad; double rx64, ry64, cos64, sin64; };
-static_assert(sizeof(TierRow) == ROW_FIELDS * sizeof(double), "a tier row takes the place of a float64 row");
-
-struct TierTab {
-    int lds_row0, k_max;
-    double dt;
-    const LonInfo *info;                 // in LDS
-    __device__ __forceinline__ const TierRow &row(int k) const
-    {
-        return *(const TierRow *)(s_lon + lds_row0 + (k < k_max ? k : k_max) * ROW_FIELDS);
-    }
-    __device__ __forceinline__ void load32(int k, Row32 &r) const
-    {
-        const TierRow &t = row(k);
-        r.sd = t.sd; r.sdd = t.sdd; r.rx = t.rx; r.ry = t.ry; r.cos_r = t.cos_r; r.sin_r = t.sin_r; r.kr = t.kr;
-        r.dkr = t.dkr; r.inv_sd = t.inv_sd;
-        asm volatile("" : "+v"(r.sd), "+v"(r.sdd), "+v"(r.rx), "+v"(r.ry), "+v"(r.cos_r), "+v"(r.sin_r), "+v"(r.kr),
-                          "+v"(r.dkr), "+v"(r.inv_sd));           // (in registers before the sink's scalar warm-up loads)
-    }
-    __device__ __forceinline__ void load_exact(int k, double &rx, double &ry, double &cr, double &sr) const
-    {
-        const TierRow &t = row(k);
-        rx = t.rx64; ry = t.ry64; cr = t.cos64; sr = t.sin64;    // (instance-local, like FusedSink's points)
-    }
-    __device__ __forceinline__ double s_at(int k) const
-    {
-        double s_, u0, u1, u2;
-        lon_sample(*info, k, dt, s_, u0, u1, u2);
-        return s_;
-    }
-};
-
-// The float64 walk of a tile the float32 walk gave up on: its rows are not in LDS (the tier's are), every lane rebuilds
-// the row it needs from its profile -- the same function that fills a float64 row table, the same values.
-struct RebuildTab {
-    static constexpr bool LOCAL = true;
-    SplineView sp;                       // (in LDS when short)
-    const LonInfo *info;                 // in LDS
-    int k_max;
-    double dt, ox, oy;
-    __device__ __forceinline__ void load(int k, LonSample &o) const
-    {
-        double sddd;
-        make_lon_sample(sp, *info, k < k_max ? k : k_max, dt, o, sddd);
-        o.rx -= ox; o.ry -= oy;
-    }
-    __device__ __forceinline__ double s_at(int k) const
-    {
-        double s_, u0, u1, u2;
-        lon_sample(*info, k, dt, s_, u0, u1, u2);
-        return s_;
-    }
-};
-#endif
 
 #ifdef FOT_TIMELINE
 // diagnostic build (scripts/timeline.sh): per tile of the last k_evaluate launch -- tile start, start of the sample
@@ -837,16 +745,6 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         double *r = my_rows + (int64_t)i * ROW_FIELDS;
         // the reference point in the instance-local frame (origin: the ego position, like the entry lists): the walk then
         // hands its points to the collision test as they are, and nothing else of it depends on the frame
-#ifdef FOT_TIER2
-        if constexpr (!SPLIT) {
-            TierRow &t = *(TierRow *)r;
-            const double lx = ls.rx - D.ego.x, ly = ls.ry - D.ego.y;
-            t.sd = (float)ls.sd; t.sdd = (float)ls.sdd; t.rx = (float)lx; t.ry = (float)ly; t.cos_r = (float)ls.cos_r;
-            t.sin_r = (float)ls.sin_r; t.kr = (float)ls.kr; t.dkr = (float)ls.dkr; t.inv_sd = (float)ls.inv_sd; t.pad = 0.0f;
-            t.rx64 = lx; t.ry64 = ly; t.cos64 = ls.cos_r; t.sin64 = ls.sin_r;
-            continue;
-        }
-#endif
         r[0] = ls.sd; r[1] = ls.sdd; r[2] = ls.rx - D.ego.x; r[3] = ls.ry - D.ego.y;
         r[4] = ls.cos_r; r[5] = ls.sin_r; r[6] = ls.kr; r[7] = ls.dkr; r[8] = ls.inv_sd;
     }
@@ -919,28 +817,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
         sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
         sink.hit_mask = 0; sink.viol = 0; sink.hit = false; sink.n_chunks = 0; sink.c_lo = 0; sink.pf = 0;
-#ifdef FOT_TIER2
-        sink.no_warm = true;                 // (no load in flight across the sample arithmetic: scalar registers are short)
-#else
         sink.no_warm = (a.ablate & 2) != 0;
-#endif
-#ifdef FOT_TIER2
-        // The float32 walk first (tier2_walk: certifies every decision of the candidate or gives up); a tile one of
-        // whose candidates it gave up on is walked by the float64 code.  Not tried where its preconditions fail: footprint
-        // circles, a stop-distance directive, an ego so slow that most of the lattice lives under the low-speed rules.
-        bool walk64 = true;
-        if constexpr (!SPLIT) {
-            const bool tier_ok = !P.has_footprint && isnan(D.max_stop) && S.frenet0[1] > 1.0;      // wave-uniform
-            if (tier_ok) {
-                TierTab tt;
-                tt.lds_row0 = tab.lds_row0; tt.k_max = tab.k_max; tt.dt = tab.dt; tt.info = tab.info;
-                const bool gave_up = tier2_walk(P, D, L, tt, q, k1, sink, g);
-                walk64 = __ballot(gave_up) != 0ull;
-                if (walk64) { seg_init(g); sink.restart(); }
-            }
-        }
-        if (walk64) {
-#endif
         // loop constants as opaque register values: the compiler then keeps them instead of re-fetching each one from
         // the parameter blocks, behind a scalar-memory wait, in every time step
         LoopConst lc = loop_const(P, D);
@@ -951,25 +828,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
                           "+v"(lc.road_lim));
         lc.n_circ_fp = __builtin_amdgcn_readfirstlane(lc.n_circ_fp);
         asm volatile("" : "+s"(lc.n_circ_fp));
-        if constexpr (SPLIT) {
-            evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);      // (a handful of egos: latency, not issue, bound)
-        } else {
-            // -DFOT_TIER: the first form of the float32 tier (fot_math.hpp tier_walk): certified float32 steps, float64
-            // where float32 proves nothing, step by step.  Exact but SLOWER as built -- 0.39 ms against 0.23 ms: 144
-            // vector registers (three waves per SIMD), 59 lane-spilled scalars.
-#if defined(FOT_TIER)
-            tier_walk(P, D, L, tab, q, k1, sink, g);
-#elif defined(FOT_TIER2)
-            RebuildTab rt;
-            rt.sp = sp_lds; rt.info = tab.info; rt.k_max = tab.k_max; rt.dt = tab.dt; rt.ox = D.ego.x; rt.oy = D.ego.y;
-            evaluate_segment(P, lc, L, rt, q, k0, k1, sink, g);
-#else
-            evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);
-#endif
-        }
-#ifdef FOT_TIER2
-        }
-#endif
+        evaluate_segment(P, lc, L, tab, q, k0, k1, sink, g);   // (SPLIT: a quarter of the steps -- latency, not issue, bound)
         hit_mask = sink.hit_mask; hit = sink.hit;
 #ifdef FOT_TIMELINE
         tl_rows = tab.t_rows;
@@ -1267,11 +1126,7 @@ k_evaluate_split(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
 // workgroups per CU -- four waves per SIMD.  Same order as above with groups in the place of tiles: queue x holds the
 // groups of the instances x, x + 8, ... position-major, an instance's last group first.
 #ifndef FOT_GROUP_WAVES
-#ifdef FOT_TIER
-#define FOT_GROUP_WAVES 3                // (the tier build needs 144 vector registers: three waves per SIMD)
-#else
 #define FOT_GROUP_WAVES 4
-#endif
 #endif
 __global__ void __launch_bounds__(GROUP_TILES * WAVE) __attribute__((amdgpu_waves_per_eu(FOT_GROUP_WAVES, FOT_GROUP_WAVES)))
 k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
@@ -1593,126 +1448,6 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     if (inst >= n_inst) return;
     cull_group<T, CULL_KG>(Pp, desc, state, sp, s_spl + 9 * lds_knots, static_xy, dyn_xy, ent_cnt, ent32, ent64, ent_sid,
                            wave_rng, tile_cand0, tile_n, tile_span, nan_flag, ablate, inst, k0);
-}
-
-// ---------------------------------------------------------------------------
-// the whole plan call of a few egos in ONE launch
-// ---------------------------------------------------------------------------
-
-// A plan call of one or two egos is three short dependent kernels; what it waits for is mostly the launch machinery
-// between them (profiles/r03_latency_anatomy.json: of 68 us on the device clock, the work inside the kernels is about
-// 40).  k_evaluate_fused runs the three phases in one grid of FUSED_WG-thread workgroups that meet at two grid-wide
-// barriers: (A) nearest point + Frenet state of every instance, NaN scan of the tensors; (B) the entry lists, groups of
-// FUSED_KG time steps; (C) the tiles, each cut into FUSED_KG time segments as in k_evaluate_split, and the selection by
-// the wave that finishes an instance's last tile.  The phases are the very device functions of the three kernels.
-//
-// The barrier is a counter in HBM that only ever grows (launch n waits for base_n + G and base_n + 2 G): every wave
-// releases its writes at agent scope, one thread adds and polls with a BOUNDED number of sleeps, every wave then
-// acquires (vector and scalar caches).  The launcher keeps the grid small enough for all workgroups to be resident
-// together on an otherwise idle GPU; should they not be (other work holds the CUs), the poll runs out, the workgroup
-// sets *error and leaves -- every wave of the grid reaches the end of the kernel whatever happens -- and the host
-// plans that call again with the three kernels.
-constexpr int FUSED_KG = 4, FUSED_WG = FUSED_KG * WAVE;
-static_assert(FUSED_WG == FRENET_WG && FUSED_KG == SEG_MAX, "one workgroup shape for the three phases");
-constexpr int FUSED_POLLS = 40000;                                   // x (sleep + one L2 round trip): tens of milliseconds
-
-struct FusedArgs {
-    MetaImport imp; NanScan scan; int n_scan_blocks;
-    const void *static_xy, *dyn_xy;
-    int32_t *ent_cnt; d2 *ent64; uint8_t *ent_sid; const int32_t *tile_span; const uint8_t *nan_flag;
-    f2 *ent32_w; TileStep *rng_w; InstState *state_w;                // the buffers phase C reads, as phase A / B write them
-    SplineView sp_hbm; int lds_knots_ab; int do_cull;
-    int32_t *barrier; int32_t base; int32_t *error;
-};
-
-__device__ __forceinline__ bool grid_barrier(int32_t *counter, int32_t target, int32_t *error)
-{
-    __shared__ int s_pass;
-    // every wave's global stores have reached L2 (the vector cache writes through) ...
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < WAVE) {
-        // ... ONE wave then writes the L2's dirty lines back (agent-scope release), counts the workgroup in, polls, and
-        // drops the stale lines of the vector cache and of the L2 (agent-scope acquire): one write-back and one invalidate
-        // per workgroup, not per wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        int pass = 0;
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int poll = 0; poll < FUSED_POLLS; ++poll) {
-                if ((int32_t)(ld_agent(counter) - target) >= 0) { pass = 1; break; }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (!pass) st_agent(error, (int32_t)1);
-            s_pass = pass;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // (the scalar cache: what the next phase reads with s_load)
-    return s_pass != 0;
-}
-
-template <typename P>
-__device__ __forceinline__ const P *const_view(const P *p)
-{
-    asm volatile("" : "+s"(p) : : "memory");
-    const uint64_t v = (uint64_t)p;                               // (an asm result counts as divergent: make it uniform again)
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (const P *)(const __attribute__((address_space(4))) P *)(((uint64_t)hi << 32) | lo);
-}
-
-// (same leading arguments as the other evaluation kernels: FusedSink reads EvalKernArgs out of the argument segment;
-//  desc / state / wave_rng / ent32 are NOT declared no-alias here -- this kernel writes them)
-template <typename T>
-__global__ void __launch_bounds__(FUSED_WG)
-k_evaluate_fused(const DevParams *__restrict__ Pp, const InstDesc *desc, const InstState *state,
-                 const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n, const TileStep *wave_rng,
-                 const f2 *ent32, const EvalKernArgs a, const FusedArgs f)
-{
-    const int n_inst = a.n_inst, G = (int)gridDim.x, b = (int)blockIdx.x;
-    {
-        // ---- A: Frenet states and NaN scan
-        const SplineView sp = stage_spline(f.sp_hbm, f.lds_knots_ab);
-        for (int blk = b; blk < n_inst + f.n_scan_blocks; blk += G) {
-            if (blk != b) __syncthreads();
-            frenet_state_block(Pp, sp, desc, f.state_w, n_inst, f.imp, f.scan, a.inst_done, blk);
-        }
-        if (!grid_barrier(f.barrier, f.base + G, f.error)) return;
-        // ---- B: entry lists
-        if (f.do_cull) {
-            const int groups = (Pp->n_total + FUSED_KG - 1) / FUSED_KG;
-            for (int item = b; item < n_inst * groups; item += G) {
-                if (item != b) __syncthreads();
-                cull_group<T, FUSED_KG>(Pp, desc, state, sp, s_spl + 9 * f.lds_knots_ab, (const T *)f.static_xy,
-                                        (const T *)f.dyn_xy, f.ent_cnt, f.ent32_w, f.ent64, f.ent_sid, f.rng_w, tile_cand0,
-                                        tile_n, f.tile_span, f.nan_flag, 0, item / groups, (item % groups) * FUSED_KG);
-            }
-        }
-        if (!grid_barrier(f.barrier, f.base + 2 * G, f.error)) return;
-    }
-    // ---- C: tiles and selection.  What the phases above wrote is read-only from here on, and the compiler is told so:
-    // the pointers come out of an opaque statement BEHIND the barrier (no load through them can move above it) as
-    // pointers into constant memory -- uniform loads through them run on the scalar unit as in k_evaluate_split
-    // (the barrier has just invalidated the scalar cache).
-    desc = const_view(desc); state = const_view(state); wave_rng = const_view(wave_rng); ent32 = const_view(ent32);
-    const int wave_doubles = eval_wave_doubles(a.row_budget);
-    double *s_part = s_lon + wave_doubles;
-    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_part + (SEG_MAX - 1) * SEG_DOUBLES);
-    const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const int lane = threadIdx.x & (WAVE - 1);
-    for (int q = b; q < n_inst * a.max_tiles; q += G) {
-        if (q != b) __syncthreads();
-        const int pos = q / n_inst, inst = q - pos * n_inst;
-        const int n_tiles = desc[inst].n_tiles;
-        if (pos >= n_tiles) continue;
-        const int tile = n_tiles - 1 - pos;
-        TilePart tp = tile_part_empty();
-        evaluate_tile<TILE_SPLIT>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile, lane,
-                                  inst & (N_XCD - 1), tp, seg, FUSED_KG, s_part);
-        if (seg == 0) tile_done(inst, tile, lane, tp);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2104,46 +1839,6 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     } else {
         k_evaluate<<<(unsigned)n_blocks, wpw * WAVE, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     }
-    FOT_LAUNCH_CHECK();
-    return 0;
-}
-
-// The whole plan call in one launch (k_evaluate_fused).  max_wg: the largest grid the caller lets it take.
-int launch_plan_fused(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_total, int n_ext,
-                      int n_inst, MetaImport imp, NanScan scan, const void *static_xy, const void *dyn_xy, int dtype,
-                      bool do_cull, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
-                      int32_t *barrier, int32_t *barrier_base, int32_t *error, int max_wg, hipStream_t st)
-{
-    if (n_inst <= 0 || tiles.n_tiles <= 0) return (int)hipErrorInvalidValue;
-    const int groups = (n_total + FUSED_KG - 1) / FUSED_KG;
-    const int n_scan = scan.flag ? n_inst * scan.blocks_per_inst : 0;
-    int grid = n_inst * tiles.max_tiles;
-    if (do_cull && n_inst * groups > grid) grid = n_inst * groups;
-    if (n_inst + n_scan > grid) grid = n_inst + n_scan;
-    if (grid > max_wg) grid = max_wg;
-    EvalKernArgs a;
-    a.Pp = P; a.sp = sp; a.desc = desc; a.state = state;
-    a.row_budget = tiles.row_budget; a.lds_knots = sp.n <= 28 ? sp.n : 0; a.ablate = 0;
-    a.n_inst = n_inst; a.max_tiles = tiles.max_tiles;
-    a.tile_cand0 = tiles.cand0; a.tile_n = tiles.n;
-    a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
-    a.cand_cost = c.cost; a.cand_status = c.status; a.cand_keep = c.keep; a.parts = c.parts;
-    a.out = out; a.inst_done = inst_done; a.done_flag = c.done_flag; a.done_seq = c.done_seq;
-    FusedArgs f;
-    f.imp = imp; f.scan = scan; f.n_scan_blocks = n_scan;
-    f.static_xy = static_xy; f.dyn_xy = dyn_xy;
-    f.ent_cnt = e.cnt; f.ent64 = e.e64; f.ent_sid = e.sid; f.tile_span = tiles.span; f.nan_flag = e.nan_flag;
-    f.ent32_w = e.e32; f.rng_w = e.rng; f.state_w = state;
-    f.sp_hbm = sp; f.lds_knots_ab = sp.n <= 64 ? sp.n : 0; f.do_cull = do_cull ? 1 : 0;
-    f.barrier = barrier; f.base = *barrier_base; f.error = error;
-    *barrier_base += 2 * grid;                                     // (wraps with the counter: compared as a difference)
-    const size_t lds_ab = 9 * (size_t)f.lds_knots_ab + (size_t)n_ext * (FUSED_KG * 2 + 9);
-    const size_t lds_c = (size_t)eval_wave_doubles(tiles.row_budget) + (size_t)(SEG_MAX - 1) * SEG_DOUBLES + 9 * (size_t)a.lds_knots;
-    const size_t lds = sizeof(double) * (lds_ab > lds_c ? lds_ab : lds_c);
-    if (dtype == FOT_F32)
-        k_evaluate_fused<float><<<(unsigned)grid, FUSED_WG, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a, f);
-    else
-        k_evaluate_fused<double><<<(unsigned)grid, FUSED_WG, lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a, f);
     FOT_LAUNCH_CHECK();
     return 0;
 }

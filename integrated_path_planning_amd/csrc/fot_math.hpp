@@ -908,180 +908,6 @@ FOT_HD bool wave_any(bool b)
 #endif
 }
 
-// One float64 time step of one candidate (what evaluate_segment does per step, the collision point aside); the row and
-// the predecessor sample are rebuilt here rather than carried through the float32 steps.  Returns false when the sample
-// ended the kept prefix (NaN position); else the point in the instance-local float32 frame + heading.
-template <class Tab>
-FOT_HD bool tier_step_f64(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab, const double *q,
-                          int k, double d, double ox, double oy, SegState &g, Tier32 &t, float &fx, float &fy,
-                          float &fct, float &fst)
-{
-    const LoopConst C = loop_const(P, D);                         // (read where it is needed: the rare path)
-    LonSample ls;
-    lon_tab.load(k, ls);
-    double u0, d_d, d_dd, d_ddd;
-    lat_sample(q, k, L.n_eval, C.dt, u0, d_d, d_dd, d_ddd);
-    CartSample c;
-    frenet_to_cart(ls, d, d_d, d_dd, c);
-    if (isnan(c.x)) { g.acc.fl |= CK_SEEN_NAN; g.first_nan = k; return false; }
-    // a local accumulator: the predecessor sample is rebuilt here, never carried across steps (sixteen registers that
-    // would otherwise live through the float32 steps)
-    CheckAcc a;
-    check_init(a);
-    a.fl = g.acc.fl;
-    if (k > 0) {                                                  // (it exists and was no NaN sample)
-        LonSample lp;
-        lon_tab.load(k - 1, lp);
-        double pd, pd_d, pd_dd, pd_ddd;
-        lat_sample(q, k - 1, L.n_eval, C.dt, pd, pd_d, pd_dd, pd_ddd);
-        CartSample pc;
-        frenet_to_cart(lp, pd, pd_d, pd_dd, pc);
-        a.prev.x = pc.x; a.prev.y = pc.y; a.prev.cos_t = pc.cos_t; a.prev.sin_t = pc.sin_t;
-        a.prev.kappa = pc.kappa; a.prev.v = pc.v; a.prev.a = pc.a; a.prev.d = pd;
-    }
-    PathSample ps;
-    ps.x = c.x; ps.y = c.y; ps.cos_t = c.cos_t; ps.sin_t = c.sin_t; ps.kappa = c.kappa;
-    ps.v = c.v; ps.a = c.a; ps.d = d;
-    check_sample(C, a, k, ps, true, true, [&] { return fabs(lon_tab.s_at(k) - lon_tab.s_at(k - 1)); });
-    g.acc.fl = a.fl;
-    if (k > 0) {                                                  // this step's squared length, both accumulators
-        if (a.max_step2 > g.acc.max_step2) g.acc.max_step2 = a.max_step2;
-        const float s2 = (float)a.max_step2;
-        t.max_step2 = s2 > t.max_step2 ? s2 : t.max_step2;
-    }
-    fx = (float)(c.x - ox); fy = (float)(c.y - oy); fct = (float)c.cos_t; fst = (float)c.sin_t;
-    g.v_last = c.v;
-    return true;
-}
-
-// The whole walk of one candidate, time steps [0, n_loop): a first pass through the tier and, when a candidate of the
-// wave ends inside the step-limit band, a second pass with every step in float64.  ox, oy: origin of the
-// instance-local frame (the ego position, as in the entry lists).  Sink::put32(k, circle, fx, fy, alive, get_exact):
-// the collision point in that frame; get_exact(px, py) rebuilds its float64 coordinates for the lanes that need them.
-template <class Tab, class Sink>
-FOT_HD void tier_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &lon_tab,
-                      const double *q, int n_loop, Sink &sink, SegState &g)
-{
-    const int n_t = L.n_t;
-    CheckAcc &acc = g.acc;
-    // (origin of the instance-local float32 frame, in the frame the table's rows are in)
-    const double ox = Tab::LOCAL ? 0.0 : D.ego.x, oy = Tab::LOCAL ? 0.0 : D.ego.y, dt64 = P.dt, road_lim = P.road_lim;
-    const float lim_speed = (float)D.lim_speed, lim_accel = (float)D.lim_accel, lim_curv = (float)D.lim_curv,
-                lim_lat = (float)D.lim_lat;
-    const int n_circ_fp = P.has_footprint ? P.n_circ : 0;
-    bool force64 = false;
-    for (int pass = 0; pass < 2; ++pass) {
-        Tier32 t;
-        tier_init(t, q, (double)(L.n_eval - 1) * dt64, dt64);
-        bool any32 = false;
-        for (int k = 0; k < n_loop; ++k) {
-          // the row, rounded to float32 at once (the float64 step and the exact collision point read it again)
-          float r_sd, r_sdd, r_rx, r_ry, r_cos, r_sin, r_kr, r_dkr, r_inv;
-          double kr64;
-          {
-              LonSample ls;
-              lon_tab.load(k, ls);
-              r_sd = (float)ls.sd; r_sdd = (float)ls.sdd; r_rx = (float)(ls.rx - ox); r_ry = (float)(ls.ry - oy);
-              r_cos = (float)ls.cos_r; r_sin = (float)ls.sin_r; r_kr = (float)ls.kr; r_dkr = (float)ls.dkr;
-              r_inv = (float)ls.inv_sd; kr64 = ls.kr;
-          }
-          sink.row_begin(k);
-          if (k < n_t) {
-            const double d = lat_offset(q, k, L.n_eval, dt64);
-            g.d_last = d;
-            const double omkd64 = 1.0 - kr64 * d;
-            check_flag(acc, isfinite(omkd64) && omkd64 <= 0.05, CK_SINGULAR);   // SINGULARITY_EPS, any sample, float64
-            if (!(acc.fl & CK_SEEN_NAN)) {
-                bool need64 = force64;
-                float fx = 0.0f, fy = 0.0f, fct = 1.0f, fst = 0.0f, step2 = 0.0f, v32 = 0.0f;
-                uint32_t fl32 = 0;
-                if (!force64) {
-                    const float tt = (float)k * t.dt;
-                    float d_d = 0.0f, d_dd = 0.0f, e1 = 0.0f, e2 = 0.0f;
-                    if (k < L.n_eval) tier_poly(t, tt, d_d, d_dd, e1, e2);       // (brake padding: d' = d'' = 0 exactly)
-                    Cart32 c;
-                    frenet_to_cart_f32(r_sd, r_sdd, r_rx, r_ry, r_cos, r_sin, r_kr, r_dkr, r_inv, (float)d, (float)omkd64,
-                                       d_d, d_dd, e1, e2, c);
-                    // what float32 cannot certify (a NaN makes every comparison below "unsure")
-                    bool unsure = !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)) || isnan(c.x) || isnan(c.y);
-                    if (k > 0) {
-                        const float sx = c.x - t.px, sy = c.y - t.py;
-                        step2 = sx * sx + sy * sy;
-                        unsure |= isnan(step2);
-                        unsure |= tier_unsure(c.v, lim_speed, c.e_v);
-                        unsure |= tier_unsure(fabsf(c.a), lim_accel, c.e_a);
-                        unsure |= !(c.v - c.e_v > 0.5f * (1.0f + TIER_U));      // at or under the low-speed gate: float64 rules
-                        unsure |= tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
-                        unsure |= tier_unsure(c.lat, lim_lat, c.e_lat);
-                        fl32 |= c.v > lim_speed ? CK_SPEED : 0u;
-                        fl32 |= fabsf(c.a) > lim_accel ? CK_ACCEL : 0u;
-                        fl32 |= fabsf(c.kappa) > lim_curv ? CK_CURV : 0u;
-                        fl32 |= c.lat > lim_lat ? CK_LAT : 0u;
-                        fl32 |= fabs(d) > road_lim ? CK_ROAD : 0u;               // (float64: exact)
-                    }
-                    need64 = wave_any(unsure);
-                    fx = c.x; fy = c.y; fct = c.cos_t; fst = c.sin_t; v32 = c.v;
-                }
-                bool counted = true;
-                if (need64) {
-                    counted = tier_step_f64(P, D, L, lon_tab, q, k, d, ox, oy, g, t, fx, fy, fct, fst);
-                } else {
-                    any32 = true;
-                    acc.fl |= fl32;
-                    if (k > 0) t.max_step2 = step2 > t.max_step2 ? step2 : t.max_step2;
-                    g.v_last = (double)v32;
-                }
-                if (counted) {
-                    t.px = fx; t.py = fy;
-                    g.k_last = k;
-                    const bool alive = (acc.fl & CK_FAILED) == 0;
-                    // collision points: float32, instance-local; the exact point only where float32 cannot settle an entry
-                    const int n_circ = n_circ_fp > 0 ? n_circ_fp : 1;
-                    for (int ci = 0; ci < n_circ; ++ci) {
-                        const float off = n_circ_fp > 0 ? (float)P.circ_off[ci] : 0.0f;
-                        sink.put32(k, ci, fx + off * fct, fy + off * fst, alive, [&](double &px, double &py) {
-                            LonSample ls;
-                            lon_tab.load(k, ls);
-                            double u0, e_d, e_dd, e_ddd;
-                            lat_sample(q, k, L.n_eval, dt64, u0, e_d, e_dd, e_ddd);
-                            CartSample ce;
-                            frenet_to_cart(ls, d, e_d, e_dd, ce);
-                            const double o64 = n_circ_fp > 0 ? P.circ_off[ci] : 0.0;
-                            px = ce.x + o64 * ce.cos_t; py = ce.y + o64 * ce.sin_t;
-                        });
-                    }
-                }
-            }
-          }
-          sink.row_end(k);
-        }
-        // --- what the float32 steps left approximate
-        bool rewalk = false;
-        if (any32) {
-            if (!(acc.fl & CK_NANSTEP) && g.k_last >= 1) {
-                // the largest step against the step limit (frenet_planner.py:953-956): certain, or walk again
-                const float lim2 = (float)(D.step_limit * D.step_limit);
-                if (t.max_step2 > lim2 * 1.002f) acc.max_step2 = INFINITY;
-                else if (t.max_step2 < lim2 * 0.998f) acc.max_step2 = 0.0;
-                else rewalk = true;
-            }
-            if (!isnan(D.max_stop) && g.k_last >= 0) {            // the stop filter compares the LAST speed: float64
-                LonSample ls;
-                lon_tab.load(g.k_last, ls);
-                double dd, d_d, d_dd, d_ddd;
-                lat_sample(q, g.k_last, L.n_eval, dt64, dd, d_d, d_dd, d_ddd);
-                CartSample c;
-                frenet_to_cart(ls, dd, d_d, d_dd, c);
-                g.v_last = c.v;
-            }
-        }
-        if (!wave_any(rewalk)) break;
-        seg_init(g);                                              // once more, every step in float64
-        sink.restart();
-        force64 = true;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Tier, second form (-DFOT_TIER2; like the first a NEGATIVE result: exact -- the CPU logic test compares every candidate
 // it certifies with the float64 walk, bit for bit -- but 0.46 ms against 0.23 ms on the GPU as built: two walks in one

@@ -156,6 +156,7 @@ class BatchPlanner:
         h = C.c_void_p()
         _abi.check(None, self._lib.fot_create(C.byref(self.params), int(device), C.byref(h)))
         self._h = h
+        _abi.register_owner(self)                # closed by _abi's atexit hook if the caller never does
         if reference_path is not None:
             self.set_path(reference_path)
         elif waypoints is not None:
@@ -163,20 +164,29 @@ class BatchPlanner:
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.fot_destroy(self._h)
-            self._h = None
+        """Release the handle (idempotent).  ``fot_destroy`` polls the handle's streams for a bounded time and never
+        blocks on a caller's stream; planners nobody closed are closed by ``_abi``'s atexit hook, which runs before
+        the interpreter starts tearing modules down."""
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _abi.unregister_owner(self)
+            self._lib.fot_destroy(h)
 
     def __del__(self):
-        # At interpreter shutdown the HIP runtime (and PyTorch's context in the same process) may already be tearing
-        # itself down: a fot_destroy then -- stream synchronisation, frees -- can block for good.  The process is about to
-        # return everything to the OS anyway.
+        # Collected while the program runs: close.  During interpreter finalisation the atexit hook has already closed
+        # every planner that was still registered (``_h`` is None then), so nothing calls into HIP from here.
         if sys.is_finalizing():
             return
         try:
             self.close()
         except Exception:
             pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # -- reference path ---------------------------------------------------
     def set_path(self, path):
@@ -422,8 +432,9 @@ class BatchPlanner:
         n = _abi.PROFILE_KERNELS
         launches = np.zeros(n, np.int32)
         ms = np.zeros(n)
-        _abi.check(self._h, self._lib.fot_profile_read(self._h, 1 if reset else 0, launches.ctypes.data_as(_ip),
-                                                       _as_dp(ms)))
+        rc = self._lib.fot_profile_read(self._h, 1 if reset else 0, n, launches.ctypes.data_as(_ip), _as_dp(ms))
+        if rc < 0:
+            _abi.check(self._h, rc)
         return {self._lib.fot_profile_kernel_name(k).decode(): {"launches": int(launches[k]), "total_ms": float(ms[k])}
                 for k in range(n)}
 
@@ -459,18 +470,6 @@ class BatchPlanner:
         (k_evaluate_group, four tiles per row table)."""
         cut = {"auto": 0, "wave": 1, "group": 2}.get(cut, cut)
         _abi.check(self._h, self._lib.fot_debug_set_tile_cut(self._h, int(cut)))
-
-    def set_fused(self, mode) -> None:
-        """Test hook (``fot_debug_set_fused``): 0 / "off" (default), 1 / "small" (synchronous calls of one or two egos
-        run as one launch), 2 / "force" (every synchronous call whose grid fits)."""
-        mode = {"off": 0, "small": 1, "force": 2}.get(mode, mode)
-        _abi.check(self._h, self._lib.fot_debug_set_fused(self._h, int(mode)))
-
-    def fused_counts(self):
-        """(one-launch plan calls so far, how many of them were repeated with the three kernels)."""
-        a, b = C.c_int64(0), C.c_int64(0)
-        _abi.check(self._h, self._lib.fot_debug_fused_counts(self._h, C.byref(a), C.byref(b)))
-        return int(a.value), int(b.value)
 
     def time_info(self, time: float):
         """(n_t, quartic inverse [2, 2], quintic inverse [3, 3]) the library solves a horizon of ``time`` seconds with

@@ -1,6 +1,6 @@
 """Device-side anatomy of the one-ego plan call from a rocprofv3 kernel trace of scripts/latency_loop.py: per call the
 duration of the three kernels and the idle gaps between them (end of one kernel to start of the next on the device
-clock) -- the time a single-launch pipeline could win at most.
+clock).
    latency_gaps.py <dir with run_kernel_trace.csv>"""
 import csv
 import glob
@@ -17,8 +17,7 @@ with open(f) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"])))
 rows.sort()
-short = lambda n: ("frenet" if "k_frenet_state" in n else "cull" if "k_cull" in n else "fused" if "k_evaluate_fused" in n
-                   else "evaluate" if "k_evaluate" in n else None)
+short = lambda n: ("frenet" if "k_frenet_state" in n else "cull" if "k_cull" in n else "evaluate" if "k_evaluate" in n else None)
 seq = [(s, e, short(n), g) for s, e, n, g in rows if short(n)]
 calls = []
 i = 0
@@ -40,9 +39,4 @@ for name, sel in (("config2", calls[: len(calls) // 2]), ("config3", calls[len(c
     out[name] = {"calls": int(len(sel)), "k_frenet_state_us": med[0], "gap_1_us": med[1], "k_cull_us": med[2],
                  "gap_2_us": med[3], "k_evaluate_us": med[4], "first_start_to_last_end_us": med[5],
                  "kernels_sum_us": med[0] + med[2] + med[4]}
-fused = np.array([(e - s_) / 1e3 for s_, e, n, g in seq if n == "fused"])
-if len(fused) > 100:
-    for name, sel in (("config2", fused[: len(fused) // 2]), ("config3", fused[len(fused) // 2:])):
-        out[name + "_k_evaluate_fused_us"] = {"calls": int(len(sel) - 30), "median": float(np.median(sel[30:])),
-                                              "p5": float(np.percentile(sel[30:], 5)), "p95": float(np.percentile(sel[30:], 95))}
 print(json.dumps(out, indent=1))

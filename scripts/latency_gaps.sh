@@ -6,9 +6,5 @@ export TMPDIR=/tmp
 OUT=gpurun_out/lat_trace
 rm -rf "$OUT"; mkdir -p "$OUT"
 timeout -k 10 200 python3 scripts/latency_loop.py 1200 2>/dev/null | tee "$OUT/bare.txt"
-FOT_FUSED=1 timeout -k 10 200 python3 scripts/latency_loop.py 1200 2>/dev/null | sed 's/^/one launch (k_evaluate_fused): /' | tee -a "$OUT/bare.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o run -- python3 scripts/latency_loop.py 400 > "$OUT/traced.txt" 2>&1
 python3 scripts/latency_gaps.py "$OUT/trace" | tee "$OUT/gaps.json"
-export FOT_FUSED=1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_fused" -o run -- python3 scripts/latency_loop.py 400 > "$OUT/traced_fused.txt" 2>&1
-python3 scripts/latency_gaps.py "$OUT/trace_fused" | tee "$OUT/gaps_fused.json"

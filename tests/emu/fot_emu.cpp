@@ -296,20 +296,7 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     }
                 }
             }
-            {   // the float32 tier of the throughput kernels (tier_walk): the same record of the candidate, and its error
-                // bounds hold sample by sample against the float64 transform
-                EntryCollider et;
-                et.init(P, D);
-                et.rng = ec.rng; et.e32 = ec.e32; et.e64 = ec.e64; et.sid = ec.sid; et.thr_k = ec.thr_k; et.thr_sure_k = ec.thr_sure_k;
-                SegState gt;
-                seg_init(gt);
-                tier_walk(P, D, Li, GlobalTab{ tab }, q, P.n_total, et, gt);
-                CandResult rt;
-                finish_candidate(P, D, Li, GlobalTab{ tab }, q, gt, et.collided(), rt);
-                if (rt.status != r.status || rt.keep != r.keep) return -120;
-                if (std::memcmp(&rt.cost, &r.cost, sizeof(double)) != 0) return -121;
-                if (final_status(rt.status, rt.v_last, rt.travel, D.max_stop) != final_status(r.status, r.v_last, r.travel, D.max_stop))
-                    return -122;
+            {   // the float32 transform of the certifying kernel: its error bounds hold sample by sample against the float64 one
                 Tier32 tt;
                 tier_init(tt, q, (double)(Li.n_eval - 1) * P.dt, P.dt);
                 for (int k = 0; k < r.keep; ++k) {

@@ -17,18 +17,14 @@ def request_from_golden(g) -> PlanRequest:
 
 
 
-# The evaluation kernels a plan call can take (csrc/fot_kernels.hip launch_evaluate / launch_plan_fused).  Every parity
-# test that asserts a per-candidate table runs under each of them: "auto" is what a caller gets (k_evaluate_split for a
-# handful of egos, k_evaluate_group for batches); "fused" forces the one-launch pipeline k_evaluate_fused (an experiment
-# that is off by default) for every synchronous call whose grid fits; "group" / "wave" walk every candidate in one piece
-# under the grouped / per-wave cut (k_evaluate_group / k_evaluate); "split-wave" cuts the per-wave tiles into time
-# segments.
-EVAL_PATHS = ("auto", "fused", "group", "wave", "split-wave")
+# The evaluation kernels a plan call can take (csrc/fot_kernels.hip launch_evaluate).  Every parity test that asserts a
+# per-candidate table runs under each of them: "auto" is what a caller gets (k_evaluate_split for a handful of egos,
+# k_evaluate_group for batches); "group" / "wave" walk every candidate in one piece under the grouped / per-wave cut
+# (k_evaluate_group / k_evaluate); "split-wave" cuts the per-wave tiles into time segments.
+EVAL_PATHS = ("auto", "group", "wave", "split-wave")
 
 
 def set_eval_path(bp, path):
-    cut, seg, fused = {"auto": (0, 0, 0), "fused": (0, 0, 2), "group": (2, 1, 0), "wave": (1, 1, 0),
-                       "split-wave": (1, 4, 0)}[path]
+    cut, seg = {"auto": (0, 0), "group": (2, 1), "wave": (1, 1), "split-wave": (1, 4)}[path]
     bp.set_tile_cut(cut)
     bp.set_eval_segments(seg)
-    bp.set_fused(fused)

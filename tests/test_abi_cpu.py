@@ -157,3 +157,82 @@ def test_header_constants_match_the_python_mirror():
     defs = {k: int(v) for k, v in re.findall(r"#define (FOT_[A-Z_]+) (\d+)\b", text)}
     assert defs["FOT_PROFILE_KERNELS"] == _abi.PROFILE_KERNELS
     assert defs["FOT_MAX_NT"] == _abi.MAX_NT
+
+
+def test_abi_info_matches_the_binding_and_the_header():
+    """fot_abi_info: what the library was built with == the ctypes mirror == include/fot.h."""
+    lib = _abi.lib()
+    want = _abi.abi_expectation()
+    got = (C.c_int32 * 64)()
+    n = lib.fot_abi_info(64, got)
+    text = open(HEADER).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define (FOT_[A-Z_]+) (\d+)\b", text)}
+    assert n == defs["FOT_ABI_INFO_WORDS"] == len(want) == len(_abi.ABI_WORD_NAMES)
+    assert list(got[:n]) == want
+    assert got[0] == defs["FOT_ABI_VERSION"] == _abi.ABI_VERSION
+    for name, value in (("FOT_MAX_NT", _abi.MAX_NT), ("FOT_MAX_CIRCLES", _abi.MAX_CIRCLES), ("FOT_MAX_TI", _abi.MAX_TI),
+                        ("FOT_MAX_TV", _abi.MAX_TV), ("FOT_MAX_BRAKE", _abi.MAX_BRAKE), ("FOT_MAX_SAMPLES", _abi.MAX_SAMPLES),
+                        ("FOT_MAX_PRED_LEN", _abi.MAX_PRED_LEN), ("FOT_PROFILE_KERNELS", _abi.PROFILE_KERNELS),
+                        ("FOT_MARGIN_GROUPS", _abi.MARGIN_GROUPS)):
+        assert defs[name] == value == got[_abi.ABI_WORD_NAMES.index(name)], name
+    assert lib.fot_abi_info(3, got) == n                          # a short array is not written past its end
+    assert lib.fot_abi_info(0, None) == n
+
+
+def test_a_library_with_other_layouts_is_refused(tmp_path):
+    """Round 3's abort (gpurun_out/ab_r3_select.log: `double free or corruption (out)` at bench.py's exit) was an OLDER
+    libfot.so -- FOT_PROFILE_KERNELS 4 -- under a binding that allocated three slots: fot_profile_read wrote past both
+    arrays.  The loader now compares fot_abi_info() with the ctypes mirror and refuses; a library without the symbol is
+    refused as well."""
+    want = _abi.abi_expectation()
+    for idx, delta, frag in ((_abi.ABI_WORD_NAMES.index("FOT_PROFILE_KERNELS"), 1, "FOT_PROFILE_KERNELS"),
+                             (_abi.ABI_WORD_NAMES.index("sizeof(fot_result)"), -7680, "sizeof(fot_result)"),
+                             (0, -1, "FOT_ABI_VERSION")):
+        vals = list(want)
+        vals[idx] += delta
+        src = tmp_path / f"fake{idx}.c"
+        src.write_text("#include <stdint.h>\nint32_t fot_abi_info(int32_t cap, int32_t *out) { static const int32_t v[] = {"
+                       + ",".join(map(str, vals)) + "}; for (int i = 0; i < %d && i < cap && out; ++i) out[i] = v[i]; return %d; }\n"
+                       % (len(vals), len(vals)))
+        so = tmp_path / f"fake{idx}.so"
+        subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+        with pytest.raises(ImportError, match=re.escape(frag)):
+            _abi._check_abi(C.CDLL(str(so)), str(so))
+    src = tmp_path / "old.c"
+    src.write_text("int fot_create(void) { return 0; }\n")
+    so = tmp_path / "old.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    with pytest.raises(ImportError, match="predates fot_abi_info"):
+        _abi._check_abi(C.CDLL(str(so)), str(so))
+
+
+def test_destroy_ignores_what_create_did_not_return():
+    """fot_destroy is idempotent and never reads a pointer it does not own."""
+    lib = _abi.lib()
+    n0 = lib.fot_live_handles()
+    junk = (C.c_char * 4096)()
+    lib.fot_destroy(C.c_void_p(C.addressof(junk)))                 # not a handle: ignored
+    lib.fot_destroy(None)
+    assert lib.fot_live_handles() == n0
+
+
+def test_exit_hook_closes_registered_owners():
+    """_abi.close_all (the atexit hook) closes every owner that is still registered, once."""
+    closed = []
+
+    class Owner:
+        def close(self):
+            closed.append(self)
+            _abi.unregister_owner(self)
+
+    a, b = Owner(), Owner()
+    _abi.register_owner(a)
+    _abi.register_owner(b)
+    b.close()
+    _abi.close_all()
+    assert closed.count(a) == 1 and closed.count(b) == 1
+    _abi.close_all()
+    assert len(closed) == 2
+    import atexit
+    atexit.unregister(_abi.close_all)                               # (registered exactly once, at import)
+    atexit.register(_abi.close_all)

@@ -125,26 +125,6 @@ def test_loop_argument_checks():
     bp.close()
 
 
-def test_one_launch_pipeline_gives_up_and_the_call_is_repeated():
-    """The grid barrier of k_evaluate_fused polls a bounded number of times: with a barrier target nobody can reach
-    (fot_debug_set_fused mode 3) every workgroup reports and leaves -- the kernel ENDS --, the library plans the call
-    again with the three kernels, and the caller sees the same records as ever; the next one-launch call works again."""
-    import integrated_path_planning_amd.synthetic as syn
-    from integrated_path_planning_amd.batch import PackedBatch, request_from_instance
-    bp = BatchPlanner(waypoints=(syn.STRAIGHT_WX, syn.STRAIGHT_WY), **syn.CONFIG3_PLANNER)
-    pb = PackedBatch([request_from_instance(syn.config3_instance(s)) for s in (3, 4)], np.float32)
-    want = bytes(bp.plan_packed(pb).records)
-    assert bp.fused_counts() == (0, 0)
-    bp.set_fused(3)
-    got = bytes(bp.plan_packed(pb).records)
-    assert bp.fused_counts() == (1, 1)
-    assert got == want
-    got = bytes(bp.plan_packed(pb).records)                        # mode 2 from here on: one launch, no repetition
-    assert bp.fused_counts() == (2, 1)
-    assert got == want
-    bp.close()
-
-
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FOT_LOOP_FUZZ_SEEDS", "12"))))
 def test_loop_calls_equal_the_separate_calls_on_random_frames(seed):
     """Random frames: 1 - 9 episodes with 0 - 12 pedestrians each, random prepend flags, staleness and footprint use,
