@@ -52,6 +52,21 @@ FOT_HD double fast_rsqrt(double a)
 
 FOT_HD double sum_sq_unfused(double a, double b);
 
+// a * b + c as ONE rounding on the device (v_fma_f64), spelled out where two kernels must produce the same bits from
+// the same expression whatever the compiler's contraction heuristics make of the code around it; two roundings on the
+// host (the CPU logic test compares with tolerances, and builds with -ffp-contract=off)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FOT_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define FOT_FMA(a, b, c) ((a) * (b) + (c))
+#endif
+
+// the lateral quintic's value: q0 + t (q1 + t (q2 + t (q3 + t (q4 + t q5)))) (:688)
+FOT_HD double quintic_value(const double *q, double t)
+{
+    return FOT_FMA(t, FOT_FMA(t, FOT_FMA(t, FOT_FMA(t, FOT_FMA(t, q[5], q[4]), q[3]), q[2]), q[1]), q[0]);
+}
+
 // ---------------------------------------------------------------------------
 // cubic spline (reference: src/planning/cubic_spline.py:47-166, 215-288)
 // ---------------------------------------------------------------------------
@@ -290,7 +305,7 @@ FOT_HD void lon_eval(const LonInfo &L, double t, double &s, double &sd, double &
 FOT_HD void lat_eval(const double *q, double t, double &d, double &dd, double &ddd, double &dddd)
 {
     // Horner form of the quintic and its three derivatives (:688-691)
-    d = q[0] + t * (q[1] + t * (q[2] + t * (q[3] + t * (q[4] + t * q[5]))));
+    d = quintic_value(q, t);
     dd = q[1] + t * (2.0 * q[2] + t * (3.0 * q[3] + t * (4.0 * q[4] + t * (5.0 * q[5]))));
     ddd = 2.0 * q[2] + t * (6.0 * q[3] + t * (12.0 * q[4] + t * (20.0 * q[5])));
     dddd = 6.0 * q[3] + t * (24.0 * q[4] + t * (60.0 * q[5]));
@@ -744,20 +759,18 @@ FOT_HD void evaluate_segment(const DevParams &P, const LoopConst &C, const LonIn
 }
 
 // ---------------------------------------------------------------------------
-// The float32 tier of the candidate walk (throughput kernels).
+// The float32 certifying walk (k_evaluate_certify, the first of the two evaluation kernels of a large batch).
 //
-// Every decision of the reference is a comparison of a float64 quantity with a threshold.  A time step is first
-// evaluated in float32 together with a first-order bound of the float32 error of every compared quantity (inputs
-// rounded to float32: 2^-24 relative each; d', d'' of the quintic: an absolute bound from the candidate's coefficient
-// magnitudes; every operation 2^-24 relative; the bounds carry a factor of four on top).  A comparison whose float32
-// value lies further from its threshold than its bound has the same outcome in float64 -- it is CERTIFIED.  A step in
-// which any candidate of the wave has an uncertified comparison (or a non-finite value, or falls under the low-speed
-// rules) is evaluated again with the float64 code, which then decides; nothing float32 ever decides a status on its
-// own.  What stays float64 throughout: the lateral offset d (road-bound test: the outermost lateral target converges to
-// the bound itself), 1 - kappa_r d (singularity test), the cost.  Positions go to the collision broad phase as float32
-// (instance-local frame; its thresholds carry the position error, filter_threshold) and are rebuilt in float64 only for
-// the entries float32 cannot settle.  The largest step length is compared at the end, in float32, against the step limit
-// +- 0.1 %: inside that band the whole candidate is walked again in float64 (tier_walk returns true).
+// Every decision of the reference is a comparison of a float64 quantity with a threshold.  The certifying walk
+// evaluates a candidate's samples in float32 together with a first-order bound of the float32 error of every compared
+// quantity (inputs rounded to float32: 2^-24 relative each; d', d'' of the quintic: an absolute bound per step from the
+// coefficients' magnitudes; every operation 2^-24 relative; the unit carries a factor of two on top).  A comparison
+// whose float32 value lies further from its threshold than its bound has the same outcome in float64: it is CERTIFIED.
+// A candidate all of whose comparisons are certified gets its status, kept length and (float64, closed-form) cost from
+// this walk; a candidate with ONE uncertified comparison is given up on, and its tile is walked by the float64 kernel
+// afterwards (k_evaluate_rest).  Nothing float32 ever decides a status that float64 could decide differently.  What
+// stays float64 here: the lateral offset d (road-bound test -- the outermost lateral target converges to the bound
+// itself --, final offset of the cost) and the cost.
 // ---------------------------------------------------------------------------
 
 FOT_HD float rcp_f32(float a)
@@ -884,8 +897,7 @@ FOT_HD void frenet_to_cart_f32(float sd, float sdd, float rx, float ry, float co
 // lateral offset alone, float64 (the rest of the lateral state goes through Tier32)
 FOT_HD double lat_offset(const double *q, int k, int n_eval, double dt)
 {
-    const double t = (double)(k < n_eval ? k : n_eval - 1) * dt;
-    return q[0] + t * (q[1] + t * (q[2] + t * (q[3] + t * (q[4] + t * q[5]))));
+    return quintic_value(q, (double)(k < n_eval ? k : n_eval - 1) * dt);
 }
 
 // |value - threshold| within the error bound (or not a number): the float32 comparison proves nothing
@@ -909,24 +921,29 @@ FOT_HD bool wave_any(bool b)
 }
 
 // ---------------------------------------------------------------------------
-// Tier, second form (-DFOT_TIER2; like the first a NEGATIVE result: exact -- the CPU logic test compares every candidate
-// it certifies with the float64 walk, bit for bit -- but 0.46 ms against 0.23 ms on the GPU as built: two walks in one
-// kernel cost 99 lane-spilled scalar registers).  ONE float32 walk of the whole candidate that
-// either certifies every decision or gives up -- then the tile is walked again by the float64 code
-// (evaluate_segment), untouched.  The two walks are two
-// loops, one after the other, so the float64 state costs the float32 loop no registers.  What the float32 walk keeps in
-// float64: the lateral offset d (road test, final offset, the low-speed slip rule together with the arc length from the
-// profile's polynomial) and the collision point of the entries float32 cannot settle (reference point + d * normal from
-// the float64 half of the row).  Tab: load32(k, Row32), load_exact(k, rx, ry, cos_r, sin_r), s_at(k).
-// Not for footprint circles or a stop-distance directive (their consumers need float64 headings / final speed): the
-// caller walks those in float64 from the start.
+// certify_walk: ONE float32 walk of a whole candidate that certifies every decision made on it, or gives up.
+//   Tab::load32(k, Row32&)   row k of the candidate's longitudinal profile, rounded to float32 from the float64 row
+//                            (reference point in the instance-local frame), plus ds = s(t_k) - s(t_k-1) formed in
+//                            float64 and rounded (the low-speed slip rule compares against it)
+//   Sink::row_begin / row_end as in evaluate_segment; Sink::test32(k, fx, fy, alive): the collision point (instance-
+//                            local float32) against the entry lists -- the sink keeps `hit` (some entry CERTAINLY within
+//                            its radius) and `near` (some entry neither certainly inside nor certainly outside)
+// Not for footprint circles, a stop-distance directive or a chance budget (their consumers need float64 headings, the
+// final speed, per-sample hit masks): the caller hands such instances to the float64 kernel from the start.
 // ---------------------------------------------------------------------------
 
-struct Row32 { float sd, sdd, rx, ry, cos_r, sin_r, kr, dkr, inv_sd; };
+struct Row32 { float sd, sdd, rx, ry, cos_r, sin_r, kr, dkr, inv_sd, ds; };
+
+struct CertifyOut {
+    uint32_t fl;                         // CK_* bits, every one of them certified
+    int first_nan, k_last;
+    bool step_over;                      // the largest step certainly exceeds the step limit (frenet_planner.py:953-956)
+    bool unsure;                         // some decision (collision aside) could not be certified: give up
+};
 
 template <class Tab, class Sink>
-FOT_HD bool tier2_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &tab, const double *q,
-                       int n_loop, Sink &sink, SegState &g)
+FOT_HD void certify_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &tab, const double *q,
+                         int n_loop, Sink &sink, CertifyOut &o)
 {
     const int n_t = L.n_t, n_eval = L.n_eval;
     const double dt64 = P.dt, road_lim = P.road_lim;
@@ -945,7 +962,6 @@ FOT_HD bool tier2_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, 
         sink.row_begin(k);
         if (k < n_t) {
             const double d = lat_offset(q, k, n_eval, dt64);
-            g.d_last = d;
             const float d32 = (float)d;
             const float kd = r.kr * d32;
             const float omkd = 1.0f - kd;
@@ -985,10 +1001,13 @@ FOT_HD bool tier2_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, 
                             unsure |= tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
                             fl |= fabsf(c.kappa) > lim_curv ? CK_CURV : 0u;
                         } else if (c.v + c.e_v < 0.5f * (1.0f - TIER_U)) {        // under it for certain: the low-speed rules
-                            // lateral slip: float64 throughout, the very expressions of check_sample
-                            const double dd = fabs(d - prev_d);
-                            const double d_s = fabs(tab.s_at(k) - tab.s_at(k - 1));
-                            fl |= dd > fmax(1.5 * d_s, 0.02) ? CK_CURV : 0u;
+                            // lateral slip |d_k - d_k-1| > max(1.5 |s_k - s_k-1|, 0.02): both differences formed in float64
+                            // and rounded once (2^-24 relative each), the product and the maximum round once more
+                            const float dd = (float)fabs(d - prev_d);
+                            const float cap_s = fmaxf(1.5f * fabsf(r.ds), 0.02f);
+                            const bool slip = dd > cap_s;
+                            if (!(fabsf(dd - cap_s) > 4.0f * TIER_U * cap_s)) unsure = true;
+                            fl |= slip ? CK_CURV : 0u;
                             // yaw step: the cap is at least 0.1 rad and |atan2(sn, cs)| <= |sn| / cs; float32 sines and cosines
                             // (errors of a few 1e-6) prove the step harmless with the margin between 0.085 and 0.09
                             const float sn = c.sin_t * pct - c.cos_t * pst, cs = c.cos_t * pct + c.sin_t * pst;
@@ -1005,28 +1024,36 @@ FOT_HD bool tier2_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, 
                     }
                     t.px = c.x; t.py = c.y; pct = c.cos_t; pst = c.sin_t; prev_d = d;
                     k_last = k;
-                    const bool alive = (fl & CK_FAILED) == 0;
-                    sink.put32(k, 0, c.x, c.y, alive, [&](double &px, double &py) {
-                        double rx, ry, cr, sr;
-                        tab.load_exact(k, rx, ry, cr, sr);
-                        px = rx - sr * d; py = ry + cr * d;       // (frenet_to_cart's x, y)
-                    });
+                    sink.test32(k, c.x, c.y, (fl & CK_FAILED) == 0);
                 }
             }
         }
         sink.row_end(k);
     }
-    g.acc.fl = fl; g.first_nan = first_nan; g.k_last = k_last; g.v_last = 0.0;   // (v_last: no stop directive here)
-    g.acc.max_step2 = -INFINITY;
-    if (k_last >= 1 && !(fl & CK_NANSTEP)) {
+    o.fl = fl; o.first_nan = first_nan; o.k_last = k_last;
+    o.step_over = false;
+    if (k_last >= 1) {
         // the largest step against the step limit (frenet_planner.py:953-956): certain, or float64
         const float lim2 = (float)(D.step_limit * D.step_limit);
-        if (t.max_step2 > lim2 * 1.002f) g.acc.max_step2 = INFINITY;
-        else if (t.max_step2 < lim2 * 0.998f) g.acc.max_step2 = 0.0;
-        else unsure = true;
+        if (t.max_step2 > lim2 * 1.002f) o.step_over = true;
+        else if (!(t.max_step2 < lim2 * 0.998f)) unsure = true;
     }
-    return unsure;
+    o.unsure = unsure;
 }
+
+// What finish_candidate needs of a certified walk: the flags, the truncation bookkeeping, the step verdict as the two
+// values check_status tells apart, and the final lateral offset (float64, from the polynomial: the walk does not carry it)
+FOT_HD void certify_state(const CertifyOut &o, const LonInfo &L, const double *q, double dt, SegState &g)
+{
+    seg_init(g);
+    g.acc.fl = o.fl; g.first_nan = o.first_nan; g.k_last = o.k_last;
+    g.acc.max_step2 = o.step_over ? INFINITY : (o.k_last >= 1 ? 0.0 : -INFINITY);
+    g.d_last = L.n_t > 0 ? lat_offset(q, L.n_t - 1, L.n_eval, dt) : 0.0;
+    g.v_last = 0.0;                                               // (no stop directive on this path)
+}
+
+// (finish_candidate reads s_at only for the travelled distance of the stop filter, which this path never applies)
+struct NoArcTab { FOT_HD double s_at(int) const { return 0.0; } };
 
 // g (segments up to some k) followed by n (the segment that starts there and holds a sample below n_t).  Returns
 // false when g already ended the kept prefix (a NaN sample): n's checks and collision points then do not count.
@@ -1537,6 +1564,30 @@ struct EntryCollider {
     }
     FOT_HD void restart() { hit_mask = 0; viol = 0; hit = false; }
     FOT_HD bool collided() const { return hit; }
+};
+
+// The sink of the certifying walk (certify_walk) in its portable form; k_evaluate_certify's CertifySink is the same logic
+// with the chunk walk on scalar loads.  No chance budget on this path: one certain hit settles the candidate.
+struct CertifyCollider {
+    const uint32_t *rng = nullptr;       // [n_total] strip ranges of this candidate's tile, nullptr: no obstacles
+    const float *thr_k = nullptr, *thr_sure_k = nullptr;   // [n_total] the tile's thresholds per step (box_thresholds)
+    const f2 *e32 = nullptr;             // of this instance
+    int ent_cap = 0;
+    bool hit = false, near = false;
+    FOT_HD void row_begin(int) {}
+    FOT_HD void row_end(int) {}
+    FOT_HD void test32(int k, float fx, float fy, bool alive)
+    {
+        if (!rng || !alive || hit) return;
+        const int c_lo = (int)(rng[k] >> 16), c_hi = (int)(rng[k] & 0xffffu);
+        if (c_hi <= c_lo) return;
+        const int64_t base = (int64_t)k * ent_cap;
+        float m_all = INFINITY;
+        for (int c = c_lo * ENT_CHUNK; c < c_hi * ENT_CHUNK; c += ENT_CHUNK)
+            m_all = fminf(m_all, min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy));
+        if (m_all <= thr_sure_k[k]) hit = true;
+        else if (m_all <= thr_k[k]) near = true;
+    }
 };
 
 // ---------------------------------------------------------------------------

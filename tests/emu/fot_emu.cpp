@@ -327,36 +327,40 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                     if (ex > epos || ey > epos) return -128;
                 }
             }
-            if (!P.has_footprint && std::isnan(D.max_stop)) {
-                // tier, second form (tier2_walk): a candidate it certifies has the float64 walk's record, bit for bit
-                struct EmuTierTab {
+            if (!P.has_footprint && std::isnan(D.max_stop) && D.max_viol == 0) {
+                // the certifying walk (certify_walk, k_evaluate_certify): a candidate it certifies has the float64 walk's
+                // record -- status, kept length, cost bit for bit
+                struct EmuCertTab {
                     GlobalTab gt; double ox, oy;
                     void load32(int k, Row32 &r) const {
                         LonSample ls; gt.load(k, ls);
                         r.sd = (float)ls.sd; r.sdd = (float)ls.sdd; r.rx = (float)(ls.rx - ox); r.ry = (float)(ls.ry - oy);
                         r.cos_r = (float)ls.cos_r; r.sin_r = (float)ls.sin_r; r.kr = (float)ls.kr; r.dkr = (float)ls.dkr;
                         r.inv_sd = (float)ls.inv_sd;
+                        r.ds = k > 0 ? (float)(gt.s_at(k) - gt.s_at(k - 1)) : 0.0f;
                     }
-                    void load_exact(int k, double &rx, double &ry, double &cr, double &sr) const {
-                        LonSample ls; gt.load(k, ls); rx = ls.rx; ry = ls.ry; cr = ls.cos_r; sr = ls.sin_r;
-                    }
-                    double s_at(int k) const { return gt.s_at(k); }
                 } ttab = { GlobalTab{ tab }, D.ego.x, D.ego.y };
-                EntryCollider e2;
-                e2.init(P, D);
-                e2.rng = ec.rng; e2.e32 = ec.e32; e2.e64 = ec.e64; e2.sid = ec.sid; e2.thr_k = ec.thr_k; e2.thr_sure_k = ec.thr_sure_k;
+                CertifyCollider e2;
+                if (D.ent_cap > 0) {
+                    e2.rng = ec.rng; e2.e32 = ec.e32; e2.thr_k = ec.thr_k; e2.thr_sure_k = ec.thr_sure_k; e2.ent_cap = D.ent_cap;
+                }
+                CertifyOut co;
+                certify_walk(P, D, Li, ttab, q, P.n_total, e2, co);
                 SegState g2;
-                seg_init(g2);
-                const bool unsure = tier2_walk(P, D, Li, ttab, q, P.n_total, e2, g2);
+                certify_state(co, Li, q, P.dt, g2);
+                int keep2 = Li.n_t;
+                if (co.fl & CK_SEEN_NAN) keep2 = co.first_nan >= 2 ? co.first_nan : 0;
+                if (co.fl & CK_SINGULAR) keep2 = 0;
+                const bool unsure = co.unsure || (check_status(D, g2.acc, keep2) == ST_PENDING && !e2.hit && e2.near);
                 long *ts = tier_stats();
                 ts[0] += 1; ts[1] += unsure ? 1 : 0;
                 tile_unsure |= unsure;
                 if ((idx & 63) == 63 || idx == S.n_cand - 1) { ts[2] += 1; ts[3] += tile_unsure ? 1 : 0; tile_unsure = false; }
                 if (!unsure) {
                     CandResult r2;
-                    finish_candidate(P, D, Li, GlobalTab{ tab }, q, g2, e2.collided(), r2);
+                    finish_candidate(P, D, Li, NoArcTab(), q, g2, e2.hit, r2);
                     if (r2.status != r.status || r2.keep != r.keep) {
-                        if (getenv("FOT_EMU_DEBUG")) fprintf(stderr, "tier2 cand %d status %d vs %d keep %d vs %d fl %x vs %x\n", idx, r2.status, r.status, r2.keep, r.keep, g2.acc.fl, 0u);
+                        if (getenv("FOT_EMU_DEBUG")) fprintf(stderr, "certify cand %d status %d vs %d keep %d vs %d fl %x\n", idx, r2.status, r.status, r2.keep, r.keep, co.fl);
                         return -130;
                     }
                     if (std::memcmp(&r2.cost, &r.cost, sizeof(double)) != 0) return -131;
