@@ -235,16 +235,6 @@ int fot_debug_margins(fot_handle *h, int32_t inst, int32_t cap, double *margins)
  * of segments for the handle's later plan calls, 0 restores the choice by batch size. */
 int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg);
 
-/* Test hook.  A large batch under the grouped cut is evaluated by TWO kernels: k_evaluate_certify walks every tile in
- * float32 with error bounds and settles the candidates all of whose decisions it can certify; k_evaluate_rest walks the
- * tiles it gave up on in float64.  Same decisions, byte-identical records as the float64 kernels alone.  mode 0 = large
- * batches only (default), 1 = never, 2 = every plan call under the grouped cut (how the tests put every reference case
- * through the certifying kernel). */
-int fot_debug_set_certify(fot_handle *h, int32_t mode);
-/* of the most recent plan call: tiles of the batch, and items the certifying kernel left for the float64 kernel (tiles it
- * gave up on + instances whose selection it handed over); 0 items when the call did not take that path */
-int fot_debug_certify_counts(fot_handle *h, int32_t *n_tiles, int32_t *n_rest);
-
 /* Test hook.  How the handle cuts a lattice into tiles (the unit of work of the evaluation kernel): 0 = chosen by
  * the lattice (default), 1 = per-wave rows (k_evaluate: every wave stages the rows of its own tile), 2 = groups
  * (k_evaluate_group: four tiles share one row table).  Same decisions, byte-identical records either way; the GPU
@@ -402,7 +392,7 @@ int fot_unpack_records(int32_t n_total, int32_t n, const void *wire, fot_result 
  * With profiling on, every kernel launch of a plan call is bracketed by HIP events on the
  * stream it is launched on.  fot_profile_read waits for the recorded work, then returns, per
  * kernel, the number of launches and the summed device time in ms since the last reset. */
-#define FOT_PROFILE_KERNELS 4
+#define FOT_PROFILE_KERNELS 3
 int fot_profile_enable(fot_handle *h, int on);
 /* launches / total_ms: arrays of `cap` entries (entries past cap are not written); returns FOT_PROFILE_KERNELS of the
  * library, or a negative error */

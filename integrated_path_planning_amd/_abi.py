@@ -114,10 +114,10 @@ LIB_PATH = os.path.join(_HERE, "libfot.so")
 SYMBOLS = ["fot_version", "fot_abi_info", "fot_create", "fot_destroy", "fot_live_handles", "fot_last_error", "fot_set_path_waypoints",
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
-           "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_set_certify", "fot_debug_certify_counts", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
+           "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
            "fot_predict_cv", "fot_safety_metrics_batch", "fot_loop_set_static", "fot_loop_plan", "fot_loop_observe", "fot_loop_observe_begin", "fot_loop_observe_end", "fot_gather_paths", "fot_wire_n_total", "fot_wire_record_bytes",
            "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
-PROFILE_KERNELS = 4                      # FOT_PROFILE_KERNELS (include/fot.h)
+PROFILE_KERNELS = 3                      # FOT_PROFILE_KERNELS (include/fot.h)
 ABI_VERSION = 4                          # FOT_ABI_VERSION
 MAX_TI, MAX_TV, MAX_BRAKE, MAX_PRED_LEN = 64, 32, 32, 32
 EGO_IS_FRENET = 3                        # FOT_EGO_IS_FRENET (fot_ego.has_prev_s)
@@ -309,8 +309,6 @@ def lib():
     L.fot_debug_margins.argtypes = [vp, C.c_int32, C.c_int32, dp]
     L.fot_debug_set_eval_segments.argtypes = [vp, C.c_int32]
     L.fot_debug_set_tile_cut.argtypes = [vp, C.c_int32]
-    L.fot_debug_set_certify.argtypes = [vp, C.c_int32]
-    L.fot_debug_certify_counts.argtypes = [vp, ip, ip]
     L.fot_debug_time_info.argtypes = [vp, C.c_double, ip, dp, dp]
     L.fot_check_paths.argtypes = [vp, C.c_int32, ip, ip] + [dp] * 9 + [C.POINTER(Overrides), C.c_double, C.c_int32, dp,
                                                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, ip]

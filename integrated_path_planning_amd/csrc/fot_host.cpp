@@ -84,13 +84,12 @@ struct Workspace {
     DevBuf dEntCnt, dEnt32, dEnt64, dEntSid, dWaveRng;   // broad phase: culled entry lists + per-wave chunk ranges
     DevBuf dNanFlag;                         // one flag per pedestrian track (NanScan)
     DevBuf dDone;                            // tiles evaluated so far, per instance (tile_done)
-    DevBuf dRest;                            // tiles the certifying kernel gave up on: count (first 256 bytes) | (inst, tile)[]
     BatchLayout last;                        // layout of this lane's part of the most recent plan call
     int first_inst = 0;                      // global index of this lane's first instance
     void release()
     {
         DevBuf *bufs[] = { &dMeta, &dState, &dCost, &dParts, &dStatus, &dKeep,
-                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag, &dDone, &dRest };
+                           &dWaveRng, &dEntCnt, &dEnt32, &dEnt64, &dEntSid, &dNanFlag, &dDone };
         for (DevBuf *b : bufs) b->release();
         for (int i = 0; i < 2; ++i) {
             staging[i].release();
@@ -138,7 +137,6 @@ struct fot_handle {
     hipStream_t order_stream = nullptr;
     bool order_valid = false;
     int eval_segments = 0;               // fot_debug_set_eval_segments
-    int certify = 0;                     // fot_debug_set_certify
     // Completion of a synchronous small call without a stream synchronisation: the wave that writes a record (into
     // pinned memory) raises that record's flag to the call's sequence number behind a system-scope release; the host
     // polls the flags.  hipStreamSynchronize returns some 10 us after the last kernel ended on this platform -- a sixth
@@ -291,7 +289,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // memory directly (fot_plan_batch, fot_safety_metrics_batch, fot_frenet_state_batch, the host path of the resampler).
 constexpr size_t SMALL_CALL_BYTES = (size_t)1 << 20;
 
-const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate", "k_evaluate_certify" };
+const char *const kKernelNames[FOT_PROFILE_KERNELS] = { "k_frenet_state", "k_cull", "k_evaluate" };
 
 // accumulate finished event pairs into the per-kernel totals (waits for them)
 int prof_drain(fot_handle *h)
@@ -307,29 +305,6 @@ int prof_drain(fot_handle *h)
     h->prof_kernel.clear();
     h->prof_used = 0;
     return FOT_OK;
-}
-
-// the same for the launchers that bracket their own launches (LaunchProfiler, fot_kernels.h)
-int prof_begin(void *ctx, int kernel, hipStream_t st)
-{
-    fot_handle *h = (fot_handle *)ctx;
-    if (!h->prof_on) return -1;
-    while (h->prof_pool.size() < h->prof_used + 2) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return -1;
-        h->prof_pool.push_back(e);
-    }
-    const int slot = (int)h->prof_used;
-    if (hipEventRecord(h->prof_pool[slot], st) != hipSuccess) return -1;
-    h->prof_used += 2;
-    h->prof_kernel.push_back(kernel);
-    return slot;
-}
-
-void prof_end(void *ctx, int slot, hipStream_t st)
-{
-    fot_handle *h = (fot_handle *)ctx;
-    (void)hipEventRecord(h->prof_pool[(size_t)slot + 1], st);
 }
 
 // brackets one launch with events when profiling is on
@@ -394,7 +369,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dWaveRng.ensure(sizeof(TileStep) * (size_t)P.n_total * (size_t)std::max(L.n_tiles, 1)));
     HIP_TRY(h, w.dNanFlag.ensure((size_t)std::max<int64_t>(L.n_tracks, 16)));
     HIP_TRY(h, w.dDone.ensure(sizeof(int32_t) * (size_t)L.n_inst));
-    HIP_TRY(h, w.dRest.ensure(256 + sizeof(int32_t) * 2 * ((size_t)std::max(L.n_tiles, 1) + (size_t)L.n_inst)));
 
     // no H2D copy in front of the kernels: k_frenet_state pulls the staging block into HBM (one dependent hop less)
     w.staging_pending[slot] = true;
@@ -406,7 +380,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     tt.span = h->dShapes.as<int32_t>() + 2 * h->shapes.cand0.size();
     tt.n_tiles = L.n_tiles; tt.max_tiles = L.max_tiles; tt.row_budget = L.row_budget;
     tt.eval_segments = h->eval_segments;
-    tt.certify = h->certify;
     tt.grouped = L.grouped;
     const DevParams *dP = h->dP.as<DevParams>();
     const SplineView sv = spline_view(h);
@@ -414,8 +387,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     ca.cost = w.dCost.as<double>(); ca.parts = w.dParts.as<TilePart>();
     ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
     if (sync_caller && h->done_seq_armed) { ca.done_flag = (int32_t *)h->hDone.p; ca.done_seq = h->done_seq; }
-    ca.rest_count = w.dRest.as<int32_t>();
-    ca.rest_items = (char *)w.dRest.p + 256;
 
     EntryArrays ea;
     ea.cnt = w.dEntCnt.as<int32_t>(); ea.e32 = w.dEnt32.as<f2>(); ea.e64 = w.dEnt64.as<d2>();
@@ -424,7 +395,6 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     MetaImport imp;
     imp.h_desc = (const InstDesc *)stg;
     imp.d_desc = (InstDesc *)w.dMeta.p;
-    imp.rest_count = ca.rest_count;
     // one scan block per 256 KB of an instance's tensor (few, fat blocks: each first reads its descriptor out of the
     // pinned staging block, a PCIe round trip), at most 64 per instance
     NanScan scan;
@@ -448,10 +418,9 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
                                   d_static, d_dyn, b.obstacle_dtype, ea, tt, st));
     }
     {
-        // (the evaluation is one launch or two -- the certifying kernel and the float64 rest --: it brackets them itself)
-        LaunchProfiler lp = { h, prof_begin, prof_end };
+        ProfScope ps(h, 2, st);
         LAUNCH_TRY(h, launch_evaluate(dP, sv, d_desc, w.dState.as<InstState>(), P.n_total, L.n_inst, tt, ea, ca, d_out,
-                                      w.dDone.as<int32_t>(), st, h->prof_on ? &lp : nullptr));
+                                      w.dDone.as<int32_t>(), st));
     }
     HIP_TRY(h, hipEventRecord(w.staging_done[slot], st));        // (behind the call: see Workspace::staging_done)
     return FOT_OK;
@@ -647,7 +616,6 @@ int fot_create(const fot_params *params, int device, fot_handle **out)
         if (upload_tile_shapes(h, cut) != FOT_OK) { std::string m = h->err; destroy_handle(h); return fail(nullptr, FOT_ERR_HIP, m); }
     }
     { std::lock_guard<std::mutex> lk(g_live_mu); live_handles().insert(h); }
-    if (const char *ev = std::getenv("FOT_CERTIFY")) h->certify = ev[0] == '0' ? 1 : ev[0] == '2' ? 2 : 0;   // diagnostics scripts
     *out = h;
     return FOT_OK;
 }
@@ -1468,32 +1436,6 @@ int fot_debug_set_eval_segments(fot_handle *h, int32_t n_seg)
     if (!h) return FOT_ERR_INVALID;
     if (n_seg < 0 || n_seg > 4) return fail(h, FOT_ERR_INVALID, "fot_debug_set_eval_segments: 0 (automatic) .. 4");
     h->eval_segments = n_seg;
-    return FOT_OK;
-}
-
-int fot_debug_set_certify(fot_handle *h, int32_t mode)
-{
-    if (!h) return FOT_ERR_INVALID;
-    if (mode < 0 || mode > 2)
-        return fail(h, FOT_ERR_INVALID, "fot_debug_set_certify: 0 (large batches), 1 (never), 2 (every call under the grouped cut)");
-    h->certify = mode;
-    return FOT_OK;
-}
-
-int fot_debug_certify_counts(fot_handle *h, int32_t *n_tiles, int32_t *n_rest)
-{
-    if (!h) return FOT_ERR_INVALID;
-    if (!h->last_valid) return fail(h, FOT_ERR_INVALID, "no completed plan call on this handle");
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipDeviceSynchronize());                          // diagnostic entry: whatever stream the plan ran on
-    int tiles = 0, rest = 0;
-    for (int l = 0; l < h->lanes_used; ++l) {
-        int32_t c = 0;
-        if (h->ws[l].dRest.p) HIP_TRY(h, hipMemcpy(&c, h->ws[l].dRest.p, sizeof(c), hipMemcpyDeviceToHost));
-        rest += c; tiles += h->ws[l].last.n_tiles;
-    }
-    if (n_tiles) *n_tiles = tiles;
-    if (n_rest) *n_rest = rest;
     return FOT_OK;
 }
 

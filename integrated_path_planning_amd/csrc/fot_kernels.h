@@ -21,15 +21,6 @@ struct CandArrays {
     TilePart *parts;                    // [n_tiles of the batch]
     int32_t *done_flag = nullptr;       // pinned, one per instance, or nullptr: raised to done_seq behind the instance's record
     int32_t done_seq = 0;
-    int32_t *rest_count = nullptr;      // tiles the certifying kernel gave up on (zeroed by k_frenet_state): count ...
-    void *rest_items = nullptr;         // ... and (instance, tile) pairs, [n_tiles of the batch]
-};
-
-// event pairs around the launches inside launch_evaluate (two kernels on the certifying path): the host's profiler
-struct LaunchProfiler {
-    void *ctx;
-    int (*begin)(void *ctx, int kernel, hipStream_t st);   // returns a slot (or -1: not recording)
-    void (*end)(void *ctx, int slot, hipStream_t st);
 };
 
 // What k_cull leaves per (tile, time step) for k_evaluate: the chunk range the tile's own profiles can reach
@@ -70,7 +61,6 @@ struct NanScan {
 struct MetaImport {
     const InstDesc *h_desc = nullptr;
     InstDesc *d_desc = nullptr;
-    int32_t *rest_count = nullptr;      // zeroed by the launch's first block (CandArrays::rest_count)
 };
 
 // The handle's tile table in HBM (built once per handle, one run per terminal-speed grid size = lattice shape):
@@ -81,7 +71,6 @@ struct TileTable {
     int n_tiles = 0, max_tiles = 0, row_budget = 0;
     int grouped = 0;                    // groups of GROUP_TILES tiles share a row table (TileShapes::grouped)
     int eval_segments = 0;              // time segments per tile in k_evaluate: 0 = by batch size, 1..4 forced (tests)
-    int certify = 0;                    // float32 certifying kernel + float64 rest: 0 = large batches, 1 = never, 2 = always (tests)
 };
 
 // every launcher returns 0 or the hipError_t of the launch
@@ -94,7 +83,7 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
 // evaluation + selection: the records land in `out`; inst_done: one counter per instance (zeroed by k_frenet_state)
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,
                     int n_inst, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
-                    hipStream_t st, const LaunchProfiler *prof = nullptr);
+                    hipStream_t st);
 int launch_debug_path(const DevParams *P, const InstDesc *desc, const InstState *state,
                       SplineView sp, int inst, int idx, double *out, int32_t *meta, hipStream_t st);
 int launch_debug_margins(const DevParams *P, const InstDesc *desc, const InstState *state, SplineView sp, int inst,

@@ -240,7 +240,6 @@ __device__ __forceinline__ void frenet_state_block(const DevParams *__restrict__
     __shared__ ScanBest s_best[FRENET_WG / WAVE];
     __shared__ InstDesc s_desc;                                   // the descriptor being worked on, read once
     int inst = block;
-    if (block == 0 && threadIdx.x == 0 && imp.rest_count) *imp.rest_count = 0;   // (the evaluation's list of given-up tiles)
     if (inst >= n_inst) {
         // the blocks behind the nearest-point blocks: NaN scan of the dynamic tensors (memory-bound, on CUs whose
         // nearest-point block is a chain of dependent spline evaluations)
@@ -430,7 +429,6 @@ struct EvalKernArgs {
     TilePart *parts;                                 // per tile: what its wave found (tile_done)
     fot_result *out; int32_t *inst_done;             // selection by the wave that finishes an instance's last tile
     int32_t *done_flag; int32_t done_seq;            // host-visible flag per record (CandArrays::done_flag)
-    int32_t *rest_count; int2 *rest_items;           // tiles k_evaluate_certify gave up on: (instance, tile), for k_evaluate_rest
 };
 // k_evaluate's argument segment: EVAL_LEAD_PTRS read-only pointers (passed on their own so that they carry
 // `__restrict__`: only no-alias inputs are certain to keep their loads on the scalar unit), then this struct
@@ -911,234 +909,6 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
 }
 
 // ---------------------------------------------------------------------------
-// the float32 certifying walk of a large batch (k_evaluate_certify) -- fot_math.hpp certify_walk
-// ---------------------------------------------------------------------------
-
-// Rows of the certifying walk: ten float32 fields (40 bytes) per (profile, time step) -- the float64 row rounded once,
-// reference point in the instance-local frame, and the arc-length step ds = s(t_k) - s(t_k-1) (formed in float64).
-constexpr int CERT_ROW_FIELDS = 10;
-static_assert(sizeof(Row32) == CERT_ROW_FIELDS * sizeof(float), "Row32 is the LDS row of the certifying walk");
-// floats of LDS of a group's table: rows | profile summaries (LonInfo, 8-byte aligned) | row offsets
-__host__ __device__ constexpr int cert_group_floats()
-{
-    return GROUP_ROWS * CERT_ROW_FIELDS + GROUP_MAX_PROFILES * LONINFO_DOUBLES * 2 + GROUP_MAX_PROFILES;
-}
-static_assert((GROUP_ROWS * CERT_ROW_FIELDS) % 2 == 0 && cert_group_floats() % 2 == 0, "the summaries and the spline behind them are doubles");
-
-struct CertTab {
-    const float *rows;                   // this lane's profile, row 0 (LDS)
-    int k_max;                           // last row of the run (grid: n_t - 1; brake ladder: the hold row n_eval)
-    __device__ __forceinline__ void load32(int k, Row32 &r) const
-    {
-        const float *p = rows + (k < k_max ? k : k_max) * CERT_ROW_FIELDS;
-        r.sd = p[0]; r.sdd = p[1]; r.rx = p[2]; r.ry = p[3]; r.cos_r = p[4]; r.sin_r = p[5]; r.kr = p[6]; r.dkr = p[7];
-        r.inv_sd = p[8]; r.ds = p[9];
-        // in registers before the sink's hand-issued scalar loads (they must not sit between these reads and their wait)
-        asm volatile("" : "+v"(r.sd), "+v"(r.sdd), "+v"(r.rx), "+v"(r.ry), "+v"(r.cos_r), "+v"(r.sin_r), "+v"(r.kr),
-                          "+v"(r.dkr), "+v"(r.inv_sd), "+v"(r.ds));
-    }
-};
-
-// FusedSink's chunk walk without the float64 re-check: a chunk whose float32 minimum lies at or below the step's `sure`
-// threshold is a certain hit (no chance budget on this path: one hit settles the candidate); one between the two
-// thresholds is left to the float64 kernel (`near`).
-struct CertifySink {
-    uint32_t my_rng;                     // lane l: strip range of time step step_base + l (0: nothing to test)
-    float my_thr, my_thr_sure;           // lane l: the float32 thresholds of that time step (TileStep)
-    int step_base, step_row, lane_id, n_total;
-    bool live;                           // the instance has entry lists at all
-    float thr, thr_sure;                 // of the current time step (wave-uniform)
-    const f2x8 *chunks;                  // float32 entries of this instance, ent_cap / 8 chunks per time step
-    int chunks_per_k;
-    int c_lo, n_chunks;                  // chunk range of the current time step
-    uint32_t pf;                         // destination of the warm-up loads, reserved until they have landed
-    bool hit, near;
-
-    __device__ __forceinline__ void steps_load(int base)
-    {
-        const EvalKernArgs &KA = eval_kernargs();
-        TileStep st = { 0u, 0.0f, 0.0f, 0u };
-        if (live && base + lane_id < n_total) st = KA.wave_rng[(int64_t)step_row * n_total + base + lane_id];
-        my_rng = st.rng; my_thr = st.thr; my_thr_sure = st.thr_sure;
-        step_base = base;
-    }
-
-    __device__ __forceinline__ void row_begin(int k)
-    {
-        if ((k & ~(WAVE - 1)) != step_base) steps_load(k & ~(WAVE - 1));      // wave-uniform; never taken up to 64 samples
-        const int kl = k & (WAVE - 1);
-        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)my_rng, kl);
-        c_lo = (int)(r >> 16);
-        n_chunks = (int)(r & 0xffffu) - c_lo;
-        thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr), kl));
-        thr_sure = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_thr_sure), kl));
-        if (n_chunks > 0) {
-            const f2x8 *row = chunks + (int64_t)k * chunks_per_k + c_lo;
-            asm volatile("s_load_dword %0, %1, 0x0\n\t"
-                         "s_load_dword %0, %1, 0x40\n\t"
-                         "s_load_dword %0, %1, 0x80\n\t"
-                         "s_load_dword %0, %1, 0xc0"
-                         : "=&s"(pf) : "s"(row) : "memory");          // (early clobber: four loads read `row`)
-        } else {
-            pf = 0;
-        }
-    }
-
-    __device__ __forceinline__ void row_end(int) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf) : : "memory"); }
-
-    __device__ __forceinline__ void test32(int k, float fx_in, float fy, bool alive)
-    {
-        if (n_chunks == 0) return;                                // wave-uniform
-        if (!alive || hit) return;                                // lanes whose collision outcome is already settled
-        float fx = fx_in;                                         // (tied into the hand-issued loads below)
-        const f2x8 *cp = chunks + (int64_t)k * chunks_per_k + c_lo;
-        float m_all = INFINITY;                                   // smallest squared distance to any entry of the step
-        // two chunk buffers filled by hand-issued scalar loads, each waited for right before its own use (FusedSink::put32)
-        f16 ca, cb;
-        sload_chunk<0>(ca, cp);
-        swait_chunk(ca);
-        for (int c = 0; c < n_chunks; c += 2) {
-            sload_chunk_ahead<64>(cb, cp, fx);
-            m_all = fminf(m_all, min_sqdist32_f16(ca, fx, fy));
-            swait_chunk(cb);
-            sload_chunk_ahead<128>(ca, cp, fx);
-            if (c + 1 < n_chunks) m_all = fminf(m_all, min_sqdist32_f16(cb, fx, fy));   // wave-uniform
-            swait_chunk(ca);
-            cp += 2;
-        }
-        if (m_all <= thr_sure) hit = true;                        // certainly within the (smaller) radius
-        else if (m_all <= thr) near = true;                       // float32 cannot tell
-    }
-};
-
-// One tile of a group, certifying walk.  Returns true when every candidate of the tile is settled (tp holds the tile's
-// partial result, as evaluate_tile leaves it); false when the tile has to be walked in float64 (one of its candidates
-// could not be certified, or the instance is outside this path's preconditions) -- nothing has been written then.
-__device__ __forceinline__ bool certify_tile(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
-                                             const InstState *__restrict__ state,
-                                             const int32_t *__restrict__ tile_cand0, const int32_t *__restrict__ tile_n,
-                                             const TileStep *__restrict__ wave_rng, const f2 *__restrict__ ent32,
-                                             const EvalKernArgs &a, const SplineView &sp_lds, float *tab_rows, int inst,
-                                             int tile, int lane, TilePart &tp, int sub, int grp_tile0, bool eligible)
-{
-    const DevParams &P = *Pp;
-    const InstDesc &D = desc[inst];
-    const InstState &S = state[inst];
-    const int n_total = P.n_total;
-    const int cand0 = tile_cand0[D.shape_off + tile];
-    int n = tile_n[D.shape_off + tile];
-    int stage_c0 = tile_cand0[D.shape_off + grp_tile0];
-    int stage_c1 = tile_cand0[D.shape_off + grp_tile0 + GROUP_TILES - 1] + tile_n[D.shape_off + grp_tile0 + GROUP_TILES - 1];
-    if (!S.c2f_ok || stage_c0 >= S.n_cand) return true;          // (the brake ladder of a standing ego) -- the whole workgroup
-    if (stage_c1 > S.n_cand) stage_c1 = S.n_cand;
-    if (cand0 + n > S.n_cand) n = S.n_cand - cand0 > 0 ? S.n_cand - cand0 : 0;
-    if (!eligible) return n <= 0;                                 // (wave-uniform per instance: the whole workgroup)
-    LonInfo *s_info = (LonInfo *)(tab_rows + GROUP_ROWS * CERT_ROW_FIELDS);
-    int *s_row0 = (int *)(s_info + GROUP_MAX_PROFILES);
-    const int slot_lo = decode_candidate(P, D, S.frenet0, stage_c0).lon_slot;
-    const int n_stage = decode_candidate(P, D, S.frenet0, stage_c1 - 1).lon_slot - slot_lo + 1;
-    const int bld_id = sub * WAVE + lane, bld_n = GROUP_TILES * WAVE;
-    int total_rows = 0, n_loop = 0;
-    for (int p = 0; p < n_stage; ++p) {                          // wave-uniform: a handful of scalar operations
-        const int r = profile_rows(P, D, slot_lo + p);
-        if (bld_id == p) s_row0[p] = total_rows;
-        total_rows += r;
-    }
-    if (bld_id < n_stage) s_info[bld_id] = profile_info(P, D, S.frenet0, slot_lo + bld_id, true);
-    __syncthreads();
-    for (int i = bld_id; i < total_rows; i += bld_n) {
-        int p = 0;
-        for (int pp = 1; pp < n_stage; ++pp) p = i >= s_row0[pp] ? pp : p;
-        const int k = i - s_row0[p];
-        const LonInfo Lp = s_info[p];
-        LonSample ls;
-        double sddd;
-        make_lon_sample(sp_lds, Lp, k, P.dt, ls, sddd);          // (k == n_eval of a brake profile: its hold state)
-        double s_prev = ls.s, u0, u1, u2;
-        if (k > 0) lon_sample(Lp, k - 1, P.dt, s_prev, u0, u1, u2);
-        float *r = tab_rows + (int64_t)i * CERT_ROW_FIELDS;
-        r[0] = (float)ls.sd; r[1] = (float)ls.sdd; r[2] = (float)(ls.rx - D.ego.x); r[3] = (float)(ls.ry - D.ego.y);
-        r[4] = (float)ls.cos_r; r[5] = (float)ls.sin_r; r[6] = (float)ls.kr; r[7] = (float)ls.dkr;
-        r[8] = (float)ls.inv_sd; r[9] = (float)(ls.s - s_prev);
-    }
-    __syncthreads();
-    if (n <= 0) return true;                                     // (a padding tile, or one past a standing ego's lattice)
-    {
-        const int own_lo = decode_candidate(P, D, S.frenet0, cand0).lon_slot - slot_lo;
-        const int own_hi = decode_candidate(P, D, S.frenet0, cand0 + n - 1).lon_slot - slot_lo;
-        for (int p = own_lo; p <= own_hi; ++p) { const int nt = s_info[p].n_t; n_loop = nt > n_loop ? nt : n_loop; }
-        n_loop = __builtin_amdgcn_readfirstlane(n_loop);
-    }
-    // lane l holds the per-step values of time step l (read back with v_readlane): loaded while every lane is active
-    TileStep my_step = { 0u, 0.0f, 0.0f, 0u };
-    if (D.ent_cap != 0 && lane < n_total) my_step = wave_rng[(int64_t)(D.tile0 + tile) * n_total + lane];
-    CertifyOut o;
-    o.fl = 0; o.first_nan = -1; o.k_last = -1; o.step_over = false; o.unsure = false;
-    bool hit = false, near = false;
-    LonInfo L;
-    int p_own = 0;
-    double q[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };              // lateral quintic of the lane's candidate
-    const bool has_cand = lane < n;
-    if (has_cand || lane < n_total) {                            // (lanes that hold per-step values stay active: evaluate_tile)
-        const int idx = cand0 + (has_cand ? lane : 0);
-        const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
-        p_own = cd.lon_slot - slot_lo;
-        L = s_info[p_own];
-        if (!has_cand) L.n_t = 0;
-        CertTab tab;
-        tab.rows = tab_rows + s_row0[p_own] * CERT_ROW_FIELDS;
-        tab.k_max = profile_rows(P, D, cd.lon_slot) - 1;
-        lat_coeffs(S.frenet0, cd.di, cd.brake ? P.brake[cd.ti] : P.ti[cd.ti], q);
-        asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));   // (wave-uniform, but cheaper in vector registers: evaluate_tile)
-        CertifySink sink;
-        sink.my_rng = my_step.rng; sink.my_thr = my_step.thr; sink.my_thr_sure = my_step.thr_sure;
-        sink.step_base = 0; sink.step_row = D.tile0 + tile; sink.lane_id = lane; sink.n_total = n_total;
-        sink.live = D.ent_cap != 0;
-        sink.thr = 0.0f; sink.thr_sure = -1.0f;
-        sink.chunks = (const f2x8 *)(ent32 + D.ent_off);
-        sink.chunks_per_k = D.ent_cap / ENT_CHUNK;
-        sink.c_lo = 0; sink.n_chunks = 0; sink.pf = 0; sink.hit = false; sink.near = false;
-        certify_walk(P, D, L, tab, q, n_loop, sink, o);
-        hit = sink.hit; near = sink.near;
-    }
-    // certified?  (the collision state only matters for a candidate that passes everything else)
-    SegState g;
-    int keep = 0, st = FOT_ST_DROPPED;
-    bool gave_up = false;
-    if (has_cand) {
-        certify_state(o, L, q, P.dt, g);
-        keep = L.n_t;
-        if (o.fl & CK_SEEN_NAN) keep = o.first_nan >= 2 ? o.first_nan : 0;
-        if (o.fl & CK_SINGULAR) keep = 0;
-        st = check_status(D, g.acc, keep);
-        gave_up = o.unsure || (st == ST_PENDING && !hit && near);
-    }
-    if (__ballot(gave_up) != 0ull) return false;                 // the float64 kernel walks this tile
-    int st_final = FOT_ST_DROPPED;
-    ScanBest mine = { INFINITY, -1 };
-    int my_keep = 0;
-    if (has_cand) {
-        CandResult r;
-        LonInfo Lf = s_info[p_own];
-        finish_candidate(P, D, Lf, NoArcTab(), q, g, hit, r);
-        st_final = r.status;                                     // (no stop-distance directive on this path)
-        const int64_t slot = (int64_t)D.cand_off + cand0 + lane;
-        const EvalKernArgs &KA = eval_kernargs();
-        KA.cand_cost[slot] = r.cost;
-        KA.cand_status[slot] = (uint8_t)st_final;
-        KA.cand_keep[slot] = (uint8_t)r.keep;
-        my_keep = r.keep;
-        if (st_final == FOT_ST_OK) { mine.dist = r.cost; mine.idx = cand0 + lane; }
-    }
-    const ScanBest best = wave_argmin(mine);                     // every lane of the wave is here
-    tp.cost = best.dist; tp.idx = best.idx;
-    tp.keep = __builtin_amdgcn_readfirstlane(__shfl(my_keep, best.idx >= 0 ? best.idx - cand0 : 0, WAVE));
-#pragma unroll
-    for (int c = 0; c < 8; ++c) tp.cnt[c] = __popcll(__ballot(st_final == c));
-    return true;
-}
-
-// ---------------------------------------------------------------------------
 // selection + output (reference: frenet_planner.py:294-324, 1235-1259)
 // ---------------------------------------------------------------------------
 
@@ -1251,7 +1021,6 @@ __device__ __forceinline__ void record_written(int inst, int lane)
 // and counts itself.  Every tile of the instance arrives exactly once; the wave that completes the count selects.
 // k_frenet_state zeroes the counters.  The partial results travel as agent-coherent stores / loads (st_agent,
 // ld_agent): once this wave's stores are acknowledged (vmcnt) they are visible to every CU, so the count needs no fence.
-template <bool SELECT = true>
 __device__ __forceinline__ void tile_done(int inst, int tile, int lane, const TilePart &tp)
 {
     const EvalKernArgs &KA = eval_kernargs();
@@ -1268,17 +1037,8 @@ __device__ __forceinline__ void tile_done(int inst, int tile, int lane, const Ti
                == KA.desc[inst].n_tiles - 1 ? 1 : 0;
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
-    if constexpr (SELECT) {
-        select_instance_wave(inst, lane);
-        record_written(inst, lane);
-    } else {
-        // the certifying kernel does not select (the selection's float64 path rebuild would set ITS register budget): the
-        // instance goes onto the rest list as an item of its own, and k_evaluate_rest selects for it
-        if (lane == 0) {
-            const int at = __hip_atomic_fetch_add(KA.rest_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            KA.rest_items[at] = make_int2(inst, -1);
-        }
-    }
+    select_instance_wave(inst, lane);
+    record_written(inst, lane);
 }
 
 // the degenerate launch: a batch without a single tile (no horizons, no brake ladder) still gets its records
@@ -1391,81 +1151,6 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
     evaluate_tile<TILE_GROUP>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, inst, tile0 + wv,
                               lane, x, tp, wv, GROUP_TILES, nullptr, tile0);
     tile_done(inst, tile0 + wv, lane, tp);
-}
-
-// The certifying kernel of a large batch: k_evaluate_group's shape (one workgroup per group of GROUP_TILES tiles, one
-// shared row table) with float32 rows -- 24 KB of LDS and a register budget of 80 per lane: six workgroups per CU, six
-// waves per SIMD.  A tile all of whose candidates are certified is done here (partial result + count, selection by the
-// instance's last arriver as ever); any other tile goes onto the batch's rest list for k_evaluate_rest.
-#ifndef FOT_CERT_WAVES
-#define FOT_CERT_WAVES 5
-#endif
-extern __shared__ float s_cert[];
-__global__ void __launch_bounds__(GROUP_TILES * WAVE) __attribute__((amdgpu_waves_per_eu(FOT_CERT_WAVES, FOT_CERT_WAVES)))
-k_evaluate_certify(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
-                   const InstState *__restrict__ state, const int32_t *__restrict__ tile_cand0,
-                   const int32_t *__restrict__ tile_n, const TileStep *__restrict__ wave_rng,
-                   const f2 *__restrict__ ent32, const EvalKernArgs a)
-{
-    // LDS: [rows | summaries | row offsets] of the group, then the spline
-    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, (double *)(s_cert + cert_group_floats()));
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int x = (int)blockIdx.x & (N_XCD - 1), q = (int)blockIdx.x >> 3;
-    const int m_x = (a.n_inst - x + N_XCD - 1) / N_XCD;
-    const int n_entries = m_x * (a.max_tiles / GROUP_TILES);      // groups in this queue
-    if (m_x <= 0 || q >= n_entries) return;
-    const int pos = q / m_x, j = q - pos * m_x;
-    const int inst = x + N_XCD * j;
-    const int n_groups = desc[inst].n_tiles / GROUP_TILES;
-    if (pos >= n_groups) return;                                 // a shorter lattice than the batch's longest
-    const int tile0 = (n_groups - 1 - pos) * GROUP_TILES;
-    // what the float32 walk is not for (fot_math.hpp certify_walk): the whole instance goes to the float64 kernel
-    const DevParams &P = *Pp;
-    const bool eligible = !P.has_footprint && isnan(desc[inst].max_stop) && desc[inst].max_viol == 0 &&
-                          state[inst].frenet0[1] > 1.0 && !(a.ablate & 4);
-    TilePart tp = tile_part_empty();
-    const bool done = certify_tile(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_cert, inst, tile0 + wv,
-                                   lane, tp, wv, tile0, eligible);
-    if (done) {
-        tile_done<false>(inst, tile0 + wv, lane, tp);
-    } else if (lane == 0) {
-        const EvalKernArgs &KA = eval_kernargs();
-        const int at = __hip_atomic_fetch_add(KA.rest_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        KA.rest_items[at] = make_int2(inst, tile0 + wv);
-    }
-}
-
-// The float64 walk of the tiles k_evaluate_certify gave up on: k_evaluate_split's shape (one workgroup per tile, its
-// waves a time segment each -- few tiles, so latency counts), dealt from the rest list.  The list's length is only
-// known on the device: the grid is its upper bound.
-__global__ void __launch_bounds__(SEG_MAX * WAVE)
-k_evaluate_rest(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc,
-                const InstState *__restrict__ state, const int32_t *__restrict__ tile_cand0,
-                const int32_t *__restrict__ tile_n, const TileStep *__restrict__ wave_rng,
-                const f2 *__restrict__ ent32, const EvalKernArgs a, const int32_t *__restrict__ rest_count,
-                const int2 *__restrict__ rest_items)
-{
-    const int n_rest = *rest_count;
-    if ((int)blockIdx.x >= n_rest) return;
-    const int n_seg = (int)blockDim.x / WAVE;
-    const int wave_doubles = eval_wave_doubles(a.row_budget);
-    double *s_part = s_lon + wave_doubles;
-    const SplineView sp_lds = stage_spline(a.sp, a.lds_knots, s_part + (SEG_MAX - 1) * SEG_DOUBLES);
-    const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    const int lane = threadIdx.x & (WAVE - 1);
-    // (one item per workgroup, no loop around the tile walk: a loop costs it 40 vector registers and 80 scalar spills;
-    //  the grid is the list's upper bound -- every tile once, every instance's selection once -- and the workgroups past
-    //  its actual length have already left)
-    const int2 it = rest_items[blockIdx.x];
-    if (it.y < 0) {                                              // an instance whose last tile the certifying kernel finished
-        if (seg == 0) { select_instance_wave(it.x, lane); record_written(it.x, lane); }
-        return;
-    }
-    TilePart tp = tile_part_empty();
-    evaluate_tile<TILE_SPLIT>(Pp, desc, state, tile_cand0, tile_n, wave_rng, ent32, a, sp_lds, s_lon, it.x, it.y, lane,
-                              it.x & (N_XCD - 1), tp, seg, n_seg, s_part);
-    if (seg == 0) tile_done(it.x, it.y, lane, tp);
 }
 
 // ---------------------------------------------------------------------------
@@ -2077,13 +1762,6 @@ k_safety(const DevParams *__restrict__ Pp, int n, const double *__restrict__ ego
 
 #define FOT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-// brackets one launch with the caller's begin / end callbacks (fot_host.cpp's event pairs), when profiling is on
-struct ProfileHook {
-    const LaunchProfiler *p; int slot; hipStream_t st;
-    ProfileHook(const LaunchProfiler *p_, int kernel, hipStream_t st_) : p(p_), st(st_) { slot = p ? p->begin(p->ctx, kernel, st) : -1; }
-    ~ProfileHook() { if (p && slot >= 0) p->end(p->ctx, slot, st); }
-};
-
 int launch_frenet_state(const DevParams *P, SplineView sp, const InstDesc *desc, InstState *state, int n_inst,
                         MetaImport imp, NanScan scan, int32_t *inst_done, hipStream_t st)
 {
@@ -2121,7 +1799,7 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
 
 int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, const InstState *state, int n_total,
                     int n_inst, TileTable tiles, EntryArrays e, CandArrays c, fot_result *out, int32_t *inst_done,
-                    hipStream_t st, const LaunchProfiler *prof)
+                    hipStream_t st)
 {
     if (n_inst <= 0) return 0;
     static const int ablate = getenv("FOT_EVAL_ABLATE") ? atoi(getenv("FOT_EVAL_ABLATE")) : 0;
@@ -2148,29 +1826,6 @@ int launch_evaluate(const DevParams *P, SplineView sp, const InstDesc *desc, con
     a.wave_rng = e.rng; a.ent32 = e.e32; a.ent64 = e.e64; a.ent_sid = e.sid;
     a.cand_cost = c.cost; a.cand_status = c.status; a.cand_keep = c.keep; a.parts = c.parts;
     a.out = out; a.inst_done = inst_done; a.done_flag = c.done_flag; a.done_seq = c.done_seq;
-    a.rest_count = c.rest_count; a.rest_items = (int2 *)c.rest_items;
-    // Large batches under the grouped cut: the float32 certifying kernel first, then the float64 kernel on the tiles it
-    // gave up on (certify 1: never, 2: whenever the cut is grouped -- the tests' way to put small calls through it)
-    const bool certify = tiles.grouped && c.rest_count && tiles.certify != 1 && (tiles.certify == 2 || n_seg == 1);
-    if (certify && tiles.n_tiles > 0) {
-        const int per_q = (n_inst + N_XCD - 1) / N_XCD * (tiles.max_tiles / GROUP_TILES);
-        const size_t c_lds = sizeof(float) * (size_t)cert_group_floats() + sizeof(double) * 9 * (size_t)lds_knots;
-        {
-            ProfileHook ph(prof, 3, st);
-            k_evaluate_certify<<<(unsigned)(per_q * N_XCD), GROUP_TILES * WAVE, c_lds, st>>>(P, desc, state, tiles.cand0,
-                                                                                            tiles.n, e.rng, e.e32, a);
-            FOT_LAUNCH_CHECK();
-        }
-        const int rest_grid = tiles.n_tiles + n_inst;             // the list's upper bound
-        const size_t r_lds = sizeof(double) * ((size_t)eval_wave_doubles(tiles.row_budget) + 9 * (size_t)lds_knots
-                                               + (size_t)(SEG_MAX - 1) * SEG_DOUBLES);
-        ProfileHook ph(prof, 2, st);
-        k_evaluate_rest<<<(unsigned)rest_grid, SEG_MAX * WAVE, r_lds, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng,
-                                                                            e.e32, a, c.rest_count, (const int2 *)c.rest_items);
-        FOT_LAUNCH_CHECK();
-        return 0;
-    }
-    ProfileHook ph(prof, 2, st);
     if (tiles.n_tiles <= 0) {
         k_select_only<<<(unsigned)n_inst, WAVE, 0, st>>>(P, desc, state, tiles.cand0, tiles.n, e.rng, e.e32, a);
     } else if (n_seg > 1) {

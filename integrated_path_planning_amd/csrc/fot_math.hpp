@@ -758,303 +758,6 @@ FOT_HD void evaluate_segment(const DevParams &P, const LoopConst &C, const LonIn
     }
 }
 
-// ---------------------------------------------------------------------------
-// The float32 certifying walk (k_evaluate_certify, the first of the two evaluation kernels of a large batch).
-//
-// Every decision of the reference is a comparison of a float64 quantity with a threshold.  The certifying walk
-// evaluates a candidate's samples in float32 together with a first-order bound of the float32 error of every compared
-// quantity (inputs rounded to float32: 2^-24 relative each; d', d'' of the quintic: an absolute bound per step from the
-// coefficients' magnitudes; every operation 2^-24 relative; the unit carries a factor of two on top).  A comparison
-// whose float32 value lies further from its threshold than its bound has the same outcome in float64: it is CERTIFIED.
-// A candidate all of whose comparisons are certified gets its status, kept length and (float64, closed-form) cost from
-// this walk; a candidate with ONE uncertified comparison is given up on, and its tile is walked by the float64 kernel
-// afterwards (k_evaluate_rest).  Nothing float32 ever decides a status that float64 could decide differently.  What
-// stays float64 here: the lateral offset d (road-bound test -- the outermost lateral target converges to the bound
-// itself --, final offset of the cost) and the cost.
-// ---------------------------------------------------------------------------
-
-FOT_HD float rcp_f32(float a)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(a);
-#else
-    return 1.0f / a;
-#endif
-}
-
-FOT_HD float rsq_f32(float a)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rsqf(a);
-#else
-    return 1.0f / sqrtf(a);
-#endif
-}
-
-constexpr float TIER_U = 1.1920929e-7f;                          // 2 x 2^-24: unit roundoff with a safety factor of two
-
-struct Tier32 {                          // per candidate
-    float c1[5];                         // d'  = c1[0] + t (c1[1] + t (c1[2] + t (c1[3] + t c1[4])))
-    float c2[4];                         // d'' = c2[0] + t (c2[1] + t (c2[2] + t c2[3]))
-    float e1, e2;                        // absolute error bounds of the float32 d', d'' (whole horizon; tier_poly: per step)
-    float dt;
-    float max_step2;                     // largest squared step so far (float32 positions)
-    float px, py;                        // previous sample, instance-local float32
-};
-
-FOT_HD void tier_init(Tier32 &t, const double *q, double T, double dt)
-{
-    const double a[6] = { fabs(q[0]), fabs(q[1]), fabs(q[2]), fabs(q[3]), fabs(q[4]), fabs(q[5]) };
-    t.c1[0] = (float)q[1]; t.c1[1] = (float)(2.0 * q[2]); t.c1[2] = (float)(3.0 * q[3]); t.c1[3] = (float)(4.0 * q[4]);
-    t.c1[4] = (float)(5.0 * q[5]);
-    t.c2[0] = (float)(2.0 * q[2]); t.c2[1] = (float)(6.0 * q[3]); t.c2[2] = (float)(12.0 * q[4]); t.c2[3] = (float)(20.0 * q[5]);
-    const double T2 = T * T, T3 = T2 * T;
-    const double B1 = a[1] + 2.0 * a[2] * T + 3.0 * a[3] * T2 + 4.0 * a[4] * T3 + 5.0 * a[5] * T2 * T2;
-    const double B2 = 2.0 * a[2] + 6.0 * a[3] * T + 12.0 * a[4] * T2 + 20.0 * a[5] * T3;
-    const double B3 = 6.0 * a[3] + 24.0 * a[4] * T + 60.0 * a[5] * T2;
-    // Horner in float32 (rounded coefficients, rounded t, one rounding per operation) on terms bounded by B1 / B2;
-    // the rounding of t moves d' by |d''| dt_err <= B2 T u and d'' by B3 T u
-    t.e1 = (float)((12.0 * B1 + 2.0 * B2 * T) * TIER_U);
-    t.e2 = (float)((10.0 * B2 + 2.0 * B3 * T) * TIER_U);
-    t.dt = (float)dt;
-    t.max_step2 = -INFINITY; t.px = 0.0f; t.py = 0.0f;
-}
-
-// d', d'' at t with the error bounds of THIS step: Horner on the coefficients' magnitudes bounds the terms (the whole-
-// horizon bounds e1, e2 are one to two orders larger early in the walk and where the polynomial's terms cancel)
-FOT_HD void tier_poly(const Tier32 &t, float tt, float &d_d, float &d_dd, float &e1, float &e2)
-{
-    d_d = t.c1[0] + tt * (t.c1[1] + tt * (t.c1[2] + tt * (t.c1[3] + tt * t.c1[4])));
-    d_dd = t.c2[0] + tt * (t.c2[1] + tt * (t.c2[2] + tt * t.c2[3]));
-    const float m1 = fabsf(t.c1[0]) + tt * (fabsf(t.c1[1]) + tt * (fabsf(t.c1[2]) + tt * (fabsf(t.c1[3]) + tt * fabsf(t.c1[4]))));
-    const float m2 = fabsf(t.c2[0]) + tt * (fabsf(t.c2[1]) + tt * (fabsf(t.c2[2]) + tt * fabsf(t.c2[3])));
-    e1 = 8.0f * TIER_U * m1;             // rounded coefficients and t (relative u each, t up to the fourth power), eight operations
-    e2 = 8.0f * TIER_U * m2;
-}
-
-struct Cart32 {
-    float x, y, cos_t, sin_t, kappa, v, a, lat;
-    float e_v, e_a, e_k, e_lat;          // bounds of |float32 value - float64 value|
-};
-
-// frenet_to_cart in float32, with the error bounds.  rx, ry: reference point in the instance-local frame.
-// e1, e2: absolute error bounds of d_d, d_dd.
-FOT_HD void frenet_to_cart_f32(float sd, float sdd, float rx, float ry, float cos_r, float sin_r, float kr, float dkr,
-                               float inv_sd, float d, float omkd, float d_d, float d_dd, float e1, float e2, Cart32 &o)
-{
-    const float u = TIER_U;
-    const float ainv = fabsf(inv_sd);
-    const float dp = d_d * inv_sd;
-    const float e_dp = e1 * ainv + u * fabsf(dp);
-    const float w = dp * sdd;
-    const float inv_sd2 = inv_sd * inv_sd;
-    const float dpp = (d_dd - w) * inv_sd2;
-    const float e_dpp = (e2 + e_dp * fabsf(sdd) + u * (fabsf(d_dd) + fabsf(w))) * inv_sd2 + u * fabsf(dpp);
-    const float e_om = u * (1.0f + fabsf(kr * d));                 // (omkd itself arrives rounded from float64)
-    const float aom = fabsf(omkd);
-    const float hh = dp * dp + omkd * omkd;
-    const float e_hh = 2.0f * (fabsf(dp) * e_dp + aom * e_om) + u * hh;
-    const float inv_h = rsq_f32(hh);
-    const float ih2 = inv_h * inv_h;
-    const float r_h = 0.5f * e_hh * ih2 + u;                       // relative error of h and of 1 / h
-    const float h = hh * inv_h;
-    const float inv_om = rcp_f32(omkd);
-    const float cos_d = omkd * inv_h, sin_d = dp * inv_h;
-    const float krdp = dkr * d + kr * dp;
-    const float e_k0 = u * (fabsf(dkr * d) + fabsf(kr * dp)) + fabsf(kr) * e_dp;
-    // kappa = ((d'' (1 - kd) + krdp d') / h^2 + kr) / h
-    const float n1 = dpp * omkd, n2 = krdp * dp;
-    const float num = n1 + n2;
-    const float e_num = e_dpp * aom + fabsf(dpp) * e_om + e_k0 * fabsf(dp) + fabsf(krdp) * e_dp + u * (fabsf(n1) + fabsf(n2));
-    const float kin = num * ih2;
-    const float kappa = (kin + kr) * inv_h;
-    const float e_kap = (e_num * ih2 + fabsf(kin) * 2.0f * r_h + u * (fabsf(kin) + fabsf(kr))) * inv_h + fabsf(kappa) * (r_h + u);
-    const float hk = h * kappa;
-    const float dtp = hk - kr;
-    const float e_dtp = h * e_kap + fabsf(hk) * r_h + u * (fabsf(hk) + fabsf(kr));
-    const float inv_cos = h * inv_om;
-    const float r_ic = r_h + e_om * fabsf(inv_om) + 2.0f * u;
-    const float g1 = dp * dtp;
-    const float g = g1 - krdp;
-    const float e_g = e_dp * fabsf(dtp) + fabsf(dp) * e_dtp + e_k0 + u * (fabsf(g1) + fabsf(krdp));
-    const float sd2 = sd * sd;
-    const float a1 = sdd * h, a2f = sd2 * inv_cos;
-    const float a2 = a2f * g;
-    o.a = a1 + a2;
-    o.e_a = fabsf(a1) * (r_h + u) + fabsf(a2f) * (e_g + fabsf(g) * (r_ic + 2.0f * u)) + u * (fabsf(a1) + fabsf(a2));
-    o.v = fabsf(sd) * h;
-    o.e_v = o.v * (r_h + 2.0f * u);
-    o.kappa = kappa; o.e_k = e_kap;
-    const float v2 = o.v * o.v;
-    o.lat = v2 * fabsf(kappa);
-    o.e_lat = 2.0f * o.v * o.e_v * fabsf(kappa) + v2 * e_kap + 2.0f * u * o.lat;
-    o.x = rx - sin_r * d;
-    o.y = ry + cos_r * d;
-    o.cos_t = cos_d * cos_r - sin_d * sin_r;
-    o.sin_t = sin_d * cos_r + cos_d * sin_r;
-}
-
-// lateral offset alone, float64 (the rest of the lateral state goes through Tier32)
-FOT_HD double lat_offset(const double *q, int k, int n_eval, double dt)
-{
-    return quintic_value(q, (double)(k < n_eval ? k : n_eval - 1) * dt);
-}
-
-// |value - threshold| within the error bound (or not a number): the float32 comparison proves nothing
-FOT_HD bool tier_unsure(float value, float threshold, float bound)
-{
-    return !(fabsf(value - threshold) > bound + TIER_U * fabsf(threshold));
-}
-
-#if !defined(__HIP_DEVICE_COMPILE__)
-// (CPU logic test only: how often the float32 tier certifies a step)
-inline long *tier_stats() { static long c[8] = { 0 }; return c; }
-#endif
-
-FOT_HD bool wave_any(bool b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __ballot(b) != 0ull;
-#else
-    return b;
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// certify_walk: ONE float32 walk of a whole candidate that certifies every decision made on it, or gives up.
-//   Tab::load32(k, Row32&)   row k of the candidate's longitudinal profile, rounded to float32 from the float64 row
-//                            (reference point in the instance-local frame), plus ds = s(t_k) - s(t_k-1) formed in
-//                            float64 and rounded (the low-speed slip rule compares against it)
-//   Sink::row_begin / row_end as in evaluate_segment; Sink::test32(k, fx, fy, alive): the collision point (instance-
-//                            local float32) against the entry lists -- the sink keeps `hit` (some entry CERTAINLY within
-//                            its radius) and `near` (some entry neither certainly inside nor certainly outside)
-// Not for footprint circles, a stop-distance directive or a chance budget (their consumers need float64 headings, the
-// final speed, per-sample hit masks): the caller hands such instances to the float64 kernel from the start.
-// ---------------------------------------------------------------------------
-
-struct Row32 { float sd, sdd, rx, ry, cos_r, sin_r, kr, dkr, inv_sd, ds; };
-
-struct CertifyOut {
-    uint32_t fl;                         // CK_* bits, every one of them certified
-    int first_nan, k_last;
-    bool step_over;                      // the largest step certainly exceeds the step limit (frenet_planner.py:953-956)
-    bool unsure;                         // some decision (collision aside) could not be certified: give up
-};
-
-template <class Tab, class Sink>
-FOT_HD void certify_walk(const DevParams &P, const InstDesc &D, const LonInfo &L, const Tab &tab, const double *q,
-                         int n_loop, Sink &sink, CertifyOut &o)
-{
-    const int n_t = L.n_t, n_eval = L.n_eval;
-    const double dt64 = P.dt, road_lim = P.road_lim;
-    const float lim_speed = (float)D.lim_speed, lim_accel = (float)D.lim_accel, lim_curv = (float)D.lim_curv,
-                lim_lat = (float)D.lim_lat;
-    Tier32 t;
-    tier_init(t, q, (double)(n_eval - 1) * dt64, dt64);
-    uint32_t fl = 0;
-    bool unsure = false;
-    float pct = 1.0f, pst = 0.0f;                                 // previous heading (low-speed yaw rule)
-    double prev_d = 0.0;
-    int first_nan = -1, k_last = -1;
-    for (int k = 0; k < n_loop; ++k) {
-        Row32 r;
-        tab.load32(k, r);
-        sink.row_begin(k);
-        if (k < n_t) {
-            const double d = lat_offset(q, k, n_eval, dt64);
-            const float d32 = (float)d;
-            const float kd = r.kr * d32;
-            const float omkd = 1.0f - kd;
-            if (omkd == omkd) {                                    // (NaN beyond the path end: not finite, no flag -- as in float64)
-                if (!(fabsf(omkd - 0.05f) > 4.0f * TIER_U * (1.0f + fabsf(kd)))) unsure = true;
-                else if (omkd <= 0.05f) fl |= CK_SINGULAR;        // SINGULARITY_EPS, any sample
-            }
-            if (!(fl & CK_SEEN_NAN)) {
-                float d_d = 0.0f, d_dd = 0.0f, e1 = 0.0f, e2 = 0.0f;
-                if (k < n_eval) tier_poly(t, (float)k * t.dt, d_d, d_dd, e1, e2);   // (brake padding: d' = d'' = 0 exactly)
-                Cart32 c;
-                frenet_to_cart_f32(r.sd, r.sdd, r.rx, r.ry, r.cos_r, r.sin_r, r.kr, r.dkr, r.inv_sd, d32, omkd, d_d, d_dd, e1, e2, c);
-                if (isnan(c.x)) {
-                    fl |= CK_SEEN_NAN; first_nan = k;             // the reference point is NaN there: exact in either precision
-                } else {
-                    unsure |= !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa));
-#if !defined(__HIP_DEVICE_COMPILE__)
-#define TIER_CAUSE(i, cond) do { if (cond) tier_stats()[4 + (i)] += 1; } while (0)
-#else
-#define TIER_CAUSE(i, cond) do { } while (0)
-#endif
-                    TIER_CAUSE(0, !(isfinite(c.v) && isfinite(c.a) && isfinite(c.kappa)));
-                    if (k > 0) {
-                        const float sx = c.x - t.px, sy = c.y - t.py;
-                        const float step2 = sx * sx + sy * sy;
-                        unsure |= isnan(step2);
-                        t.max_step2 = step2 > t.max_step2 ? step2 : t.max_step2;
-                        unsure |= tier_unsure(c.v, lim_speed, c.e_v);
-                        unsure |= tier_unsure(fabsf(c.a), lim_accel, c.e_a);
-                        unsure |= tier_unsure(c.lat, lim_lat, c.e_lat);
-                        TIER_CAUSE(1, tier_unsure(c.v, lim_speed, c.e_v) || tier_unsure(fabsf(c.a), lim_accel, c.e_a) || tier_unsure(c.lat, lim_lat, c.e_lat));
-                        fl |= c.v > lim_speed ? CK_SPEED : 0u;
-                        fl |= fabsf(c.a) > lim_accel ? CK_ACCEL : 0u;
-                        fl |= c.lat > lim_lat ? CK_LAT : 0u;
-                        fl |= fabs(d) > road_lim ? CK_ROAD : 0u;                  // (float64: exact)
-                        if (c.v - c.e_v > 0.5f * (1.0f + TIER_U)) {               // above the LOW_SPEED_CURVATURE_GATE for certain
-                            unsure |= tier_unsure(fabsf(c.kappa), lim_curv, c.e_k);
-                            fl |= fabsf(c.kappa) > lim_curv ? CK_CURV : 0u;
-                        } else if (c.v + c.e_v < 0.5f * (1.0f - TIER_U)) {        // under it for certain: the low-speed rules
-                            // lateral slip |d_k - d_k-1| > max(1.5 |s_k - s_k-1|, 0.02): both differences formed in float64
-                            // and rounded once (2^-24 relative each), the product and the maximum round once more
-                            const float dd = (float)fabs(d - prev_d);
-                            const float cap_s = fmaxf(1.5f * fabsf(r.ds), 0.02f);
-                            const bool slip = dd > cap_s;
-                            if (!(fabsf(dd - cap_s) > 4.0f * TIER_U * cap_s)) unsure = true;
-                            fl |= slip ? CK_CURV : 0u;
-                            // yaw step: the cap is at least 0.1 rad and |atan2(sn, cs)| <= |sn| / cs; float32 sines and cosines
-                            // (errors of a few 1e-6) prove the step harmless with the margin between 0.085 and 0.09
-                            const float sn = c.sin_t * pct - c.cos_t * pst, cs = c.cos_t * pct + c.sin_t * pst;
-                            // ... and |yaw step| >= |sin(yaw step)| = |sn| proves it over the cap max(kappa_max * step, 0.1)
-                            const float cap_hi = fmaxf(lim_curv * sqrtf(step2) * 1.001f, 0.1f);
-                            const bool over = fabsf(sn) - 1e-4f > cap_hi, harmless = cs > 0.5f && fabsf(sn) <= 0.085f * cs;
-                            fl |= over ? CK_CURV : 0u;
-                            if (!over && !harmless) unsure = true;
-                            TIER_CAUSE(2, !over && !harmless);
-                        } else {
-                            unsure = true;                                      // at the gate
-                            TIER_CAUSE(3, true);
-                        }
-                    }
-                    t.px = c.x; t.py = c.y; pct = c.cos_t; pst = c.sin_t; prev_d = d;
-                    k_last = k;
-                    sink.test32(k, c.x, c.y, (fl & CK_FAILED) == 0);
-                }
-            }
-        }
-        sink.row_end(k);
-    }
-    o.fl = fl; o.first_nan = first_nan; o.k_last = k_last;
-    o.step_over = false;
-    if (k_last >= 1) {
-        // the largest step against the step limit (frenet_planner.py:953-956): certain, or float64
-        const float lim2 = (float)(D.step_limit * D.step_limit);
-        if (t.max_step2 > lim2 * 1.002f) o.step_over = true;
-        else if (!(t.max_step2 < lim2 * 0.998f)) unsure = true;
-    }
-    o.unsure = unsure;
-}
-
-// What finish_candidate needs of a certified walk: the flags, the truncation bookkeeping, the step verdict as the two
-// values check_status tells apart, and the final lateral offset (float64, from the polynomial: the walk does not carry it)
-FOT_HD void certify_state(const CertifyOut &o, const LonInfo &L, const double *q, double dt, SegState &g)
-{
-    seg_init(g);
-    g.acc.fl = o.fl; g.first_nan = o.first_nan; g.k_last = o.k_last;
-    g.acc.max_step2 = o.step_over ? INFINITY : (o.k_last >= 1 ? 0.0 : -INFINITY);
-    g.d_last = L.n_t > 0 ? lat_offset(q, L.n_t - 1, L.n_eval, dt) : 0.0;
-    g.v_last = 0.0;                                               // (no stop directive on this path)
-}
-
-// (finish_candidate reads s_at only for the travelled distance of the stop filter, which this path never applies)
-struct NoArcTab { FOT_HD double s_at(int) const { return 0.0; } };
-
 // g (segments up to some k) followed by n (the segment that starts there and holds a sample below n_t).  Returns
 // false when g already ended the kept prefix (a NaN sample): n's checks and collision points then do not count.
 FOT_HD bool seg_merge(SegState &g, const SegState &n)
@@ -1440,8 +1143,8 @@ FOT_HD FilterConst filter_const(double sq, double sq_min)
 
 FOT_HD FilterConst filter_const(double sq) { return filter_const(sq, sq); }
 
-// (e: 2^-21 since the float32 tier: the candidate's point may itself be computed in float32 -- frenet_to_cart_f32, a
-// handful of roundings of coordinates of this magnitude -- instead of being the rounding of its float64 value)
+// (e: 2^-21 -- room for a point that is itself computed in float32 instead of being the rounding of its float64 value;
+//  the shipped kernels hand over rounded float64 points)
 FOT_HD float filter_threshold(const FilterConst &f, float px, float py)
 {
     const float e = (fabsf(px) + fabsf(py) + 2.0f * f.r + 12.0f) * 4.7683716e-7f;
@@ -1564,30 +1267,6 @@ struct EntryCollider {
     }
     FOT_HD void restart() { hit_mask = 0; viol = 0; hit = false; }
     FOT_HD bool collided() const { return hit; }
-};
-
-// The sink of the certifying walk (certify_walk) in its portable form; k_evaluate_certify's CertifySink is the same logic
-// with the chunk walk on scalar loads.  No chance budget on this path: one certain hit settles the candidate.
-struct CertifyCollider {
-    const uint32_t *rng = nullptr;       // [n_total] strip ranges of this candidate's tile, nullptr: no obstacles
-    const float *thr_k = nullptr, *thr_sure_k = nullptr;   // [n_total] the tile's thresholds per step (box_thresholds)
-    const f2 *e32 = nullptr;             // of this instance
-    int ent_cap = 0;
-    bool hit = false, near = false;
-    FOT_HD void row_begin(int) {}
-    FOT_HD void row_end(int) {}
-    FOT_HD void test32(int k, float fx, float fy, bool alive)
-    {
-        if (!rng || !alive || hit) return;
-        const int c_lo = (int)(rng[k] >> 16), c_hi = (int)(rng[k] & 0xffffu);
-        if (c_hi <= c_lo) return;
-        const int64_t base = (int64_t)k * ent_cap;
-        float m_all = INFINITY;
-        for (int c = c_lo * ENT_CHUNK; c < c_hi * ENT_CHUNK; c += ENT_CHUNK)
-            m_all = fminf(m_all, min_sqdist32_8(*(const f2x8 *)(e32 + base + c), fx, fy));
-        if (m_all <= thr_sure_k[k]) hit = true;
-        else if (m_all <= thr_k[k]) near = true;
-    }
 };
 
 // ---------------------------------------------------------------------------

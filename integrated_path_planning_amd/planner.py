@@ -471,12 +471,6 @@ class BatchPlanner:
         cut = {"auto": 0, "wave": 1, "group": 2}.get(cut, cut)
         _abi.check(self._h, self._lib.fot_debug_set_tile_cut(self._h, int(cut)))
 
-    def set_certify(self, mode) -> None:
-        """Test hook (``fot_debug_set_certify``): 0 / "auto" (large batches take the float32 certifying kernel + the
-        float64 kernel on the rest), 1 / "off", 2 / "force" (every call under the grouped cut)."""
-        mode = {"auto": 0, "off": 1, "force": 2}.get(mode, mode)
-        _abi.check(self._h, self._lib.fot_debug_set_certify(self._h, int(mode)))
-
     def time_info(self, time: float):
         """(n_t, quartic inverse [2, 2], quintic inverse [3, 3]) the library solves a horizon of ``time`` seconds with
         (``fot_debug_time_info``)."""

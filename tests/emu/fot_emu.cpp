@@ -257,7 +257,6 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
         int cnt_st[8] = { 0 };
         ScanBest best = { INFINITY, -1 };
         int best_keep = 0;
-        bool tile_unsure = false;
         for (int idx = 0; idx < S.n_cand; ++idx) {
             const CandDecode cd = decode_candidate(P, D, S.frenet0, idx);
             const LonInfo &Li = lon_info[D.lon_off + cd.lon_slot];
@@ -294,76 +293,6 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
                         const float fx = (float)(v.x - D.ego.x), fy = (float)(v.y - D.ego.y);
                         if (!(std::fabs(fx) + std::fabs(fy) <= bound + 2.0f * box_footprint_slack(P) + 2e-3f)) return -113;
                     }
-                }
-            }
-            {   // the float32 transform of the certifying kernel: its error bounds hold sample by sample against the float64 one
-                Tier32 tt;
-                tier_init(tt, q, (double)(Li.n_eval - 1) * P.dt, P.dt);
-                for (int k = 0; k < r.keep; ++k) {
-                    LonSample ls;
-                    GlobalTab{ tab }.load(k, ls);
-                    double d, d_d, d_dd, d_ddd;
-                    lat_sample(q, k, Li.n_eval, P.dt, d, d_d, d_dd, d_ddd);
-                    CartSample c64;
-                    frenet_to_cart(ls, d, d_d, d_dd, c64);
-                    const float tk = (float)k * tt.dt;
-                    float f_d = 0.0f, f_dd = 0.0f, e1 = 0.0f, e2 = 0.0f;
-                    if (k < Li.n_eval) tier_poly(tt, tk, f_d, f_dd, e1, e2);
-                    if (std::fabs((double)f_d - d_d) > (double)e1 + 1e-30 || std::fabs((double)f_dd - d_dd) > (double)e2 + 1e-30) return -123;
-                    Cart32 c32;
-                    frenet_to_cart_f32((float)ls.sd, (float)ls.sdd, (float)(ls.rx - D.ego.x), (float)(ls.ry - D.ego.y),
-                                       (float)ls.cos_r, (float)ls.sin_r, (float)ls.kr, (float)ls.dkr, (float)ls.inv_sd, (float)d,
-                                       (float)(1.0 - ls.kr * d), f_d, f_dd, e1, e2, c32);
-                    if (!(std::isfinite(c32.v) && std::isfinite(c32.a) && std::isfinite(c32.kappa))) continue;   // (float64 decides)
-                    if (std::fabs((double)c32.v - c64.v) > (double)c32.e_v + 1e-20) return -124;
-                    if (std::fabs((double)c32.a - c64.a) > (double)c32.e_a + 1e-20) {
-                        if (getenv("FOT_EMU_DEBUG")) fprintf(stderr, "cand %d k %d a32 %.9g a64 %.17g e_a %.3g v %.6g kappa %.6g omkd %.6g sd %.6g inv_sd %.6g d_d %.6g d_dd %.6g e1 %.3g e2 %.3g\n", idx, k, c32.a, c64.a, c32.e_a, c64.v, c64.kappa, c64.omkd, ls.sd, ls.inv_sd, d_d, d_dd, tt.e1, tt.e2);
-                        return -125;
-                    }
-                    if (std::fabs((double)c32.kappa - c64.kappa) > (double)c32.e_k + 1e-20) return -126;
-                    if (std::fabs((double)c32.lat - c64.v * c64.v * std::fabs(c64.kappa)) > (double)c32.e_lat + 1e-20) return -127;
-                    const double ex = std::fabs((double)c32.x - (c64.x - D.ego.x)), ey = std::fabs((double)c32.y - (c64.y - D.ego.y));
-                    const double epos = 4.7683716e-7 * (std::fabs(c64.x - D.ego.x) + std::fabs(c64.y - D.ego.y) + 12.0);   // filter_threshold's e
-                    if (ex > epos || ey > epos) return -128;
-                }
-            }
-            if (!P.has_footprint && std::isnan(D.max_stop) && D.max_viol == 0) {
-                // the certifying walk (certify_walk, k_evaluate_certify): a candidate it certifies has the float64 walk's
-                // record -- status, kept length, cost bit for bit
-                struct EmuCertTab {
-                    GlobalTab gt; double ox, oy;
-                    void load32(int k, Row32 &r) const {
-                        LonSample ls; gt.load(k, ls);
-                        r.sd = (float)ls.sd; r.sdd = (float)ls.sdd; r.rx = (float)(ls.rx - ox); r.ry = (float)(ls.ry - oy);
-                        r.cos_r = (float)ls.cos_r; r.sin_r = (float)ls.sin_r; r.kr = (float)ls.kr; r.dkr = (float)ls.dkr;
-                        r.inv_sd = (float)ls.inv_sd;
-                        r.ds = k > 0 ? (float)(gt.s_at(k) - gt.s_at(k - 1)) : 0.0f;
-                    }
-                } ttab = { GlobalTab{ tab }, D.ego.x, D.ego.y };
-                CertifyCollider e2;
-                if (D.ent_cap > 0) {
-                    e2.rng = ec.rng; e2.e32 = ec.e32; e2.thr_k = ec.thr_k; e2.thr_sure_k = ec.thr_sure_k; e2.ent_cap = D.ent_cap;
-                }
-                CertifyOut co;
-                certify_walk(P, D, Li, ttab, q, P.n_total, e2, co);
-                SegState g2;
-                certify_state(co, Li, q, P.dt, g2);
-                int keep2 = Li.n_t;
-                if (co.fl & CK_SEEN_NAN) keep2 = co.first_nan >= 2 ? co.first_nan : 0;
-                if (co.fl & CK_SINGULAR) keep2 = 0;
-                const bool unsure = co.unsure || (check_status(D, g2.acc, keep2) == ST_PENDING && !e2.hit && e2.near);
-                long *ts = tier_stats();
-                ts[0] += 1; ts[1] += unsure ? 1 : 0;
-                tile_unsure |= unsure;
-                if ((idx & 63) == 63 || idx == S.n_cand - 1) { ts[2] += 1; ts[3] += tile_unsure ? 1 : 0; tile_unsure = false; }
-                if (!unsure) {
-                    CandResult r2;
-                    finish_candidate(P, D, Li, NoArcTab(), q, g2, e2.hit, r2);
-                    if (r2.status != r.status || r2.keep != r.keep) {
-                        if (getenv("FOT_EMU_DEBUG")) fprintf(stderr, "certify cand %d status %d vs %d keep %d vs %d fl %x\n", idx, r2.status, r.status, r2.keep, r.keep, co.fl);
-                        return -130;
-                    }
-                    if (std::memcmp(&r2.cost, &r.cost, sizeof(double)) != 0) return -131;
                 }
             }
             for (int n_seg = 2; n_seg <= 4; ++n_seg) {   // k_evaluate_split: time segments merged == the single walk
@@ -429,8 +358,6 @@ extern "C" int emu_plan_batch(const fot_params *params, int n_knots, const doubl
     }
     return FOT_OK;
 }
-
-extern "C" void emu_tier_stats(long *out) { for (int i = 0; i < 8; ++i) { out[i] = tier_stats()[i]; tier_stats()[i] = 0; } }
 
 extern "C" int emu_spline(int n, const double *wx, const double *wy, double *out9n)
 {

@@ -20,15 +20,11 @@ def request_from_golden(g) -> PlanRequest:
 # The evaluation kernels a plan call can take (csrc/fot_kernels.hip launch_evaluate).  Every parity test that asserts a
 # per-candidate table runs under each of them: "auto" is what a caller gets (k_evaluate_split for a handful of egos,
 # k_evaluate_group for batches); "group" / "wave" walk every candidate in one piece under the grouped / per-wave cut
-# (k_evaluate_group / k_evaluate, the certifying kernel off); "split-wave" cuts the per-wave tiles into time segments;
-# "certify" puts the call -- whatever its size -- through the float32 certifying kernel and the float64 kernel on the
-# tiles it gives up on (k_evaluate_certify + k_evaluate_rest: what a LARGE batch takes under "auto").
-EVAL_PATHS = ("auto", "certify", "group", "wave", "split-wave")
+# (k_evaluate_group / k_evaluate); "split-wave" cuts the per-wave tiles into time segments.
+EVAL_PATHS = ("auto", "group", "wave", "split-wave")
 
 
 def set_eval_path(bp, path):
-    cut, seg, cert = {"auto": (0, 0, 0), "certify": (2, 1, 2), "group": (2, 1, 1), "wave": (1, 1, 1),
-                      "split-wave": (1, 4, 1)}[path]
+    cut, seg = {"auto": (0, 0), "group": (2, 1), "wave": (1, 1), "split-wave": (1, 4)}[path]
     bp.set_tile_cut(cut)
     bp.set_eval_segments(seg)
-    bp.set_certify(cert)
