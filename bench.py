@@ -53,11 +53,46 @@ sys.path.insert(0, ROOT)
 
 N_SIMD = 1024                    # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                 # MI355X peak engine clock
-# Issue cost of one wave64 vector instruction on a SIMD that holds at least two waves, in cycles
-# (MI355X_MICROARCH.md constants table: v_fma_f32 2, transcendental 8, fp64 at half rate; the other classes measured with
-# scripts/micro/issue_bench.hip on the same part, profiles/r03_issue_costs.jsonl, relative to v_add_f32 = 2:
-# compares / three-source VOP3 / packed-float32 / moves of 64-bit pairs 3.5-4, v_readlane 4).
+# Issue cost of one wave64 vector instruction, in cycles, by class.  The guide's figures (MI355X_MICROARCH.md constants
+# table: v_fma_f32 2, transcendental 8, fp64 at half rate) are the fallback; what roofline_issue uses is what
+# scripts/micro/issue_bench.hip MEASURED on this part (profiles/r03_issue_costs.jsonl: 131 k independent instructions
+# per wave at 1 / 2 / 4 / 8 waves per SIMD), relative to v_add_f32 = 2 and interpolated at the number of resident waves
+# the committed profile of the kernel reports (measured_issue_cycles below): fp64 arithmetic comes out at 2.8 - 3.2
+# rather than 4, fp64 reciprocals at 10 - 12 rather than 16.
 ISSUE_CYCLES = {"f64": 4.0, "trans_f64": 16.0, "f32": 2.0, "trans_f32": 8.0, "int": 2.0, "cvt": 4.0, "other": 3.5}
+ISSUE_OPS = {"f64": ("v_fma_f64", "v_mul_f64", "v_add_f64"), "trans_f64": ("v_rcp_f64", "v_rsq_f64"),
+             "f32": ("v_fma_f32", "v_mul_f32", "v_add_f32"), "trans_f32": ("v_rcp_f32", "v_rsq_f32", "v_sqrt_f32"),
+             "int": ("v_and_b32",),
+             # what the class counters leave over: compares, three-source VOP3, 64-bit moves, packed float32, lane reads,
+             # plain moves (v_cndmask_b32 is not in the mean: its microbenchmark chains through VCC)
+             "other": ("v_cmp_f64", "v_cmp_f32", "v_min3_f32", "v_lshl_or_b32", "v_mov_b64", "v_pk_fma_f32",
+                       "v_readlane_b32", "v_mov_b32")}
+
+
+def measured_issue_cycles(resident_waves):
+    """Class weights from profiles/r03_issue_costs.jsonl at `resident_waves` per SIMD (log-linear between the measured
+    occupancies), normalised to v_add_f32 = 2 cycles; None if the file is missing."""
+    try:
+        rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r03_issue_costs.jsonl")) if l.strip()]
+    except Exception:
+        return None
+    cost = {}
+    for r in rows:
+        cost.setdefault(r["op"], {})[int(r["waves_per_simd"])] = float(r["cycles_per_instr_per_simd"])
+
+    def at(op, w):
+        pts = sorted(cost[op].items())
+        w = min(max(w, pts[0][0]), pts[-1][0])
+        for (w0, c0), (w1, c1) in zip(pts, pts[1:]):
+            if w0 <= w <= w1:
+                f = (np.log(w) - np.log(w0)) / (np.log(w1) - np.log(w0))
+                return c0 + f * (c1 - c0)
+        return pts[-1][1]
+
+    base = at("v_add_f32", resident_waves)
+    out = {c: 2.0 * float(np.mean([at(o, resident_waves) for o in ops if o in cost])) / base for c, ops in ISSUE_OPS.items()}
+    out["cvt"] = out["f64"]                                      # (not measured: conversions to / from fp64 run at its rate)
+    return out
 ISSUE_CLASSES = {"f64": ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"),
                  "trans_f64": ("SQ_INSTS_VALU_TRANS_F64",),
                  "f32": ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"),
@@ -114,6 +149,8 @@ def parse_args():
     ap.add_argument("--dyn-layout", choices=("spt", "tsp"), default="spt",
                     help="layout of the obstacle tensors: spt = the reference's [S][P][T][2] (default), tsp = time-major "
                          "[T][S][P][2] as libfot's own resampler can write it (FOT_DYN_LAYOUT_TSP)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed K-step headline leg is run this many times; the line reports the median repeat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
@@ -290,10 +327,17 @@ def main():
     if n_ov > 1:
         pg = make_pg(max(2, n_ov))
         leg = Leg(n_ov, make_planner, dev, bstructs, out_bytes, pg, rehearse, n_inst, wire_bytes)
-        elapsed, _, first = leg.run(args.warmup, args.steps, profile=False)
-        elapsed = reduce_max(elapsed)
+        # the K-step leg `--repeats` times (W warm-up steps before the first, each repeat bracketed by the barrier +
+        # synchronise of Leg.fence and reduced with MAX over the ranks): the line carries the MEDIAN repeat, min / max beside
+        runs = []
+        for r_ in range(max(1, args.repeats)):
+            el_, _, first_ = leg.run(args.warmup if r_ == 0 else 0, args.steps, profile=False)
+            runs.append((reduce_max(el_), first_))
+        elapsed, first = sorted(runs)[(len(runs) - 1) // 2]
+        repeats_ms = [e_ / args.steps * 1e3 for e_, _ in runs]
     else:
         pg, leg, elapsed, first = pg1, leg1, el1, first1
+        repeats_ms = [el1 / args.steps * 1e3]
 
     # ---- candidates actually generated: one untimed pass per rotation batch, counted from its result records
     bp = leg1.planners[0]
@@ -409,15 +453,22 @@ def main():
         by_class = {c: sum(float(pmc_k.get(k, 0.0)) for k in ks) for c, ks in ISSUE_CLASSES.items()}
         have_classes = any(k in pmc_k for ks in ISSUE_CLASSES.values() for k in ks)
         by_class["other"] = max(n_valu - sum(by_class.values()), 0.0) if have_classes else 0.0
+        # class weights: measured on this part, at the occupancy the profile of this kernel shows (fallback: the guide's)
+        prof_ms0 = pmc_d.get("_meta", {}).get("kernel_ms", {}).get(pmc_name)
+        res_waves = (float(pmc_k["SQ_WAVE_CYCLES"]) * 4.0 / (N_SIMD * prof_ms0 * 1e-3 * CLOCK_HZ)
+                     if prof_ms0 and "SQ_WAVE_CYCLES" in pmc_k else 2.0)
+        weights = measured_issue_cycles(res_waves) or ISSUE_CYCLES
         if have_classes:
-            cycles = sum(by_class[c] * ISSUE_CYCLES[c] for c in by_class)
+            cycles = sum(by_class[c] * weights[c] for c in by_class)
         else:                                                        # an old profile without the class counters
             cycles = n_valu * 4.0
         issue_ms = cycles * scale / (N_SIMD * CLOCK_HZ) * 1e3
         issue = {"kernel": dom, "bound": "valu_issue", "unit": "ms", "achieved": issue_ms, "peak": dom_ms,
                  "frac": issue_ms / dom_ms, "valu_instructions_per_launch": n_valu * scale,
                  "instructions_by_class": {c: v * scale for c, v in by_class.items()} if have_classes else None,
-                 "cycles_per_instruction_by_class": ISSUE_CYCLES if have_classes else {"all": 4.0},
+                 "cycles_per_instruction_by_class": {c: round(v, 3) for c, v in weights.items()} if have_classes else {"all": 4.0},
+                 "weights_source": ("profiles/r03_issue_costs.jsonl (scripts/micro/issue_bench.hip), v_add_f32 = 2, at %.2f "
+                                    "resident waves per SIMD" % res_waves) if weights is not ISSUE_CYCLES else "guide constants",
                  "mean_cycles_per_instruction": cycles / n_valu if n_valu else None,
                  "simds": N_SIMD, "clock_ghz": CLOCK_HZ / 1e9,
                  "profiled_kernel": pmc_name,
@@ -610,6 +661,9 @@ def main():
         "metric": "candidate trajectories/sec", "value": value, "unit": "candidates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "repeats": {"n": len(repeats_ms), "ms_per_step": [round(v, 5) for v in repeats_ms], "min": min(repeats_ms),
+                    "max": max(repeats_ms), "reported": "median repeat (value, ms_per_step): each repeat is exactly "
+                    "`steps` timed steps between a barrier + synchronise on both sides, MAX over the ranks"},
         "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if not rehearse else "synthetic (REHEARSAL of the N>1 control flow on one GPU: not a measurement)",
         "config": {"workload": "%s: %d ego instances/GPU x 2240-candidate lattice (5 s, dt 0.1 s), "

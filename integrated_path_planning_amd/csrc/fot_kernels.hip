@@ -116,7 +116,7 @@ __device__ __forceinline__ double refine_nearest_wave(const SplineView &sp, doub
         const double probe = pos == 0 ? fmax(0.0, ms - mds) : (pos == 1 ? ms : fmin(s_end, ms + mds));
         double px, py;
         spline_xy(sp, probe, px, py);
-        const double dist = hypot(x - px, y - py);
+        const double dist = hypot_cr(x - px, y - py);
         const int rounds = 20 - it < 3 ? 20 - it : 3;
         int base = 0, r1 = 0;
         for (int r = 0; r < rounds; ++r) {

@@ -68,6 +68,52 @@ FOT_HD double quintic_value(const double *q, double t)
 }
 
 // ---------------------------------------------------------------------------
+// Correctly rounded hypot and cube, for the nearest-point search.
+//
+// The search (coordinate_converter.py:202-308) DECIDES by comparing math.hypot(x - px, y - py) of neighbouring probes,
+// with px = a + b h + c h**2.0 + d h**3.0 (cubic_spline.py:70-71): probes a few micrometres apart tie at rounding
+// level, and whichever implementation's last bit differs picks another probe -- the arc length then ends a refinement
+// step away (round 3's "nearest-point tie": 3e-6 m, once 3e-5 m when only the contraction flag of this file changed).
+// Python's hypot, NumPy's power (glibc pow) and glibc's hypot all return the correctly rounded result in practice; so do
+// these two (exact squares / products through FMA residuals, one correction step), on the device as on the host, and the
+// probe position below follows the reference's own operation order with every operation rounded once.  The library's
+// arc length is then the reference's bit for bit, whatever flags this file is compiled with.
+// ---------------------------------------------------------------------------
+
+FOT_HD double hypot_cr(double x, double y)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    x = fabs(x); y = fabs(y);
+    if (isinf(x) || isinf(y)) return INFINITY;
+    if (isnan(x) || isnan(y)) return NAN;
+    if (x < y) { const double t = x; x = y; y = t; }
+    if (y == 0.0) return x;
+    double back = 1.0;                                            /* far from 1: scaled by a power of two (exact) */
+    if (x > 0x1p500) { x *= 0x1p-600; y *= 0x1p-600; back = 0x1p600; }
+    else if (x < 0x1p-500) { x *= 0x1p600; y *= 0x1p600; back = 0x1p-600; }
+    const double xx = x * x, ex = __builtin_fma(x, x, -xx);       // x^2 = xx + ex exactly
+    const double yy = y * y, ey = __builtin_fma(y, y, -yy);
+    const double s = xx + yy, bb = s - xx;
+    const double es = (xx - (s - bb)) + (yy - bb);                // xx + yy = s + es exactly
+    const double lo = es + (ex + ey);
+    const double h = sqrt(s);                                     // correctly rounded square root of the leading part
+    const double r = __builtin_fma(-h, h, s) + lo;                // (x^2 + y^2) - h^2, to working precision
+    return (h + r / (2.0 * h)) * back;
+}
+
+FOT_HD double cube_cr(double h)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const double p = h * h, e = __builtin_fma(h, h, -p);          // h^2 = p + e exactly
+    const double t = p * h, e2 = __builtin_fma(p, h, -t);         // p h = t + e2 exactly
+    return t + __builtin_fma(e, h, e2);
+}
+
+// ---------------------------------------------------------------------------
 // cubic spline (reference: src/planning/cubic_spline.py:47-166, 215-288)
 // ---------------------------------------------------------------------------
 
@@ -112,13 +158,20 @@ FOT_HD bool spline_point(const SplineView &sp, double s, SplinePt &o)
     return true;
 }
 
+// position alone, for the nearest-point search: the reference's expression a + b h + c h**2.0 + d h**3.0 evaluated left
+// to right, every operation rounded once (no contraction), the cube correctly rounded as NumPy's power returns it
 FOT_HD void spline_xy(const SplineView &sp, double s, double &x, double &y)
 {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     if (!(s >= sp.s[0] && s <= sp.s[sp.n - 1])) { x = NAN; y = NAN; return; }
     const int i = spline_index(sp, s);
-    const double h = s - sp.s[i], h2 = h * h;
-    x = sp.ax[i] + sp.bx[i] * h + sp.cx[i] * h2 + sp.dx[i] * (h2 * h);
-    y = sp.ay[i] + sp.by[i] * h + sp.cy[i] * h2 + sp.dy[i] * (h2 * h);
+    const double h = s - sp.s[i], h2 = h * h, h3 = cube_cr(h);
+    const double bxh = sp.bx[i] * h, cxh = sp.cx[i] * h2, dxh = sp.dx[i] * h3;
+    const double byh = sp.by[i] * h, cyh = sp.cy[i] * h2, dyh = sp.dy[i] * h3;
+    x = ((sp.ax[i] + bxh) + cxh) + dxh;
+    y = ((sp.ay[i] + byh) + cyh) + dyh;
 }
 
 // tangent direction as (cos, sin), curvature (:246) and curvature rate (:265-273)
@@ -143,6 +196,12 @@ FOT_HD void spline_frame(const SplinePt &p, double &cos_r, double &sin_r, double
 // numpy.linspace(a, b, num)[i]
 FOT_HD double linspace_at(double a, double b, int num, int i)
 {
+    // start + i * step with the product and the sum rounded separately, as NumPy forms them: a standing ego sits exactly
+    // on its previous arc length, the 100-sample window is then symmetric about it and samples 49 and 50 TIE up to these
+    // very roundings (a fused multiply-add here moved the result of a reference closed-loop call by 3e-5 m)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     if (num == 1) return a;
     if (i == num - 1) return b;
     const double step = (b - a) / (double)(num - 1);
@@ -170,7 +229,7 @@ FOT_HD ScanBest scan_samples(const SplineView &sp, double x, double y, double s_
         const double s = linspace_at(s_lo, s_hi, num, i);
         double px, py;
         spline_xy(sp, s, px, py);
-        double dist = hypot(x - px, y - py);
+        double dist = hypot_cr(x - px, y - py);
         if (nan_first && isnan(dist)) dist = -INFINITY;
         if (dist < best.dist) { best.dist = dist; best.idx = i; }
     }
@@ -193,11 +252,11 @@ FOT_HD double refine_nearest(const SplineView &sp, double x, double y, double be
         const double s_right = fmin(s_end, best_s + ds);
         double px, py;
         spline_xy(sp, s_left, px, py);
-        const double dist_left = hypot(x - px, y - py);
+        const double dist_left = hypot_cr(x - px, y - py);
         spline_xy(sp, s_right, px, py);
-        const double dist_right = hypot(x - px, y - py);
+        const double dist_right = hypot_cr(x - px, y - py);
         spline_xy(sp, best_s, px, py);
-        const double dist_curr = hypot(x - px, y - py);
+        const double dist_curr = hypot_cr(x - px, y - py);
         if (dist_left < dist_curr && dist_left < dist_right) best_s = s_left;
         else if (dist_right < dist_curr && dist_right < dist_left) best_s = s_right;
         else ds *= 0.5;
@@ -221,7 +280,7 @@ FOT_HD bool frenet_state_at(const SplineView &sp, const fot_ego &ego, double rs,
     const double dx = ego.x - p.x, dy = ego.y - p.y;
     const double cr = cos(rtheta), sr = sin(rtheta);
     const double cross = cr * dy - sr * dx;
-    const double d = copysign(hypot(dx, dy), cross);
+    const double d = copysign(hypot_cr(dx, dy), cross);           // (np.hypot, coordinate_converter.py:65)
     const double delta = ego.yaw - rtheta;
     const double tan_d = tan(delta), cos_d = cos(delta);
     const double omkd = 1.0 - rkappa * d;

@@ -423,3 +423,23 @@ extern "C" int emu_check_tile_tables(const fot_params *params, int32_t *n_tiles_
     }
     return 0;
 }
+
+// hypot_cr / cube_cr (fot_math.hpp) on arrays, for the test that holds them to Python's math.hypot and NumPy's power
+extern "C" void emu_hypot_cr(int n, const double *x, const double *y, double *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = hypot_cr(x[i], y[i]);
+}
+
+extern "C" void emu_cube_cr(int n, const double *h, double *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = cube_cr(h[i]);
+}
+
+extern "C" void emu_spline_xy(int n_knots, const double *coef9n, int n, const double *s, double *x, double *y)
+{
+    SplineView v;
+    v.s = coef9n; v.ax = coef9n + n_knots; v.bx = coef9n + 2 * n_knots; v.cx = coef9n + 3 * n_knots; v.dx = coef9n + 4 * n_knots;
+    v.ay = coef9n + 5 * n_knots; v.by = coef9n + 6 * n_knots; v.cy = coef9n + 7 * n_knots; v.dy = coef9n + 8 * n_knots;
+    v.n = n_knots; v._pad = 0;
+    for (int i = 0; i < n; ++i) spline_xy(v, s[i], x[i], y[i]);
+}

@@ -67,5 +67,8 @@ def dump(root):
     print(f"  instances {r['instances']}, candidates {r['candidates']}, status differences {r['status_differences']}"
           f" (inside the {EPS_BAND:g} band: {r['differences_inside_band']})")
     t = r["value_tolerances"]
-    print(f"  records compared {t['records']}: nearest-point ties (held to the north star's 1e-5) {t['nearest_point_ties']}, "
-          f"curvature samples at a crawl beyond 1e-8 {t['crawl_curvature_samples']}")
+    print(f"  records compared {t['records']}: arc length of the nearest point differing from the oracle's in ANY bit "
+          f"{t['nearest_point_ties']}, curvature samples at a crawl beyond 1e-8 {t['crawl_curvature_samples']}")
+    from oracle.check import crawl_labels
+    for lab, err, sd in crawl_labels[:40]:
+        print(f"    crawl allowance used: {lab}: curvature error {err:.3e} at s_d {sd:.3e}")

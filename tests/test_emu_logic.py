@@ -131,3 +131,67 @@ def test_tile_tables_of_random_lattices(emu):
         assert rc == 0, (rc, kw)
         chosen.append(c.value)
     assert len(chosen) > 150 and sum(chosen) > 0                      # (the grouped cut wins on every lattice tried so far)
+
+
+def test_hypot_and_cube_are_the_references_bit_for_bit(emu):
+    """The nearest-point search decides by comparing math.hypot values of probes micrometres apart, positions from
+    a + b h + c h**2.0 + d h**3.0 (coordinate_converter.py:253-280, cubic_spline.py:70-71).  hypot_cr of the kernel
+    headers must be Python's math.hypot bit for bit (= the correctly rounded hypotenuse), cube_cr the correctly rounded
+    cube, spline_xy the reference's operation order with every operation rounded once -- on operands of the magnitudes
+    the search sees and on near-ties."""
+    import math
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(7)
+    n = 400_000
+    x = np.concatenate([rng.uniform(-200, 200, n), rng.uniform(-2, 2, n), rng.normal(0, 1e-3, n), rng.uniform(-5, 5, n)])
+    y = np.concatenate([rng.uniform(-200, 200, n), rng.uniform(-2, 2, n), rng.normal(0, 1e-3, n),
+                        rng.uniform(-5, 5, n) * 1e-9])
+    # neighbours in the last place: what a tie between two probes looks like
+    x = np.concatenate([x, np.nextafter(x[:n], np.inf), x[:n]])
+    y = np.concatenate([y, y[:n], np.nextafter(y[:n], -np.inf)])
+    out = np.empty_like(x)
+    emu.emu_hypot_cr(len(x), x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    # (np.hypot -- glibc 2.35's hypot -- is NOT the yardstick: it differs from the correctly rounded value, and from
+    #  math.hypot, in about 0.6 % of the calls; the reference's search calls math.hypot)
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    exact = np.array([float((Decimal(float(a)) ** 2 + Decimal(float(b)) ** 2).sqrt()) for a, b in zip(x[:20000], y[:20000])])
+    assert np.array_equal(out[:20000], exact), "hypot_cr is not the correctly rounded hypotenuse"
+    sel = rng.integers(0, len(x), 300_000)
+    want = np.array([math.hypot(float(x[i]), float(y[i])) for i in sel])
+    assert np.array_equal(out[sel], want), "hypot_cr differs from Python's math.hypot"
+    for a, b, w in ((3.0, 4.0, 5.0), (0.0, -2.5, 2.5), (np.inf, np.nan, np.inf), (1e-200, 1e-200, math.hypot(1e-200, 1e-200))):
+        o = np.empty(1)
+        emu.emu_hypot_cr(1, np.array([a]).ctypes.data_as(dp), np.array([b]).ctypes.data_as(dp), o.ctypes.data_as(dp))
+        assert o[0] == w, (a, b, o[0], w)
+    o = np.empty(1)
+    emu.emu_hypot_cr(1, np.array([np.nan]).ctypes.data_as(dp), np.array([1.0]).ctypes.data_as(dp), o.ctypes.data_as(dp))
+    assert np.isnan(o[0])
+    # the cube: correctly rounded.  (NumPy's power on an ARRAY -- what the reference evaluates, cubic_spline.py:70-71 behind
+    # np.atleast_1d -- is a SIMD routine that misses the correctly rounded cube in ~5 % of the calls on an AVX512 host and
+    # differs from glibc's pow(): the reference's own last bit depends on the NumPy build, so no implementation can be
+    # "the reference's" there; the library and the oracle both take the platform-independent value.)
+    from fractions import Fraction
+    h = np.concatenate([rng.uniform(0, 30, 20000), rng.uniform(0, 1, 20000), rng.uniform(0, 1e-3, 20000)])
+    c = np.empty_like(h)
+    emu.emu_cube_cr(len(h), h.ctypes.data_as(dp), c.ctypes.data_as(dp))
+    exact3 = np.array([float(Fraction(float(v)) ** 3) for v in h])             # (Fraction -> float rounds correctly)
+    assert np.array_equal(c, exact3), "cube_cr is not the correctly rounded cube"
+    # the probe position, against the reference's expression evaluated by NumPy on the reference's coefficients
+    from conftest import Golden
+    for name in ("curved_a", "cfg2_s2"):
+        g = Golden(name)
+        k = len(g["sp_s"])
+        pad = lambda a: np.concatenate([a, np.zeros(k - len(a))])
+        coef = np.ascontiguousarray(np.concatenate([g["sp_s"], g["sp_ax"], pad(g["sp_bx"]), g["sp_cx"], pad(g["sp_dx"]),
+                                                    g["sp_ay"], pad(g["sp_by"]), g["sp_cy"], pad(g["sp_dy"])]))
+        s = np.ascontiguousarray(rng.uniform(g["sp_s"][0], g["sp_s"][-1], 20_000))
+        px, py = np.empty_like(s), np.empty_like(s)
+        emu.emu_spline_xy(k, coef.ctypes.data_as(dp), len(s), s.ctypes.data_as(dp), px.ctypes.data_as(dp), py.ctypes.data_as(dp))
+        i = np.clip(np.searchsorted(g["sp_s"], s, side="right") - 1, 0, k - 2)
+        dx = s - g["sp_s"][i]
+        for got, (a_, b_, c_, d_) in ((px, (g["sp_ax"], g["sp_bx"], g["sp_cx"], g["sp_dx"])),
+                                      (py, (g["sp_ay"], g["sp_by"], g["sp_cy"], g["sp_dy"]))):
+            cube = np.array([float(Fraction(float(v)) ** 3) for v in dx])
+            want = a_[i] + b_[i] * dx + c_[i] * dx ** 2.0 + d_[i] * cube                # cubic_spline.py:70-71
+            assert np.array_equal(got, want), name
