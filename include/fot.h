@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define FOT_MAX_NT 128       /* samples per candidate: round(max_t/dt)+1 must be <= 128 (dt = 0.05 s at max_t = 5 s: 101) */
+#define FOT_MAX_NT 256       /* samples per candidate: round(max_t/dt)+1 must be <= 256 (dt = 0.02 s at max_t = 5 s: 251);
+                                also the stride of the 15 path arrays of fot_result -- the library only ever touches the
+                                first round(max_t/dt)+1 entries of each */
 #define FOT_MAX_CIRCLES 8    /* ego footprint circles (footprint.py:26) */
 #define FOT_MAX_TI 64        /* time horizons  int((max_t-min_t)/dt)+1  (min_t = 1 s at max_t = 5 s, dt = 0.1 s: 41) */
 #define FOT_MAX_TV 32        /* terminal speeds per horizon */
@@ -123,6 +125,9 @@ typedef struct fot_result {
     double new_prev_s;           /* value of converter._prev_s after the call */
     double frenet0[6];           /* s, s_d, s_dd, d, d_d, d_dd of the ego (frenet_planner.py:371) */
     double ref0[6];              /* rs, rx, ry, rtheta, rkappa, rdkappa (coordinate_converter.py:308) */
+    /* path arrays: entries [0, n_keep) hold the path, [n_keep, n_total) are written as zero, entries from
+     * n_total = round(max_t/dt)+1 on are NEVER touched (fot_plan_batch hands them back zero; a caller of
+     * fot_plan_batch_device who compares whole records zero-fills its buffer once) */
     double t[FOT_MAX_NT], s[FOT_MAX_NT], s_d[FOT_MAX_NT], s_dd[FOT_MAX_NT], s_ddd[FOT_MAX_NT];
     double d[FOT_MAX_NT], d_d[FOT_MAX_NT], d_dd[FOT_MAX_NT], d_ddd[FOT_MAX_NT];
     double x[FOT_MAX_NT], y[FOT_MAX_NT], yaw[FOT_MAX_NT], v[FOT_MAX_NT], a[FOT_MAX_NT], c[FOT_MAX_NT];

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 import weakref
 
-MAX_NT = 128
+MAX_NT = 256
 MAX_CIRCLES = 8
 MAX_SAMPLES = 64
 

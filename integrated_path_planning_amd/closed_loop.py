@@ -32,7 +32,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 
 from .batch import PlanRequest
-from .data_structures import EgoVehicleState, FrenetPath
+from .data_structures import EgoVehicleState, FrenetPath, PedestrianState
 from .footprint import EgoFootprint
 from .planner import BatchPlanner
 from .prediction import PredictionResampler
@@ -43,7 +43,7 @@ from .state_machine import FailSafeStateMachine, VehicleState
 class ReplayPedestrians:
     """Frame-by-frame replay of [T, N, 2] tracks: step()/get_state() of replay_source.py:31-118."""
 
-    def __init__(self, trajectories, dt: float, velocities=None, goals=None):
+    def __init__(self, trajectories, dt: float, velocities=None, goals=None, ids=None):
         traj = np.asarray(trajectories, dtype=float)
         if traj.ndim != 3 or traj.shape[2] != 2:
             raise ValueError(f"trajectories must be [T, N, 2], got shape {traj.shape}")
@@ -61,6 +61,7 @@ class ReplayPedestrians:
                 vel[-1] = vel[-2]
             self.velocities = vel
         self.goals = np.asarray(goals, dtype=float) if goals is not None else traj[-1].copy()
+        self.ids = np.asarray(ids) if ids is not None else np.arange(self.n_peds)      # (replay_source.py:71-73)
 
     def step(self, ego_state=None, n: int = 1) -> None:
         """Advance n frames (the position holds at the last frame, the clock keeps running; the ego is ignored:
@@ -81,10 +82,10 @@ class ReplayPedestrians:
     def current_velocities(self) -> np.ndarray:
         return self.velocities[self._idx]
 
-    def get_state(self) -> Dict[str, Any]:
-        """positions / velocities / goals / timestamp of the current frame (PedestrianState's fields)."""
-        return dict(positions=self.positions.copy(), velocities=self.current_velocities.copy(), goals=self.goals.copy(),
-                    timestamp=self.time, n_peds=self.n_peds)
+    def get_state(self) -> PedestrianState:
+        """The current frame as the reference's carrier (replay_source.py:98-106): attribute access, ids included."""
+        return PedestrianState(positions=self.positions.copy(), velocities=self.current_velocities.copy(),
+                               goals=self.goals.copy(), ids=self.ids.copy(), timestamp=self.time)
 
 
 class Observer:
@@ -654,12 +655,13 @@ class BatchedClosedLoop:
             i32[:, 28] = who
             return req
 
+        # (view=True: the records are read -- the selected paths copied into the history arena -- before the next call)
         rec0, m = self.engine.loop_plan(requests(everyone, st0, sm.clear_ahead[sel], self.prev_s[sel], np.zeros(n, bool)),
-                                        frame)
+                                        frame, view=True)
         t_pred = 0.0                                                  # (inside the one call: not separable)
         clearance, clearance_ahead = m["clearance"].copy(), m["clearance_ahead"].copy()
         self.last_clearance[sel] = clearance_ahead
-        plan = lambda *a: self.engine.loop_plan(requests(*a))[0]
+        plan = lambda *a: self.engine.loop_plan(requests(*a), view=True)[0]
         return self._finish_step(sel, off, pos, vel, None, pred_src, t_pred, t0, plan, st0, n_lvl, everyone, speed,
                                  clearance, clearance_ahead, lambda new_ego: self.engine.loop_observe_begin(new_ego, self.goal_prev_s[sel]),
                                  first=rec0)

@@ -41,6 +41,13 @@ struct DevBuf {
         return hipSuccess;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    // the same, and a block that grew starts out all zero (record blocks: entries past n_total are never written)
+    hipError_t ensure_zeroed(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        hipError_t e = ensure(bytes);
+        return e != hipSuccess ? e : hipMemset(p, 0, cap);
+    }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -56,6 +63,7 @@ struct PinnedBuf {
         // blocks while the host polls them (wait_records)
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped);
         if (e != hipSuccess) { p = nullptr; return e; }
+        std::memset(p, 0, want);                                  // (record blocks: entries past n_total are never written)
         cap = want;
         return hipSuccess;
     }
@@ -158,6 +166,7 @@ struct fot_handle {
     int lanes_used = 0;                      // lanes of the most recent plan call
     DevBuf dUserStatic, dUserDyn, dOut;      // device copies for the host-pointer entry point
     PinnedBuf hSmallIn, hSmallOut;           // ... and, for small calls, pinned host blocks the kernels use directly
+    PinnedBuf hRecOut;                       // ... the records of a small plan call (a block of its own: zero past n_total)
     DevBuf dTmpA, dTmpB, dTmpC, dTmpD;
     LoopState loop;
     bool last_valid = false;
@@ -360,7 +369,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     HIP_TRY(h, w.dCost.ensure(sizeof(double) * slots));
     HIP_TRY(h, w.dParts.ensure(sizeof(TilePart) * (size_t)std::max(L.n_tiles, 1)));
     HIP_TRY(h, w.dStatus.ensure(slots));
-    HIP_TRY(h, w.dKeep.ensure(slots));
+    HIP_TRY(h, w.dKeep.ensure(sizeof(uint16_t) * slots));
     const size_t n_ent = (size_t)L.n_entries + 64;              // slack: the scalar prefetch reads one chunk ahead
     HIP_TRY(h, w.dEntCnt.ensure(sizeof(int32_t) * (size_t)P.n_total * (size_t)L.n_inst));
     HIP_TRY(h, w.dEnt32.ensure(sizeof(f2) * n_ent));
@@ -385,7 +394,7 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     const SplineView sv = spline_view(h);
     CandArrays ca;
     ca.cost = w.dCost.as<double>(); ca.parts = w.dParts.as<TilePart>();
-    ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint8_t>();
+    ca.status = w.dStatus.as<uint8_t>(); ca.keep = w.dKeep.as<uint16_t>();
     if (sync_caller && h->done_seq_armed) { ca.done_flag = (int32_t *)h->hDone.p; ca.done_seq = h->done_seq; }
 
     EntryArrays ea;
@@ -663,7 +672,7 @@ void destroy_handle(fot_handle *h)
                      };
     for (DevBuf *b : bufs) b->release();
     for (Workspace &w : h->ws) w.release();
-    h->hSmallIn.release(); h->hSmallOut.release(); h->hDone.release();
+    h->hSmallIn.release(); h->hSmallOut.release(); h->hRecOut.release(); h->hDone.release();
     h->loop.release();
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -955,7 +964,7 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
     bool metrics = false;
     if (frame) {
         const int n = frame->n_episodes;
-        if (n < 0 || (n > 0 && !frame->ped_off)) return fail(h, FOT_ERR_INVALID, "frame: n_episodes / ped_off");
+        if (n < 0 || !frame->ped_off) return fail(h, FOT_ERR_INVALID, "frame: n_episodes / ped_off (one offset even for no episode)");
         L.have_frame = false;
         for (int i = 0; i < n; ++i)
             if (frame->ped_off[i + 1] < frame->ped_off[i] || frame->ped_off[0] != 0)
@@ -1214,7 +1223,7 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
     if (st_bytes + dy_bytes <= 2 * SMALL_CALL_BYTES && out_bytes <= 8 * SMALL_CALL_BYTES) {   // (records stream out as instances finish)
         const size_t dy_off = align256(st_bytes);
         HIP_TRY(h, h->hSmallIn.ensure(dy_off + dy_bytes + 256));
-        HIP_TRY(h, h->hSmallOut.ensure(out_bytes));
+        HIP_TRY(h, h->hRecOut.ensure(out_bytes));
         char *in = (char *)h->hSmallIn.p;
         if (st_bytes) std::memcpy(in, batch->static_xy, st_bytes);
         if (dy_bytes) std::memcpy(in + dy_off, batch->dyn_xy, dy_bytes);
@@ -1223,16 +1232,16 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
         void *stage = nullptr;
         if (dy_bytes && !no_stage) { HIP_TRY(h, h->dUserDyn.ensure(dy_bytes + 256)); stage = h->dUserDyn.p; }
         arm_records(h, batch->n_inst);
-        rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hSmallOut.p, h->stream, true, stage);
+        rc = enqueue_plan(h, *batch, in, in + dy_off, (fot_result *)h->hRecOut.p, h->stream, true, stage);
         if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
         rc = wait_records(h, batch->n_inst, h->stream);
         if (rc != FOT_OK) return rc;
-        std::memcpy(out, h->hSmallOut.p, out_bytes);
+        std::memcpy(out, h->hRecOut.p, out_bytes);
         return FOT_OK;
     }
     HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
     HIP_TRY(h, h->dUserDyn.ensure(std::max<size_t>(dy_bytes, 16)));
-    HIP_TRY(h, h->dOut.ensure(sizeof(fot_result) * (size_t)batch->n_inst));
+    HIP_TRY(h, h->dOut.ensure_zeroed(sizeof(fot_result) * (size_t)batch->n_inst));
     if (st_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserStatic.p, batch->static_xy, st_bytes, hipMemcpyHostToDevice, h->stream));
     if (dy_bytes) HIP_TRY(h, hipMemcpyAsync(h->dUserDyn.p, batch->dyn_xy, dy_bytes, hipMemcpyHostToDevice, h->stream));
     rc = enqueue_plan(h, *batch, h->dUserStatic.p, h->dUserDyn.p, h->dOut.as<fot_result>(), h->stream);
@@ -1306,13 +1315,14 @@ int fot_debug_candidates(fot_handle *h, int32_t inst, int32_t cap, double *cost,
     const int n = S.n_cand;
     const int m = n < cap ? n : cap;
     if (m <= 0) return n;
-    std::vector<uint8_t> st8((size_t)m), kp8((size_t)m);
+    std::vector<uint8_t> st8((size_t)m);
+    std::vector<uint16_t> kp16((size_t)m);
     if (cost) HIP_TRY(h, hipMemcpy(cost, w->dCost.as<double>() + D.cand_off, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(st8.data(), w->dStatus.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(kp8.data(), w->dKeep.as<uint8_t>() + D.cand_off, (size_t)m, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(kp16.data(), w->dKeep.as<uint16_t>() + D.cand_off, sizeof(uint16_t) * (size_t)m, hipMemcpyDeviceToHost));
     for (int i = 0; i < m; ++i) {
         if (status) status[i] = st8[i];
-        if (keep) keep[i] = kp8[i];
+        if (keep) keep[i] = kp16[i];
         if (n_t) {
             if (i < D.n_grid) n_t[i] = h->P.ti[i / (D.n_tv * h->P.n_di)].n_t;
             else n_t[i] = h->P.n_total;

@@ -17,7 +17,8 @@ struct TilePart {
 
 struct CandArrays {
     double *cost;                       // per candidate, for fot_debug_candidates: cost, final status, kept samples
-    uint8_t *status, *keep;
+    uint8_t *status;
+    uint16_t *keep;                     // (up to FOT_MAX_NT = 256 kept samples)
     TilePart *parts;                    // [n_tiles of the batch]
     int32_t *done_flag = nullptr;       // pinned, one per instance, or nullptr: raised to done_seq behind the instance's record
     int32_t done_seq = 0;

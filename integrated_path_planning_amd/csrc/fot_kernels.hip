@@ -425,7 +425,7 @@ struct EvalKernArgs {
     int row_budget, lds_knots, ablate, n_inst, max_tiles;
     const int32_t *tile_cand0, *tile_n;
     const TileStep *wave_rng; const f2 *ent32; const d2 *ent64; const uint8_t *ent_sid;
-    double *cand_cost; uint8_t *cand_status, *cand_keep;      // per candidate: for fot_debug_candidates only
+    double *cand_cost; uint8_t *cand_status; uint16_t *cand_keep;   // per candidate: for fot_debug_candidates only
     TilePart *parts;                                 // per tile: what its wave found (tile_done)
     fot_result *out; int32_t *inst_done;             // selection by the wave that finishes an instance's last tile
     int32_t *done_flag; int32_t done_seq;            // host-visible flag per record (CandArrays::done_flag)
@@ -883,7 +883,7 @@ __device__ __forceinline__ void evaluate_tile(const DevParams *__restrict__ Pp, 
         const EvalKernArgs &KA = eval_kernargs();
         KA.cand_cost[slot] = r.cost;
         KA.cand_status[slot] = (uint8_t)st_final;
-        KA.cand_keep[slot] = (uint8_t)r.keep;
+        KA.cand_keep[slot] = (uint16_t)r.keep;
         my_keep = r.keep;
         if (st_final == FOT_ST_OK) { mine.dist = r.cost; mine.idx = cand0 + lane; }
     }
@@ -932,10 +932,20 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
     const InstDesc &D = KA.desc[inst];
     const InstState &S = KA.state[inst];
     fot_result &R = KA.out[inst];
-    // the record starts out all zero (this wave alone writes it: program order is enough)
-    for (int i = lane; i < (int)(sizeof(fot_result) / sizeof(unsigned long long)); i += WAVE)
-        ((unsigned long long *)&R)[i] = 0ull;
+    // The record's header starts out all zero, and so do the first n_total entries of its 15 path arrays wherever no
+    // path sample lands (this wave alone writes the record: program order is enough).  Entries from n_total on are never
+    // touched: the arrays' stride is FOT_MAX_NT whatever the planner's horizon, the work here is not.
+    constexpr int HEADER_WORDS = (int)(offsetof(fot_result, t) / sizeof(unsigned long long));
+    static_assert(offsetof(fot_result, t) % sizeof(unsigned long long) == 0, "the header is zeroed in 8-byte words");
+    if (lane < HEADER_WORDS) ((unsigned long long *)&R)[lane] = 0ull;
+    static_assert(HEADER_WORDS <= WAVE, "one word per lane");
+    const auto zero_samples = [&](int k0) {                       // entries [k0, n_total) of every array
+        for (int k = k0 + lane; k < P.n_total; k += WAVE)
+#pragma unroll
+            for (int f = 0; f < 15; ++f) R.t[f * FOT_MAX_NT + k] = 0.0;
+    };
     if (!S.c2f_ok) {
+        zero_samples(0);
         if (lane == 0) {
             R.status = FOT_PLAN_C2F_FAILED; R.best_index = -1; R.n_cand = 0; R.n_keep = 0;
             R.cost = INFINITY; R.stats_valid = 0;
@@ -980,6 +990,7 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
         for (int i = 0; i < 6; ++i) { R.frenet0[i] = S.frenet0[i]; R.ref0[i] = S.ref0[i]; }
     }
     if (best.idx < 0) {
+        zero_samples(0);
         if (lane == 0) { R.n_keep = 0; R.new_last_kappa = D.ego.last_kappa; }
         return;
     }
@@ -1001,6 +1012,7 @@ __device__ __forceinline__ void select_instance_wave(int inst, int lane)
         if (k == 1) R.new_last_kappa = o[14];                              // frenet_planner.py:301-302
     }
 #endif
+    zero_samples(keep);
     if (lane == 0) {
         R.n_keep = keep;
         if (keep <= 1) R.new_last_kappa = D.ego.last_kappa;
@@ -1032,10 +1044,19 @@ __device__ __forceinline__ void tile_done(int inst, int tile, int lane, const Ti
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores, before the count
     int last = 0;
+    // (-DFOT_SAFE_SELECT: the textbook form -- an acquire-release count at agent scope, i.e. an L2 write-back before and
+    //  an invalidate behind it in EVERY wave: +45 % on the launch when measured; the shipped form relies on the sc1
+    //  stores / loads above and below, which scripts/isa_check_async.py verifies in the ISA of every build)
+#ifdef FOT_SAFE_SELECT
+    constexpr int COUNT_ORDER = __ATOMIC_ACQ_REL;
+#else
+    constexpr int COUNT_ORDER = __ATOMIC_RELAXED;
+#endif
     if (lane == 0)
-        last = __hip_atomic_fetch_add(&KA.inst_done[inst], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+        last = __hip_atomic_fetch_add(&KA.inst_done[inst], 1, COUNT_ORDER, __HIP_MEMORY_SCOPE_AGENT)
                == KA.desc[inst].n_tiles - 1 ? 1 : 0;
     last = __builtin_amdgcn_readfirstlane(last);
+    asm volatile("" ::: "memory");                                // no load of the partials may be hoisted above the count
     if (!last) return;
     select_instance_wave(inst, lane);
     record_written(inst, lane);

@@ -8,7 +8,7 @@ Same field names and behaviour as the reference's planner-facing types
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -55,6 +55,38 @@ def _len(seq) -> int:
         return len(seq)
     except TypeError:
         return 0
+
+
+@dataclass
+class PedestrianState:
+    """What a pedestrian source's ``get_state()`` returns (reference: data_structures.py:66-109): positions,
+    velocities, goals [n_peds, 2], ids [n_peds] (0..n-1 when not given), timestamp."""
+    positions: np.ndarray
+    velocities: np.ndarray
+    goals: np.ndarray
+    ids: Optional[np.ndarray] = None
+    timestamp: float = 0.0
+
+    def __post_init__(self):
+        for name in ("positions", "velocities", "goals"):
+            arr = getattr(self, name)
+            if arr.ndim != 2 or arr.shape[1] != 2:
+                raise AssertionError(f"{name} must be (n_peds, 2)")
+        if not (len(self.positions) == len(self.velocities) == len(self.goals)):
+            raise AssertionError("All arrays must have same number of pedestrians")
+        if self.ids is None:
+            self.ids = np.arange(self.n_peds)
+
+    @property
+    def n_peds(self) -> int:
+        return int(self.positions.shape[0])
+
+    @property
+    def pedestrians(self) -> np.ndarray:
+        return self.positions
+
+    def to_social_force_format(self) -> np.ndarray:
+        return np.hstack([self.positions, self.velocities, self.goals])
 
 
 @dataclass

@@ -16,10 +16,15 @@ class EgoFootprint:
         """n equal circles, each circumscribing one L/n x W slice of the rectangle."""
         if n_circles < 1:
             raise ValueError(f"n_circles must be >= 1, got {n_circles}")
-        seg = vehicle_length / n_circles
-        offsets = -vehicle_length / 2 + seg / 2 + seg * np.arange(n_circles)
-        return cls(offsets=offsets, radius=float(np.hypot(seg / 2, vehicle_width / 2)))
+        half_slice = 0.5 * vehicle_length / n_circles             # half the length of one slice
+        # centre k sits in the middle of slice k, counted from the rear end at -L/2: -L/2 + (2k + 1) half_slice
+        k = np.arange(n_circles)
+        return cls(offsets=(2 * k + 1) * half_slice - 0.5 * vehicle_length,
+                   radius=float(np.sqrt(half_slice ** 2 + (0.5 * vehicle_width) ** 2)))
 
     def circle_centers(self, x: float, y: float, yaw: float) -> np.ndarray:
-        direction = np.array([np.cos(yaw), np.sin(yaw)])
-        return np.array([x, y]) + self.offsets[:, None] * direction
+        """[n_circles, 2]: the centres of a vehicle at (x, y) heading yaw."""
+        out = np.empty((len(self.offsets), 2))
+        out[:, 0] = x + self.offsets * np.cos(yaw)
+        out[:, 1] = y + self.offsets * np.sin(yaw)
+        return out

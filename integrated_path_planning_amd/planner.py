@@ -323,15 +323,17 @@ class BatchPlanner:
         pts = np.ascontiguousarray(np.empty((0, 2)) if points is None else points, dtype=np.float64).reshape(-1, 2)
         _abi.check(self._h, self._lib.fot_loop_set_static(self._h, len(pts), _addr(pts) if len(pts) else None))
 
-    def loop_plan(self, requests: np.ndarray, frame: Optional[dict] = None):
+    def loop_plan(self, requests: np.ndarray, frame: Optional[dict] = None, view: bool = False):
         """``fot_loop_plan``: constant-velocity prediction of the frame's pedestrians into the handle's own tensor,
         safety metrics of the current ego states, and the requests' plan() calls against that tensor -- one
         synchronisation.  ``requests``: structured [r] of ``LOOP_REQUEST_DT``.  ``frame`` (None = the tensor of the
         previous call): ped_off [n+1], ped_pos / ped_vel [sum P, 2], obs_last / obs_prev [sum P, 2] float32 or None
         (predictor not ready), prepend [n] bool, ego [n, 4] (x, y, yaw, v) or None, staleness, pred_len, rp
         (``_abi.ResampleParams``), ego_radius, ped_radius, use_footprint.
-        Returns (records, metrics): the records as a structured VIEW of the handle's pinned block (valid until the next
-        ``loop_plan``: copy what outlives it) and the metrics [n] of ``SAFETY_DT`` (None without a frame or egos)."""
+        Returns (records, metrics): the records as a structured array of ``RESULT_DT`` -- a COPY by default; with
+        ``view=True`` a view of the handle's pinned block, valid only until the next ``loop_plan`` or ``close()`` on this
+        planner (the lock-step driver reads it at once and keeps nothing) -- and the metrics [n] of ``SAFETY_DT`` (None
+        without a frame or egos)."""
         req = np.ascontiguousarray(requests, dtype=self.LOOP_REQUEST_DT)
         r = int(req.shape[0])
         fr_addr, metrics, keep = None, None, []
@@ -370,6 +372,8 @@ class BatchPlanner:
         if r and rec_ptr.value:
             buf = (C.c_char * (r * _abi.RESULT_BYTES)).from_address(rec_ptr.value)
             records = np.frombuffer(buf, dtype=self.RESULT_DT, count=r)
+            if not view:
+                records = records.copy()
         else:
             records = np.zeros(0, dtype=self.RESULT_DT)
         return records, (metrics[:n] if metrics is not None else None)
@@ -643,13 +647,33 @@ class FrenetPlanner:
         self.converter = _NearestPointState(reference_path)
         self._last_kappa = 0.0
         self.last_check_stats = None
-        self._engine = BatchPlanner(
-            reference_path=reference_path, device=int(kwargs.get("device", -1)),
-            max_speed=max_speed, max_accel=max_accel, max_curvature=max_curvature, dt=dt, d_road_w=d_road_w,
-            max_road_width=max_road_width, robot_radius=robot_radius, obstacle_radius=obstacle_radius, min_t=min_t,
-            max_t=max_t, d_t_s=d_t_s, max_lat_accel=self.max_lat_accel, k_j=self.k_j, k_t=self.k_t, k_d=self.k_d,
-            k_s_dot=self.k_s_dot, k_lat=self.k_lat, k_lon=self.k_lon, chance_epsilon=self.chance_epsilon,
-            collision_margin_inflation=self.collision_margin_inflation, footprint=self.footprint)
+        # The reference plans any lattice and its plan() never raises (frenet_planner.py:266-268: a failure is `None`).
+        # The library has capacities (include/fot.h FOT_MAX_*: 256 samples per candidate, 64 horizons, 32 terminal speeds,
+        # 32 brake horizons, 8 footprint circles, 64 prediction samples); a configuration or a call beyond them keeps the
+        # reference's contract: a warning once, plan() returns None with last_check_stats None, and `last_error` says why.
+        self.last_error: Optional[str] = None
+        self._warned = False
+        try:
+            self._engine = BatchPlanner(
+                reference_path=reference_path, device=int(kwargs.get("device", -1)),
+                max_speed=max_speed, max_accel=max_accel, max_curvature=max_curvature, dt=dt, d_road_w=d_road_w,
+                max_road_width=max_road_width, robot_radius=robot_radius, obstacle_radius=obstacle_radius, min_t=min_t,
+                max_t=max_t, d_t_s=d_t_s, max_lat_accel=self.max_lat_accel, k_j=self.k_j, k_t=self.k_t, k_d=self.k_d,
+                k_s_dot=self.k_s_dot, k_lat=self.k_lat, k_lon=self.k_lon, chance_epsilon=self.chance_epsilon,
+                collision_margin_inflation=self.collision_margin_inflation, footprint=self.footprint)
+        except _abi.FotError as e:
+            if e.code != _abi.ERR_UNSUPPORTED:
+                raise
+            self._engine = None
+            self._unsupported(str(e))
+
+    def _unsupported(self, msg: str) -> None:
+        self.last_error = msg
+        if not self._warned:
+            import warnings
+            warnings.warn(f"FrenetPlanner: beyond the library's capacities, plan() returns None ({msg})", RuntimeWarning,
+                          stacklevel=3)
+            self._warned = True
 
     @property
     def engine(self) -> BatchPlanner:
@@ -672,9 +696,18 @@ class FrenetPlanner:
         """Same contract as the reference (frenet_planner.py:227-304): best path or None; never
         raises on "no path"; updates last_check_stats, _last_kappa and the nearest-point cache."""
         self.last_check_stats = None
+        if self._engine is None:                                   # (a configuration beyond the library's capacities)
+            return None
         req = self._request(ego_state, static_obstacles, dynamic_obstacles, target_speed, constraint_overrides,
                             dynamic_obstacles_distribution, max_stop_distance)
-        res = self._engine.plan_batch([req])
+        try:
+            res = self._engine.plan_batch([req])
+        except _abi.FotError as e:                                 # (a call beyond them: more prediction samples than 64, ...)
+            if e.code != _abi.ERR_UNSUPPORTED:
+                raise
+            self._unsupported(str(e))
+            return None
+        self.last_error = None
         rec = res.records[0]
         if not np.isnan(rec.new_prev_s):
             self.converter._prev_s = float(rec.new_prev_s)

@@ -80,6 +80,10 @@ def assert_record_matches_oracle(rec, want, tol=TIGHT, label=""):
             tolerance_stats["crawl_curvature_samples"] += n_loose
             if n_loose:
                 crawl_labels.append((label, float(err.max()), float(sd[int(err.argmax())])))
+                import os
+                if os.environ.get("FOT_CRAWL_LOG"):                  # (sweeps under pytest-xdist: the workers' reports are not shown)
+                    with open(os.environ["FOT_CRAWL_LOG"], "a") as f:
+                        f.write(f"{label}\t{err.max():.3e}\t{sd[int(err.argmax())]:.3e}\n")
             assert np.all(ok), f"{label} c: max error {err.max():.3e} at sample {int(err.argmax())} (s_d {sd[int(err.argmax())]:.3e})"
         else:
             np.testing.assert_allclose(got, exp, rtol=tol, atol=tol, err_msg=f"{label} {f}")

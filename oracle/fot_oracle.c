@@ -482,10 +482,16 @@ static void eval_lat(const quintic *q, int n, double dt, cand_path *cp)
     }
 }
 
-/* np.sum(np.square(a)) for n <= 128: NumPy's pairwise kernel = 8 strided partial
- * sums, combined pairwise, remainder added serially */
+/* np.sum(np.square(a)): NumPy's pairwise summation -- up to 128 elements 8 strided partial sums, combined pairwise,
+ * remainder added serially; longer arrays are halved (the first half rounded down to a multiple of 8) and the two
+ * halves' sums added */
 static double np_sum_sq(const double *a, int n)
 {
+    if (n > 128) {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_sum_sq(a, n2) + np_sum_sq(a + n2, n - n2);
+    }
     if (n < 8) {
         double r = 0.0;   /* NumPy starts from -0.0 semantics irrelevant here */
         for (int i = 0; i < n; ++i) r += a[i] * a[i];

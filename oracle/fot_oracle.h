@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_NT 128         /* samples per candidate (round(max_t/dt)+1) */
+#define ORC_MAX_NT 256         /* samples per candidate (round(max_t/dt)+1) */
 #define ORC_MAX_CIRCLES 8
 
 /* candidate status == index into stats[] (order of the reference's path_dict,

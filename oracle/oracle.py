@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libfot_oracle.so")
 
-MAX_NT = 128
+MAX_NT = 256
 MAX_CIRCLES = 8
 
 STATUS_NAMES = [

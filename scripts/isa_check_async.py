@@ -134,6 +134,44 @@ def analyse(name, body, callee_regs):
     return n_loads, findings
 
 
+def check_selection_handoff(name, body):
+    """The fence-free selection (fot_kernels.hip tile_done / select_instance_wave): a wave leaves its tile's partial
+    result with agent-coherent stores (`sc1`: write-through the XCD's L2), waits for them (`s_waitcnt vmcnt(0)`), counts
+    itself with an agent-scope atomic, and the wave that completes the count reads all partials with agent-coherent loads
+    (`sc1`) -- issued behind the wait that returns the atomic.  Correct only if the ISA really looks like that: checked
+    here on every build instead of trusted.  Returns a list of problems."""
+    ins = [l.split(';')[0].strip() for l in body]
+    ins = [l for l in ins if l and not l.startswith('.') and not l.endswith(':')]
+    atom = [k for k, l in enumerate(ins) if l.startswith('global_atomic_add')]
+    if not atom:
+        return ['no global_atomic_add (the per-instance tile counter) found']
+    probs = []
+    for a in atom:
+        # the partial's stores: the run of global_store* right before the wait in front of the atomic
+        w = max((k for k in range(a) if ins[k].startswith('s_waitcnt') and 'vmcnt(0)' in ins[k]), default=None)
+        stores = [k for k in range(max(0, (w or a) - 40), w or a) if ins[k].startswith('global_store')]
+        if w is None or not stores:
+            probs.append('no s_waitcnt vmcnt(0) between the partial-result stores and the tile counter')
+            continue
+        if any(ins[k].startswith(('global_', 'buffer_', 'flat_')) for k in range(w + 1, a)):
+            probs.append('a memory instruction sits between the wait for the partial-result stores and the tile counter')
+        if len(stores) < 11:
+            probs.append(f'only {len(stores)} stores in front of the tile counter (a TilePart is 11)')
+        for k in stores[-11:]:
+            if ' sc1' not in ins[k]:
+                probs.append(f'partial-result store without sc1: {ins[k]}')
+        # behind the atomic: its wait, then the selecting wave's loads
+        wa = next((k for k in range(a + 1, len(ins)) if ins[k].startswith('s_waitcnt') and 'vmcnt(0)' in ins[k]), None)
+        loads = [k for k in range(a + 1, min(len(ins), a + 400)) if ins[k].startswith('global_load') and ' sc1' in ins[k]]
+        if wa is None:
+            probs.append('the tile counter is never waited for')
+        elif any(k < wa for k in loads):
+            probs.append('an agent-coherent load of a partial result is issued before the tile counter has returned')
+        if len(loads) < 11:
+            probs.append(f'only {len(loads)} agent-coherent loads behind the tile counter (the selecting wave reads 11 fields per tile)')
+    return probs
+
+
 def metadata(t):
     out = {}
     for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.wavefront_size', t, re.S):
@@ -170,6 +208,10 @@ def main(argv):
         for k, code, why in findings[:12]:
             print(f"   instruction {k}: {code}   ({why})")
         bad_total += len(findings)
+        if '--no-handoff-check' not in argv:
+            for msg in check_selection_handoff(m.group(1), body):
+                print(f"   {m.group(1)}: selection hand-off: {msg}")
+                bad_total += 1
         if not allow_scratch and (md.get('vspill', 0) or md.get('scratch', 0)):
             print(f"   {m.group(1)} spills vector registers / uses scratch memory: not a build to ship")
             bad_total += 1

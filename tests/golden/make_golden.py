@@ -225,6 +225,13 @@ def build_cases():
         dyn=inst.dist[0].astype(np.float64), target_speed=6.0)
     add("dt005_stop", "straight", dict(syn.CONFIG3_PLANNER, dt=0.05, max_road_width=3.0), [30.0, 0.2, 0.0, 3.0, -0.5],
         max_stop=6.0, target_speed=0.0, overrides=dict(max_accel=6.0, max_lat_accel=6.0))
+    # --- round 4: 251 samples per candidate, 51 horizons (dt = 0.02 s; FOT_MAX_NT 256)
+    inst = syn.config3_instance(15, S=3, P=12, T=251, dt=0.02)
+    add("dt002_dist", "straight", dict(syn.CONFIG3_PLANNER, dt=0.02, max_road_width=2.0), inst.ego,
+        dist=inst.dist.astype(np.float64))
+    add("dt002_curved_stop", "curved", dict(SCEN03, dt=0.02, max_curvature=1.0, max_road_width=1.5), [-20.0, 2.4, 0.0, 3.5, 0.1],
+        target_speed=0.0, max_stop=9.0, static=np.array([[-8.0, 1.5], [-1.0, -1.0]]), prev_s=9.0,
+        overrides=dict(max_accel=6.0))
     return cases
 
 
@@ -258,6 +265,49 @@ def build_random_cases(n, seed0=7000):
     return cases
 
 
+def build_fuzz_cases(seed_inst):
+    """Instances of the GPU fuzz test itself (tests/test_gpu_fuzz.py run_seed: seed -> path, planner arguments, six
+    requests) put before the REFERENCE: the cases a sweep singled out -- `crawl_<seed>_<inst>`: the library's curvature
+    differs from the oracle's by more than 1e-8 at a sample just above the EPS_S_DOT gate -- so that the reference says
+    which side, if either, holds its value."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as fz
+    from integrated_path_planning_amd.footprint import EgoFootprint
+    from oracle import oracle as orc
+    cases = []
+    for seed, inst in seed_inst:
+        rng = np.random.default_rng(1000 + seed)
+        wx, wy = fz.random_path(rng)
+        drawn = {}
+        orig = EgoFootprint.multi_circle.__func__
+
+        def recording(cls, length, width, n, _orig=orig, _d=drawn):
+            _d.update(length=float(length), width=float(width), n=int(n))
+            return _orig(cls, length, width, n)
+        EgoFootprint.multi_circle = classmethod(recording)
+        try:
+            kw = fz.random_planner_kwargs(rng)
+        finally:
+            EgoFootprint.multi_circle = classmethod(orig)
+        fp = dict(drawn) if kw.pop("footprint", None) is not None else None
+        sp = orc.Spline(wx, wy)
+        rq = None
+        for _ in range(inst + 1):
+            rq = fz.random_request(rng, sp, kw, False)
+        for arr in (rq.static, rq.dyn, rq.dist):
+            assert arr is None or not np.isnan(arr).any(), "a NaN track: not a case for this generator"
+        cases.append(dict(name=f"crawl_{seed}_{inst}", path=dict(wx=[float(v) for v in wx], wy=[float(v) for v in wy]),
+                          planner=kw, ego=[rq.x, rq.y, rq.yaw, rq.v, rq.a], target_speed=rq.target_speed,
+                          overrides=rq.overrides, max_stop=rq.max_stop_distance, prev_s=rq.prev_s,
+                          last_kappa=rq.last_kappa, footprint=fp,
+                          static=np.empty((0, 2)) if rq.static is None else rq.static, dyn=rq.dyn, dist=rq.dist))
+    return cases
+
+
+# what the 36 000-seed sweep of round 4 flagged (profiles/r04_fuzz36000.log, gpurun_out/r04_crawl.txt)
+CRAWL_CASES = [(17857, 3), (19368, 3)]
+
+
 def run_case(ref, case, out_dir):
     FrenetPlanner, CubicSpline2D, EgoVehicleState, EgoFootprint = ref
     wx, wy = waypoints(case["path"])
@@ -286,7 +336,7 @@ def run_case(ref, case, out_dir):
     # --- the stages of plan() (frenet_planner.py:259-304), run one by one to capture per-candidate data
     planner.last_check_stats = None
     fs = planner._cartesian_to_frenet_state(ego)
-    if fs is None and case["name"].startswith("rnd_"):
+    if fs is None and case["name"].startswith(("rnd_", "crawl_")):
         print(case["name"], "skipped: the conversion to the Frenet frame fails")
         return
     assert fs is not None
@@ -327,7 +377,8 @@ def run_case(ref, case, out_dir):
     probes = sorted(set(i for i in [0, 1, n // 3, n // 2, (2 * n) // 3, n - 8, n - 1,
                                     int(out["best_index"])] if 0 <= i < n))
     out["probe_idx"] = np.array(probes, dtype=np.int32)
-    width = 64 if max(len(fp_list[i].t) for i in probes) <= 64 else 128      # (64: the fixtures of rounds 1-2, unchanged)
+    longest = max(len(fp_list[i].t) for i in probes)
+    width = 64 if longest <= 64 else 128 if longest <= 128 else 256         # (64 / 128: the fixtures of rounds 1-3, unchanged)
     for f in FIELDS:
         arr = np.full((len(probes), width), np.nan)
         for r, i in enumerate(probes):
@@ -397,6 +448,10 @@ def main():
     ref = import_reference(args.ref)
     if args.only == "time_cache":
         run_time_cache(ref, HERE)
+        return
+    if args.only == "crawl":                         # the fuzz instances a sweep flagged
+        for case in build_fuzz_cases(CRAWL_CASES):
+            run_case(ref, case, HERE)
         return
     if args.only == "rnd":                           # the random block alone (--random N of them)
         for case in build_random_cases(args.random):

@@ -82,7 +82,7 @@ def test_create_fails_loudly_without_gpu_or_succeeds_with_one():
 def test_create_rejects_unsupported_configurations():
     lib = _abi.lib()
     h = C.c_void_p()
-    for kw, code in ((dict(dt=0.02), _abi.ERR_UNSUPPORTED),          # 251 samples > FOT_MAX_NT (128)
+    for kw, code in ((dict(dt=0.01), _abi.ERR_UNSUPPORTED),          # 501 samples > FOT_MAX_NT (256)
                      (dict(dt=-1.0), _abi.ERR_INVALID),
                      (dict(dt=0.1, min_t=0.5, max_t=7.0), _abi.ERR_UNSUPPORTED)):   # 66 horizons > FOT_MAX_TI (64)
         p = make_params(**kw)
@@ -90,7 +90,8 @@ def test_create_rejects_unsupported_configurations():
         assert lib.fot_last_error(None)
     # what rounds 1-2 refused: 101 samples per candidate (dt = 0.05 s), 41 horizons (min_t = 1 s) -- the reference has
     # no such limit (frenet_planner.py:397-398, 586-617); without a GPU the call gets as far as the device
-    for kw in (dict(dt=0.05), dict(dt=0.1, min_t=1.0, max_t=5.0), dict(dt=0.05, min_t=2.0, max_t=5.0)):
+    # ... and round 4: 251 samples per candidate (dt = 0.02 s), 51 horizons
+    for kw in (dict(dt=0.05), dict(dt=0.1, min_t=1.0, max_t=5.0), dict(dt=0.05, min_t=2.0, max_t=5.0), dict(dt=0.02)):
         p = make_params(**kw)
         rc = lib.fot_create(C.byref(p), -1, C.byref(h))
         assert rc in (_abi.OK, _abi.ERR_HIP), (kw, lib.fot_last_error(None))

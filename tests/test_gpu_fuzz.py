@@ -140,7 +140,8 @@ def run_seed(seed, n_inst, dense):
     reqs = [random_request(rng, sp, kw, dense) for _ in range(n_inst)]
     wants = [oracle_plan_for_request(orc, params, sp, rq, table=True) for rq in reqs]
     # the oracle once, the library under every evaluation kernel it ships (FOT_FUZZ_SEGMENTS: that segment count only)
-    for path in (EVAL_PATHS if not FORCE_SEGMENTS else ("forced",)):
+    paths = tuple(p_ for p_ in os.environ.get("FOT_FUZZ_PATHS", "").split(",") if p_) or EVAL_PATHS   # (sweeps: a subset)
+    for path in (paths if not FORCE_SEGMENTS else ("forced",)):
         if FORCE_SEGMENTS:
             bp.set_eval_segments(FORCE_SEGMENTS)
         else:

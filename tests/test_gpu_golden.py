@@ -51,9 +51,21 @@ def test_golden_case(golden, eval_path):
         assert len(got) == len(exp), f
         if f == "yaw":
             np.testing.assert_allclose(wrap_angle(got - exp), 0.0, atol=TIGHT)
+        elif f == "c":
+            # curvature at a crawl (|s_d| < 0.05: the reference's own value moves with the last bit of s_d there; the
+            # `crawl_*` goldens are such fuzz instances put before the reference -- oracle/check.py CRAWL_*)
+            from oracle.check import CRAWL_C_TOL, CRAWL_S_DOT
+            loose = np.where(np.abs(g["best_s_d"]) < CRAWL_S_DOT, CRAWL_C_TOL, 0.0)
+            err = np.abs(got - exp)
+            assert np.all(err <= TIGHT + TIGHT * np.abs(exp) + loose), (f, float(err.max()))
+            if g.name.startswith("crawl_"):
+                k = int(err.argmax())
+                print(f"\n{g.name} [{eval_path}]: curvature sample {k} (s_d {g['best_s_d'][k]:.3e}): reference {exp[k]!r}, "
+                      f"library {got[k]!r}, |difference| {err[k]:.3e} ({err[k] / abs(exp[k]):.3e} relative)")
         else:
             np.testing.assert_allclose(got, exp, rtol=TIGHT, atol=TIGHT, err_msg=f)
-    np.testing.assert_allclose(r.new_last_kappa, float(g["last_kappa_after"]), rtol=TIGHT, atol=TIGHT)
+    lk_tol = TIGHT if abs(g["best_s_d"][1]) >= 0.05 else 1e-6      # (_last_kappa = c[1]: the same rule)
+    np.testing.assert_allclose(r.new_last_kappa, float(g["last_kappa_after"]), rtol=lk_tol, atol=lk_tol)
 
 
 def test_spline_matches_reference(golden):

@@ -58,12 +58,14 @@ def test_distribution_larger_than_cull_cache_with_budget():
     _check(bp, orc.make_params(**okw), orc.Spline(WX, WY), reqs)
 
 
-@pytest.mark.parametrize("max_t,n_samples", [(6.3, 64), (6.4, 65), (12.7, 128)])
-def test_longest_horizons(max_t, n_samples):
-    """Samples per candidate around the wave width and at the limit of the build (FOT_MAX_NT = 128): 64 samples fill the
-    lanes that hold the per-step values exactly once, 65 need the second block of steps for ONE step, 128 two full
-    blocks.  The dynamic tensor is as long as the horizon, so the late steps do collide."""
-    kw = dict(dt=0.1, min_t=max_t - 0.4, max_t=max_t, max_road_width=1.0, d_road_w=0.5, robot_radius=1.0,
+@pytest.mark.parametrize("dt,max_t,n_samples", [(0.1, 6.3, 64), (0.1, 6.4, 65), (0.1, 12.7, 128), (0.1, 12.8, 129),
+                                                (0.05, 12.75, 256)])
+def test_longest_horizons(dt, max_t, n_samples):
+    """Samples per candidate around the wave width and up to the limit of the build (FOT_MAX_NT = 256): 64 samples fill
+    the lanes that hold the per-step values exactly once, 65 need the second block of steps for ONE step, 128 two full
+    blocks, 129 a third for one step, 256 four.  The dynamic tensor is as long as the horizon, so the late steps do
+    collide."""
+    kw = dict(dt=dt, min_t=max_t - 4 * dt, max_t=max_t, max_road_width=1.0, d_road_w=0.5, robot_radius=1.0,
               obstacle_radius=0.2, max_speed=20.0)
     rng = np.random.default_rng(2)
     wx = np.arange(0.0, 301.0, 10.0)
@@ -80,9 +82,33 @@ def test_longest_horizons(max_t, n_samples):
         if res.records[0].status == _abi.PLAN_OK:
             assert res.records[0].n_keep <= n_samples
     assert res.records[0].stats[_abi.ST_COLLISION] > 0
-    if n_samples == 128:
-        with pytest.raises(Exception):
-            BatchPlanner(waypoints=(wx, 0 * wx), **dict(kw, max_t=12.8))   # 129 samples: rejected loudly, not planned slowly
+    if n_samples == 256:
+        with pytest.raises(_abi.FotError) as ei:
+            BatchPlanner(waypoints=(wx, 0 * wx), **dict(kw, max_t=12.8))   # 257 samples: the C ABI says so (FOT_ERR_UNSUPPORTED)
+        assert ei.value.code == _abi.ERR_UNSUPPORTED
+
+
+def test_drop_in_planner_never_raises_beyond_the_capacities():
+    """The reference plans any lattice and its plan() never raises (frenet_planner.py:266-268).  Beyond the library's
+    capacities the drop-in class keeps that contract: it warns once, plan() returns None with last_check_stats None, and
+    last_error says which capacity -- for a planner that cannot be built (501 samples per candidate) and for a single
+    call (65 prediction samples) on a planner that otherwise works."""
+    from integrated_path_planning_amd.cubic_spline import CubicSpline2D
+    from integrated_path_planning_amd.data_structures import EgoVehicleState
+    from integrated_path_planning_amd.planner import FrenetPlanner
+    csp = CubicSpline2D(list(WX), list(WY))
+    ego = EgoVehicleState(5.0, 0.0, 0.0, 5.0, 0.0)
+    with pytest.warns(RuntimeWarning, match="capacities"):
+        too_fine = FrenetPlanner(csp, dt=0.01)
+    assert too_fine.plan(ego, np.empty((0, 2))) is None and too_fine.last_check_stats is None
+    assert "FOT_MAX_" in too_fine.last_error                        # (101 horizons and 501 samples: whichever is checked first)
+    ok = FrenetPlanner(csp, dt=0.2)
+    assert ok.plan(ego, np.empty((0, 2))) is not None and ok.last_error is None
+    dist = np.full((65, 2, 26, 2), 400.0)
+    with pytest.warns(RuntimeWarning, match="capacities"):
+        assert ok.plan(ego, np.empty((0, 2)), dynamic_obstacles_distribution=dist) is None
+    assert ok.last_check_stats is None and "sample" in ok.last_error.lower()
+    assert ok.plan(ego, np.empty((0, 2)), dynamic_obstacles_distribution=dist[:64]) is not None and ok.last_error is None
 
 
 def test_empty_and_degenerate_inputs():

@@ -44,7 +44,9 @@ def synthetic(loop_body, scratch=0, vspill=0, callee="\ts_mov_b32 s4, 0\n\ts_set
 def run_guard(text, tmp_path, *args):
     p = tmp_path / "k.s"
     p.write_text(text)
-    r = subprocess.run([sys.executable, GUARD, str(p), "--min-kernels", "3", *args], capture_output=True, text=True, timeout=60)
+    extra = [] if "--handoff" in args else ["--no-handoff-check"]     # (the hazard cases below hold no selection code)
+    args = [a for a in args if a != "--handoff"]
+    r = subprocess.run([sys.executable, GUARD, str(p), "--min-kernels", "3", *extra, *args], capture_output=True, text=True, timeout=60)
     return r.returncode, r.stdout + r.stderr
 
 
@@ -80,6 +82,30 @@ def test_guard_rejects_scratch_and_vector_spills(tmp_path):
     assert run_guard(synthetic(clean, scratch=104, vspill=29), tmp_path)[0] == 1
     assert run_guard(synthetic(clean, scratch=104, vspill=29), tmp_path, "--allow-scratch")[0] == 0
     assert run_guard(synthetic(clean), tmp_path)[0] == 0
+
+
+def handoff(store_flag=" sc1", wait="\ts_waitcnt vmcnt(0)", load_flag=" sc1", loads_first=False, n_stores=11):
+    """the selection hand-off as the evaluation kernels hold it: partial result out, wait, count, wait, partials in"""
+    st = "\n".join(f"\tglobal_store_dword v[2:3], v{4 + i}, off offset:{4 * i}{store_flag}" for i in range(n_stores))
+    ld = "\n".join(f"\tglobal_load_dword v{20 + i}, v[0:1], off offset:{4 * i}{load_flag}" for i in range(11))
+    tail = (ld + "\n\ts_waitcnt vmcnt(0)") if loads_first else ("\ts_waitcnt vmcnt(0)\n" + ld)
+    return st + "\n" + wait + "\n\tglobal_atomic_add v1, v1, v2, s[6:7] sc0\n" + tail
+
+
+def test_guard_checks_the_fence_free_selection(tmp_path):
+    """the selection folded into the evaluation has no release / acquire pair; it is correct only while the
+    ISA keeps sc1 on the partial-result stores and loads, a wait between stores and count, and the loads behind the wait
+    that returns the count.  The guard asserts exactly that on every build."""
+    clean = "\tv_pk_mul_f32 v[4:5], v[4:5], v[4:5]\n"
+    assert run_guard(synthetic(clean + handoff()), tmp_path, "--handoff")[0] == 0
+    for bad, word in ((handoff(store_flag=""), "store without sc1"),
+                      (handoff(wait="\ts_nop 0"), "no s_waitcnt vmcnt(0) between"),
+                      (handoff(load_flag=""), "agent-coherent loads behind"),
+                      (handoff(loads_first=True), "before the tile counter has returned"),
+                      (handoff(n_stores=9), "only 9 stores"),
+                      ("\ts_nop 0", "no global_atomic_add")):
+        rc, out = run_guard(synthetic(clean + bad), tmp_path, "--handoff")
+        assert rc == 1 and word in out, (word, out)
 
 
 def test_makefile_runs_the_guard():

@@ -102,40 +102,41 @@ def _traj():
 
 def test_get_state_returns_current_frame():
     s0 = ReplayPedestrians(_traj(), dt=0.4).get_state()
-    assert s0["n_peds"] == 2
-    np.testing.assert_allclose(s0["positions"], [[0, 0], [5, 5]])
-    assert s0["timestamp"] == pytest.approx(0.0)
+    assert s0.n_peds == 2
+    np.testing.assert_array_equal(s0.ids, [0, 1])                  # (replay_source.py:71-73, 98-106)
+    np.testing.assert_allclose(s0.positions, [[0, 0], [5, 5]])
+    assert s0.timestamp == pytest.approx(0.0)
 
 
 def test_step_advances_frame_and_time():
     src = ReplayPedestrians(_traj(), dt=0.4)
     src.step()
     s1 = src.get_state()
-    np.testing.assert_allclose(s1["positions"], [[1, 0], [5, 6]])
-    assert s1["timestamp"] == pytest.approx(0.4)
+    np.testing.assert_allclose(s1.positions, [[1, 0], [5, 6]])
+    assert s1.timestamp == pytest.approx(0.4)
 
 
 def test_step_clamps_position_but_time_advances():
     src = ReplayPedestrians(_traj(), dt=0.4)
     src.step(n=10)
     s = src.get_state()
-    np.testing.assert_allclose(s["positions"], [[2, 0], [5, 7]])
-    assert s["timestamp"] == pytest.approx(10 * 0.4)
+    np.testing.assert_allclose(s.positions, [[2, 0], [5, 7]])
+    assert s.timestamp == pytest.approx(10 * 0.4)
 
 
 def test_velocities_finite_difference():
     s0 = ReplayPedestrians(_traj(), dt=0.4).get_state()
-    np.testing.assert_allclose(s0["velocities"], [[2.5, 0.0], [0.0, 2.5]])
+    np.testing.assert_allclose(s0.velocities, [[2.5, 0.0], [0.0, 2.5]])
 
 
 def test_goals_default_to_final_position():
-    np.testing.assert_allclose(ReplayPedestrians(_traj(), dt=0.4).get_state()["goals"], [[2, 0], [5, 7]])
+    np.testing.assert_allclose(ReplayPedestrians(_traj(), dt=0.4).get_state().goals, [[2, 0], [5, 7]])
 
 
 def test_ego_state_is_ignored():
     src = ReplayPedestrians(_traj(), dt=0.4)
     src.step(ego_state=object())
-    np.testing.assert_allclose(src.get_state()["positions"], [[1, 0], [5, 6]])
+    np.testing.assert_allclose(src.get_state().positions, [[1, 0], [5, 6]])
 
 
 def test_rejects_bad_shape():
@@ -146,8 +147,8 @@ def test_rejects_bad_shape():
 def test_supplied_velocities_and_reset():
     traj = _traj()
     src = ReplayPedestrians(traj, dt=0.4, velocities=np.ones_like(traj))
-    np.testing.assert_allclose(src.get_state()["velocities"], np.ones((2, 2)))
+    np.testing.assert_allclose(src.get_state().velocities, np.ones((2, 2)))
     src.step(n=2)
     src.reset()
-    assert src.get_state()["timestamp"] == pytest.approx(0.0)
-    np.testing.assert_allclose(src.get_state()["positions"], [[0, 0], [5, 5]])
+    assert src.get_state().timestamp == pytest.approx(0.0)
+    np.testing.assert_allclose(src.get_state().positions, [[0, 0], [5, 5]])

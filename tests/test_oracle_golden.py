@@ -73,9 +73,20 @@ def test_selection(golden):
         assert len(got) == len(want_arr), f
         if f == "yaw":
             np.testing.assert_allclose(wrap_angle(got - want_arr), 0.0, atol=TOL)
+        elif f == "c":
+            # Curvature at a crawl: a sample whose arc-length speed is just above the 1e-3 gate divides by s_d and s_d^2
+            # (frenet_planner.py:792-799), s_d being what is left of a quartic's terms cancelling -- the REFERENCE's own
+            # value there moves with the last bit of s_d.  The `crawl_*` goldens are the fuzz instances a round-4 sweep
+            # flagged, put before the reference: the oracle holds its curvature to 4e-8 relative there (one sample each),
+            # the library to 1.1e-7 -- neither to 1e-9, both far inside the north star's 1e-5 (oracle/check.py CRAWL_*).
+            from oracle.check import CRAWL_C_TOL, CRAWL_S_DOT
+            loose = np.where(np.abs(golden["best_s_d"]) < CRAWL_S_DOT, CRAWL_C_TOL, 0.0)
+            err = np.abs(got - want_arr)
+            assert np.all(err <= TOL + TOL * np.abs(want_arr) + loose), (f, float(err.max()))
         else:
             np.testing.assert_allclose(got, want_arr, rtol=TOL, atol=TOL, err_msg=f)
-    np.testing.assert_allclose(out.new_last_kappa, float(golden["last_kappa_after"]), rtol=TOL, atol=TOL)
+    lk_tol = TOL if abs(golden["best_s_d"][1]) >= 0.05 else 1e-6      # (_last_kappa = c[1]: the same rule)
+    np.testing.assert_allclose(out.new_last_kappa, float(golden["last_kappa_after"]), rtol=lk_tol, atol=lk_tol)
 
 
 def test_probe_paths(golden):
@@ -90,5 +101,9 @@ def test_probe_paths(golden):
             got = arr[fi, :keep]
             if f == "yaw":
                 np.testing.assert_allclose(wrap_angle(got - want), 0.0, atol=TOL)
+            elif f == "c":                                       # (curvature at a crawl: see test_selection)
+                from oracle.check import CRAWL_C_TOL, CRAWL_S_DOT
+                loose = np.where(np.abs(golden["probe_s_d"][r, :keep]) < CRAWL_S_DOT, CRAWL_C_TOL, 0.0)
+                assert np.all(np.abs(got - want) <= TOL + TOL * np.abs(want) + loose), f"{f} cand {idx}"
             else:
                 np.testing.assert_allclose(got, want, rtol=TOL, atol=TOL, err_msg=f"{f} cand {idx}")
