@@ -167,10 +167,11 @@ const char *fot_version(void);
  * four profile slots under a binding that allocated three aborted the process at exit with "double free or
  * corruption").  out[i], i < cap: FOT_ABI_VERSION, sizeof of fot_params, fot_ego, fot_overrides, fot_result, fot_batch,
  * fot_resample_params, fot_safety, fot_loop_frame, fot_loop_request, fot_wire_header, then FOT_MAX_NT, FOT_MAX_CIRCLES,
- * FOT_MAX_TI, FOT_MAX_TV, FOT_MAX_BRAKE, FOT_MAX_SAMPLES, FOT_MAX_PRED_LEN, FOT_PROFILE_KERNELS, FOT_MARGIN_GROUPS.
+ * FOT_MAX_TI, FOT_MAX_TV, FOT_MAX_BRAKE, FOT_MAX_SAMPLES, FOT_MAX_PRED_LEN, FOT_PROFILE_KERNELS, FOT_MARGIN_GROUPS,
+ * sizeof of fot_loop_config, fot_loop_step_out.
  * Returns the number of words the library knows (FOT_ABI_INFO_WORDS of ITS header). */
 #define FOT_ABI_VERSION 4
-#define FOT_ABI_INFO_WORDS 20
+#define FOT_ABI_INFO_WORDS 22
 int32_t fot_abi_info(int32_t cap, int32_t *out);
 
 /* FrenetPlanner.__init__ (frenet_planner.py:149-225).  device < 0: current device. */
@@ -365,6 +366,47 @@ int fot_loop_observe(fot_handle *h, int32_t n, const double *ego5, const double 
                      fot_safety *safety_out, double *new_prev_s);
 int fot_loop_observe_begin(fot_handle *h, int32_t n, const double *ego5, const double *prev_s);
 int fot_loop_observe_end(fot_handle *h, fot_safety *safety_out, double *new_prev_s);
+/* The WHOLE lock step behind one call: the episodes' state lives in the handle (ego, the planner's nearest-point cache and
+ * last curvature, the fail-safe state machine), a step is
+ *   prediction + current metrics + the level-0 plan() of every running episode (fot_loop_plan with the frame)
+ *   -> every further escalation level of the episodes whose first attempt failed, in one more launch
+ *   -> the reference's retry loop replayed on the records (integrated_simulator.py:576-653, state_machine.py:116-247)
+ *   -> ego update from the selected path's sample 1, or the emergency stop (:655-676, :749-802)
+ *   -> metrics of the new states + the goal test's nearest point (fot_loop_observe).
+ * fot_loop_config: IntegratedSimulator's and FailSafeStateMachine's constants as the reference resolves them from its
+ * configuration (state_machine.py:32-98); emergency_decel NaN = 2 x max_accel.
+ * fot_loop_begin: n_episodes slots, ego5 [n][5] = x, y, yaw, v, a; every machine NORMAL, no caches.
+ * fot_loop_step: frame as for fot_loop_plan (its `ego` is ignored: the handle knows the egos), episode[i] = the slot
+ * of the frame's episode i (distinct); out arrays of frame->n_episodes entries, any may be NULL.  out->records: the
+ * step's records in pinned memory owned by the handle (level 0 of episode i = record i, escalation levels behind),
+ * valid until the next loop call; out->record[i]: the record whose path episode i follows (-1: emergency stop). */
+typedef struct fot_loop_config {
+    double dt, target_speed, max_accel, emergency_decel;
+    double clearance_caution, clearance_emergency;               /* recovery thresholds (combined radii subtracted) */
+    double trigger_clearance_caution, trigger_time_headway;      /* preventive escalation */
+    double envelope_decel, envelope_standoff;                    /* speed envelope on the clearance ahead */
+    double caution_accel, caution_speed, caution_speed_mult;     /* CAUTION: overrides, target speed factor */
+    double emergency_accel, emergency_lat_accel;                 /* EMERGENCY: overrides */
+    int32_t max_replan;                                          /* integrated_simulator.py:383 */
+    int32_t _pad;
+} fot_loop_config;
+typedef struct fot_loop_step_out {
+    double *ego;                /* [n][5] the new ego states */
+    double *jerk;               /* [n] */
+    int32_t *state;             /* [n] 0 / 1 / 2 = NORMAL / CAUTION / EMERGENCY after the step */
+    int32_t *stats;             /* [n][8] last_check_stats of the last plan() of the step; a row of -1: None */
+    int32_t *record;            /* [n] */
+    int32_t *keep;              /* [n] samples of the followed path (0: none) */
+    double *cost;               /* [n] */
+    fot_safety *before, *after; /* [n] metrics of the current / of the new ego states */
+    double *s_now;              /* [n] arc length of the new state's nearest path point */
+    const fot_result *records;  /* out */
+    int32_t n_records;          /* out */
+    int32_t _pad;
+} fot_loop_step_out;
+int fot_loop_begin(fot_handle *h, int32_t n_episodes, const fot_loop_config *cfg, const double *ego5);
+int fot_loop_step(fot_handle *h, const fot_loop_frame *frame, const int32_t *episode, fot_loop_step_out *out);
+
 /* Host utility (no GPU): the first kmax samples of the 15 path arrays of records[index[i]], i < n, as one dense block
  * out[15][n][kmax] in fot_result array order (t .. c) -- what a history keeps of a step's records. */
 int fot_gather_paths(const fot_result *records, int32_t n, const int32_t *index, int32_t kmax, double *out);

@@ -97,6 +97,19 @@ class LoopRequest(C.Structure):                                    # fot_loop_re
                 ("max_stop_distance", C.c_double), ("episode", C.c_int32), ("_pad", C.c_int32)]
 
 
+class LoopConfig(C.Structure):                                     # fot_loop_config
+    _fields_ = [(n, C.c_double) for n in
+                ("dt", "target_speed", "max_accel", "emergency_decel", "clearance_caution", "clearance_emergency",
+                 "trigger_clearance_caution", "trigger_time_headway", "envelope_decel", "envelope_standoff",
+                 "caution_accel", "caution_speed", "caution_speed_mult", "emergency_accel", "emergency_lat_accel")] + \
+               [("max_replan", C.c_int32), ("_pad", C.c_int32)]
+
+
+class LoopStepOut(C.Structure):                                    # fot_loop_step_out
+    _fields_ = [(n, C.c_void_p) for n in ("ego", "jerk", "state", "stats", "record", "keep", "cost", "before", "after",
+                                          "s_now", "records")] + [("n_records", C.c_int32), ("_pad", C.c_int32)]
+
+
 class Batch(C.Structure):
     _fields_ = [("n_inst", C.c_int32), ("obstacle_dtype", C.c_int32),
                 ("ego", C.POINTER(Ego)), ("target_speed", C.POINTER(C.c_double)),
@@ -115,7 +128,7 @@ SYMBOLS = ["fot_version", "fot_abi_info", "fot_create", "fot_destroy", "fot_live
            "fot_set_path_coeffs", "fot_get_path_coeffs", "fot_spline_eval", "fot_plan_batch",
            "fot_plan_batch_device", "fot_synchronize", "fot_frenet_state_batch", "fot_debug_candidates",
            "fot_debug_candidate_path", "fot_debug_margins", "fot_debug_set_eval_segments", "fot_debug_set_tile_cut", "fot_debug_time_info", "fot_check_collision_paths", "fot_check_paths", "fot_resample_n_dense", "fot_resample_predictions",
-           "fot_predict_cv", "fot_safety_metrics_batch", "fot_loop_set_static", "fot_loop_plan", "fot_loop_observe", "fot_loop_observe_begin", "fot_loop_observe_end", "fot_gather_paths", "fot_wire_n_total", "fot_wire_record_bytes",
+           "fot_predict_cv", "fot_safety_metrics_batch", "fot_loop_set_static", "fot_loop_plan", "fot_loop_observe", "fot_loop_observe_begin", "fot_loop_observe_end", "fot_loop_begin", "fot_loop_step", "fot_gather_paths", "fot_wire_n_total", "fot_wire_record_bytes",
            "fot_pack_records_device", "fot_pack_records_host", "fot_unpack_records", "fot_profile_enable", "fot_profile_read", "fot_profile_kernel_name"]
 PROFILE_KERNELS = 3                      # FOT_PROFILE_KERNELS (include/fot.h)
 ABI_VERSION = 4                          # FOT_ABI_VERSION
@@ -131,14 +144,15 @@ def abi_expectation():
     """What fot_abi_info() must report for THIS binding: version, structure sizes, array capacities (include/fot.h)."""
     return [ABI_VERSION, C.sizeof(Params), C.sizeof(Ego), C.sizeof(Overrides), C.sizeof(Result), C.sizeof(Batch),
             C.sizeof(ResampleParams), C.sizeof(Safety), C.sizeof(LoopFrame), C.sizeof(LoopRequest), C.sizeof(WireHeader),
-            MAX_NT, MAX_CIRCLES, MAX_TI, MAX_TV, MAX_BRAKE, MAX_SAMPLES, MAX_PRED_LEN, PROFILE_KERNELS, MARGIN_GROUPS]
+            MAX_NT, MAX_CIRCLES, MAX_TI, MAX_TV, MAX_BRAKE, MAX_SAMPLES, MAX_PRED_LEN, PROFILE_KERNELS, MARGIN_GROUPS,
+            C.sizeof(LoopConfig), C.sizeof(LoopStepOut)]
 
 
 ABI_WORD_NAMES = ["FOT_ABI_VERSION", "sizeof(fot_params)", "sizeof(fot_ego)", "sizeof(fot_overrides)", "sizeof(fot_result)",
                   "sizeof(fot_batch)", "sizeof(fot_resample_params)", "sizeof(fot_safety)", "sizeof(fot_loop_frame)",
                   "sizeof(fot_loop_request)", "sizeof(fot_wire_header)", "FOT_MAX_NT", "FOT_MAX_CIRCLES", "FOT_MAX_TI",
                   "FOT_MAX_TV", "FOT_MAX_BRAKE", "FOT_MAX_SAMPLES", "FOT_MAX_PRED_LEN", "FOT_PROFILE_KERNELS",
-                  "FOT_MARGIN_GROUPS"]
+                  "FOT_MARGIN_GROUPS", "sizeof(fot_loop_config)", "sizeof(fot_loop_step_out)"]
 
 
 def _check_abi(L, path):
@@ -323,6 +337,8 @@ def lib():
     L.fot_loop_observe.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     L.fot_loop_observe_begin.argtypes = [vp, C.c_int32, vp, vp]
     L.fot_loop_observe_end.argtypes = [vp, vp, vp]
+    L.fot_loop_begin.argtypes = [vp, C.c_int32, vp, vp]
+    L.fot_loop_step.argtypes = [vp, vp, vp, vp]
     L.fot_gather_paths.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
     L.fot_wire_n_total.argtypes = [vp]
     L.fot_wire_record_bytes.argtypes = [C.c_int32]

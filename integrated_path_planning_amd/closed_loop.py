@@ -23,6 +23,7 @@ All arithmetic on candidate paths, predictions and metrics runs in libfot.
 """
 from __future__ import annotations
 
+import math
 import os
 import time
 from collections import deque
@@ -306,7 +307,11 @@ def emergency_stop(x, y, yaw, v, clearance_ahead, dt, max_accel, emergency_decel
     max_dec = np.clip(required, max_accel, cap)
     nv = np.maximum(0.0, v - max_dec * dt)
     na = np.where(nv > 0, -max_dec, 0.0)
-    return x + v * np.cos(yaw) * dt, y + v * np.sin(yaw) * dt, nv, na
+    # (the C library's cos / sin element by element -- what math.cos calls and what fot_loop_step's C++ calls: NumPy's
+    #  array loops are a SIMD routine of their own that may differ from it in the last place)
+    cy = np.array([math.cos(float(t)) for t in np.atleast_1d(yaw)]).reshape(np.shape(yaw))
+    sy = np.array([math.sin(float(t)) for t in np.atleast_1d(yaw)]).reshape(np.shape(yaw))
+    return x + v * cy * dt, y + v * sy * dt, nv, na
 
 
 class BatchedClosedLoop:
@@ -362,9 +367,15 @@ class BatchedClosedLoop:
         # the step's device work in two calls, prediction resident in HBM (fot_loop_*): the constant-velocity predictor
         # on the library's own engine; a sample source hands its samples over on the host, stand-in engines have no device
         can_fuse = sample_source is None and resampler is None and hasattr(self.engine, "loop_plan")
+        if fused not in (None, False, True, "two-call"):
+            raise ValueError("fused: None (automatic), False, True or 'two-call'")
         if fused and not can_fuse:
             raise ValueError("fused=True needs the constant-velocity predictor on the library's own engine")
         self._fused = can_fuse if fused is None else bool(fused)
+        # ... and, on the library's own engine, the whole step behind ONE call (fot_loop_step: the episodes' state, the
+        # fail-safe machine and the retry loop live in the handle); fused="two-call" keeps the round-3 form (two calls,
+        # the retry loop replayed here on arrays) -- the tests run both against each other and against the five-call step
+        self._native = self._fused and fused != "two-call" and hasattr(self.engine, "loop_step")
         if self._fused:
             self.engine.loop_set_static(self.static_obstacle_points)
         self.sgan_dt = 0.4                                            # integrated_simulator.py:323-327
@@ -417,6 +428,18 @@ class BatchedClosedLoop:
         self.termination = np.zeros(n, np.int8)                      # index into _TERMINATION
         self.episodes: List[Episode] = [Episode(self, e) for e in range(n)]
         self._warmup()
+        if self._native:
+            sm_, lc = self.sm, _abi.LoopConfig()
+            lc.dt, lc.target_speed, lc.max_accel = float(c.dt), float(sm_.target), float(c.ego_max_accel)
+            dec = getattr(c, "ego_emergency_decel", None)
+            lc.emergency_decel = float("nan") if dec is None else float(dec)
+            lc.clearance_caution, lc.clearance_emergency = float(sm_.clr_caution), float(sm_.clr_emergency)
+            lc.trigger_clearance_caution, lc.trigger_time_headway = float(sm_.trig_c), float(sm_.trig_h)
+            lc.envelope_decel, lc.envelope_standoff = float(sm_.env_decel), float(sm_.env_standoff)
+            lc.caution_accel, lc.caution_speed, lc.caution_speed_mult = float(sm_.c_accel), float(sm_.c_speed), float(sm_.c_speed_mult)
+            lc.emergency_accel, lc.emergency_lat_accel = float(sm_.e_accel), float(sm_.e_lat)
+            lc.max_replan = self.MAX_REPLAN
+            self.engine.loop_begin(lc, self.ego)
 
     def close(self) -> None:
         """Release the libfot handle (streams, workspace) now rather than at garbage collection."""
@@ -546,6 +569,8 @@ class BatchedClosedLoop:
         n_lvl = np.minimum(3 - st0, 1 + self.MAX_REPLAN)             # NORMAL -> CAUTION -> EMERGENCY, then no change
         everyone = np.arange(n)
         speed = self.ego[sel, 3].copy()
+        if self._native:
+            return self._step_native(sel, off, pos, vel)
         if self._fused:
             return self._step_fused(sel, off, counts, pos, vel, st0, n_lvl, everyone, speed)
         pred, prepend, t_pred, dist = self._predict(sel, off, pos)    # 2. prediction
@@ -619,25 +644,7 @@ class BatchedClosedLoop:
         sm = self.sm
         n = len(sel)
         t0 = time.perf_counter()
-        frame = dict(ped_off=off, ped_pos=pos, ped_vel=vel, ego=self.ego[sel, :4], ego_radius=self.ego_radius,
-                     ped_radius=self.ped_radius, use_footprint=self.footprint is not None)
-        pred_src = None
-        if self.observer.is_ready:
-            rows = self._rows_of(sel)
-            hist = self.observer.history
-            o32 = np.stack([hist[-2][rows], hist[-1][rows]], axis=0).astype(np.float32)
-            last = self.observer.last_sample_time
-            stale = max(self.ped_time - last, 0.0) if last is not None else 0.0
-            # np.allclose(pred[:, 0], current) (:503-511) needs the first predicted sample only: obs_last + v (dt + stale),
-            # the velocity formed in float32 as the kernel (and the reference, trajectory_predictor.py:216) forms it
-            vel32 = (o32[1] - o32[0]) / np.float32(self.sgan_dt)
-            first = o32[1].astype(np.float64) + vel32.astype(np.float64) * ((self.dt + 0.0 * self.dt) + stale)
-            far = np.any(np.abs(first - pos) > 1e-8 + 1e-5 * np.abs(pos), axis=1)
-            n_far = np.concatenate([[0], np.cumsum(far)])
-            same = n_far[off[1:]] == n_far[off[:-1]]                  # per episode (True without pedestrians)
-            frame.update(obs_last=o32[1], obs_prev=o32[0], prepend=~same, staleness=stale,
-                         pred_len=self.resampler.pred_len, rp=self.resampler.params)
-            pred_src = (o32, stale)
+        frame, pred_src = self._loop_frame(sel, off, pos, vel)
 
         def requests(who, state, clear_ahead, prev_s, chain):
             # fot_loop_request is 15 eight-byte slots: x y yaw v a last_kappa prev_s | has_prev_s, pad | 4 overrides |
@@ -665,6 +672,66 @@ class BatchedClosedLoop:
         return self._finish_step(sel, off, pos, vel, None, pred_src, t_pred, t0, plan, st0, n_lvl, everyone, speed,
                                  clearance, clearance_ahead, lambda new_ego: self.engine.loop_observe_begin(new_ego, self.goal_prev_s[sel]),
                                  first=rec0)
+
+    def _loop_frame(self, sel, off, pos, vel):
+        """The frame of fot_loop_plan / fot_loop_step for the running episodes: pedestrians, the observer's last two
+        samples, per episode whether the current positions lead the prediction (:503-511), staleness."""
+        frame = dict(ped_off=off, ped_pos=pos, ped_vel=vel, ego=self.ego[sel, :4], ego_radius=self.ego_radius,
+                     ped_radius=self.ped_radius, use_footprint=self.footprint is not None)
+        pred_src = None
+        if self.observer.is_ready:
+            rows = self._rows_of(sel)
+            hist = self.observer.history
+            o32 = np.stack([hist[-2][rows], hist[-1][rows]], axis=0).astype(np.float32)
+            last = self.observer.last_sample_time
+            stale = max(self.ped_time - last, 0.0) if last is not None else 0.0
+            # np.allclose(pred[:, 0], current) (:503-511) needs the first predicted sample only: obs_last + v (dt + stale),
+            # the velocity formed in float32 as the kernel (and the reference, trajectory_predictor.py:216) forms it
+            vel32 = (o32[1] - o32[0]) / np.float32(self.sgan_dt)
+            first = o32[1].astype(np.float64) + vel32.astype(np.float64) * ((self.dt + 0.0 * self.dt) + stale)
+            far = np.any(np.abs(first - pos) > 1e-8 + 1e-5 * np.abs(pos), axis=1)
+            n_far = np.concatenate([[0], np.cumsum(far)])
+            same = n_far[off[1:]] == n_far[off[:-1]]                  # per episode (True without pedestrians)
+            frame.update(obs_last=o32[1], obs_prev=o32[0], prepend=~same, staleness=stale,
+                         pred_len=self.resampler.pred_len, rp=self.resampler.params)
+            pred_src = (o32, stale)
+
+        return frame, pred_src
+
+    def _step_native(self, sel, off, pos, vel):
+        """Steps 2-5 behind ONE libfot call (fot_loop_step): the episodes' state -- ego, planner caches, fail-safe machine
+        -- lives in the handle, the retry loop is replayed there; what is left here is the pedestrian frame, the
+        observer, the history and the termination test."""
+        n = len(sel)
+        t0 = time.perf_counter()
+        frame, pred_src = self._loop_frame(sel, off, pos, vel)
+        frame.pop("ego")
+        o = self.engine.loop_step(frame, sel)
+        t_plan = (time.perf_counter() - t0) / n
+        rec, path_rec, keep = o["records"], o["record"].astype(np.int64), o["keep"].astype(np.int64)
+        new_ego = o["ego"]
+        self.ego[sel], self.jerk[sel] = new_ego, o["jerk"]
+        self.sm.state[sel] = o["state"]
+        self.last_stats[sel] = o["stats"]
+        chosen = np.maximum(path_rec, 0)
+        kmax = int(keep.max()) if n else 0
+        slot = np.full(len(self.episodes), -1, np.int64)
+        slot[sel] = np.arange(n)
+        block = self.engine.gather_paths(rec, chosen, kmax, out=self._history_block(len(self._steps), n, kmax))
+        paths = {f: block[j] for j, f in enumerate(_abi.PATH_FIELDS)}
+        after, s_now = o["after"], o["s_now"]
+        self._steps.append(dict(
+            time=self.time, slot=slot, off=off, ego=new_ego, jerk=o["jerk"], state=self.sm.state[sel].copy(), pos=pos, vel=vel,
+            pred=None, pred_src=pred_src, after=after, stats=self.last_stats[sel].copy(), has_path=path_rec >= 0, keep=keep,
+            cost=o["cost"], paths=paths, t_pred=0.0, t_plan=t_plan, sel=sel))
+        collided = after["collision"] != 0
+        at_goal = self.s_end - s_now < 2.0
+        self.step_counts[sel] += 1
+        self.termination[sel[at_goal & ~collided]] = 2
+        self.termination[sel[collided]] = 1
+        self.alive[sel[collided | at_goal]] = False
+        self.time += self.dt
+        return n
 
     def _finish_step(self, sel, off, pos, vel, pred, pred_src, t_pred, t0, plan, st0, n_lvl, everyone, speed, clearance,
                      clearance_ahead, observe, first=None):

@@ -108,8 +108,23 @@ struct Workspace {
     }
 };
 
+// fot_loop_begin / fot_loop_step: the episodes' own state (what IntegratedSimulator, its planner and its
+// FailSafeStateMachine carry from step to step), one slot per episode
+struct LoopEpisodes {
+    int n = 0;
+    fot_loop_config cfg = fot_loop_config();
+    std::vector<double> ego;                 // [n][5] x, y, yaw, v, a
+    std::vector<double> prev_s, last_kappa;  // planner.converter._prev_s (NaN: none yet), planner._last_kappa
+    std::vector<double> goal_prev_s;         // the simulator's own converter (integrated_simulator.py:873)
+    std::vector<double> last_clearance;      // clearance_ahead of the step's own metrics (emergency stop)
+    std::vector<double> clear, clear_ahead;  // the state machine's _last_clearance / _last_clearance_ahead
+    std::vector<int32_t> state, fails;       // 0 / 1 / 2 = NORMAL / CAUTION / EMERGENCY; consecutive failures
+    std::vector<int32_t> stats;              // [n][8] last_check_stats, a row of -1: None
+};
+
 // fot_loop_*: what one closed-loop step leaves behind for the step's later calls
 struct LoopState {
+    LoopEpisodes ep;
     PinnedBuf hFrame, hObserve, hOut, hRec;  // frame inputs | fot_loop_observe's inputs | small outputs | records
     DevBuf dDyn, dStatic;                    // the prediction tensor; the static points, one copy per request
     std::vector<double> static_xy;           // host copy of the static points
@@ -568,6 +583,7 @@ int32_t fot_abi_info(int32_t cap, int32_t *out)
         (int32_t)sizeof(fot_loop_frame), (int32_t)sizeof(fot_loop_request), (int32_t)sizeof(fot_wire_header),
         FOT_MAX_NT, FOT_MAX_CIRCLES, FOT_MAX_TI, FOT_MAX_TV, FOT_MAX_BRAKE, FOT_MAX_SAMPLES, FOT_MAX_PRED_LEN,
         FOT_PROFILE_KERNELS, FOT_MARGIN_GROUPS,
+        (int32_t)sizeof(fot_loop_config), (int32_t)sizeof(fot_loop_step_out),
     };
     for (int i = 0; i < FOT_ABI_INFO_WORDS && i < cap && out; ++i) out[i] = v[i];
     return FOT_ABI_INFO_WORDS;
@@ -946,8 +962,14 @@ int fot_loop_set_static(fot_handle *h, int32_t n_points, const double *xy)
     return FOT_OK;
 }
 
-int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, const fot_loop_request *req,
-                  fot_safety *safety_out, const fot_result **records)
+}  // extern "C"
+
+namespace {
+
+// fot_loop_plan; rec_first: the request's records start at record rec_first of the handle's pinned block (the escalation
+// levels of a step land behind its level-0 records, which stay where they are)
+int loop_plan_impl(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, const fot_loop_request *req,
+                   fot_safety *safety_out, const fot_result **records, int32_t rec_first)
 {
     if (!h) return FOT_ERR_INVALID;
     if (!h->has_path) return fail(h, FOT_ERR_NO_PATH_SET, "fot_set_path_* has not been called");
@@ -1065,12 +1087,15 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
         b.ego = ego.data(); b.target_speed = tgt.data(); b.overrides = ov.data(); b.max_stop_distance = stop.data();
         if (n_static > 0) { b.static_xy = L.dStatic.p; b.static_off = s_off.data(); }
         if (any_dyn) { b.dyn_xy = L.dyn_ptr; b.dyn_off = d_off.data(); b.dyn_dims = dims.data(); }
-        HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * (size_t)n_req));
+        if (rec_first > 0 && sizeof(fot_result) * ((size_t)rec_first + (size_t)n_req) > L.hRec.cap)
+            return fail(h, FOT_ERR_INVALID, "internal: record block too small for the escalation levels");
+        HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * ((size_t)rec_first + (size_t)n_req)));
+        fot_result *rec_out = (fot_result *)L.hRec.p + rec_first;
         {
             // the records' flags instead of the stream (wait_records): the metrics' kernel ran ahead of the plan kernels on
             // this stream and wrote host memory directly, so its results are there once a record behind it is
             arm_records(h, n_req);
-            int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, (fot_result *)L.hRec.p, st, true);
+            int rc = enqueue_plan(h, b, b.static_xy, b.dyn_xy, rec_out, st, true);
             if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
             rc = wait_records(h, n_req, st);
             if (rc != FOT_OK) return rc;
@@ -1080,8 +1105,18 @@ int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, con
         HIP_TRY(h, hipStreamSynchronize(st));
     }
     if (metrics) std::memcpy(safety_out, L.hOut.p, sizeof(fot_safety) * (size_t)n_ep);
-    if (records) *records = n_req > 0 ? (const fot_result *)L.hRec.p : nullptr;
+    if (records) *records = n_req > 0 ? (const fot_result *)L.hRec.p + rec_first : nullptr;
     return FOT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fot_loop_plan(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, const fot_loop_request *req,
+                  fot_safety *safety_out, const fot_result **records)
+{
+    return loop_plan_impl(h, frame, n_req, req, safety_out, records, 0);
 }
 
 int fot_loop_observe_begin(fot_handle *h, int32_t n, const double *ego5, const double *prev_s)
@@ -1145,6 +1180,233 @@ int fot_loop_observe(fot_handle *h, int32_t n, const double *ego5, const double 
     int rc = fot_loop_observe_begin(h, n, ego5, prev_s);
     return rc != FOT_OK ? rc : fot_loop_observe_end(h, safety_out, new_prev_s);
 }
+
+}  // extern "C"
+
+// ---- the whole lock step of n episodes behind ONE call (SURVEY 8 f2 + f4) -------------------------------------------
+namespace {
+
+// FailSafeStateMachine._get_planner_config (state_machine.py:181-247): the planner configuration of `state` on the
+// clearance ahead the machine last observed -> target speed, constraint overrides (NaN = absent), stop room (NaN = None)
+void sm_config(const fot_loop_config &c, int state, double clear_ahead, double *target, fot_overrides *ov, double *stop)
+{
+    const bool fin = std::isfinite(clear_ahead), has_env = fin && c.envelope_decel > 0.0;
+    const double v_env = std::sqrt(2.0 * c.envelope_decel * std::fmax((fin ? clear_ahead : 0.0) - c.envelope_standoff, 0.0));
+    const double stop_room = fin ? std::fmax(clear_ahead - 0.2, 0.05) : NAN;
+    *target = c.target_speed;
+    ov->max_speed = ov->max_accel = ov->max_curvature = ov->max_lat_accel = NAN;
+    *stop = NAN;
+    if (state == 0) {
+        if (has_env && v_env < c.target_speed) *target = v_env;
+    } else if (state == 1) {
+        const double t_ca = c.target_speed * c.caution_speed_mult;
+        *target = has_env ? std::fmin(t_ca, v_env) : t_ca;
+        if (has_env && v_env <= 0.0) *stop = stop_room;
+        ov->max_accel = c.caution_accel; ov->max_speed = c.caution_speed;
+    } else {
+        *target = 0.0;
+        ov->max_accel = c.emergency_accel; ov->max_lat_accel = c.emergency_lat_accel;
+        if (c.envelope_decel > 0.0) *stop = stop_room;
+    }
+}
+
+// FailSafeStateMachine.update (state_machine.py:116-179) of episode e: observe the metrics, then the transition
+void sm_update(LoopEpisodes &E, int e, bool found, double clearance, double clearance_ahead, double speed)
+{
+    const fot_loop_config &c = E.cfg;
+    E.clear[e] = clearance; E.clear_ahead[e] = clearance_ahead;
+    const int st = E.state[e], fl = E.fails[e];
+    const double trigger = c.trigger_clearance_caution + c.trigger_time_headway * std::fmax(speed, 0.0);
+    if (st == 0) {
+        if (!found) { E.state[e] = 1; E.fails[e] = fl + 1; }
+        else if (trigger > 0.0 && clearance < trigger) { E.state[e] = 1; E.fails[e] = 0; }   // preventive escalation
+        else E.fails[e] = 0;
+    } else if (st == 1) {
+        if (found && fl == 0) { if (clearance > std::fmax(c.clearance_caution, trigger)) E.state[e] = 0; }
+        else if (!found) { E.state[e] = 2; E.fails[e] = fl + 1; }
+        else E.fails[e] = 0;
+    } else {
+        if (found && clearance > c.clearance_emergency) E.state[e] = 1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fot_loop_begin(fot_handle *h, int32_t n_episodes, const fot_loop_config *cfg, const double *ego5)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (n_episodes < 0 || !cfg || (n_episodes > 0 && !ego5)) return fail(h, FOT_ERR_INVALID, "fot_loop_begin: arguments");
+    if (!(cfg->dt > 0.0) || cfg->max_replan < 0 || cfg->max_replan > 8) return fail(h, FOT_ERR_INVALID, "fot_loop_begin: dt / max_replan");
+    LoopEpisodes &E = h->loop.ep;
+    const size_t n = (size_t)n_episodes;
+    E.n = n_episodes; E.cfg = *cfg;
+    E.ego.assign(ego5, ego5 + 5 * n);
+    E.prev_s.assign(n, NAN); E.last_kappa.assign(n, 0.0); E.goal_prev_s.assign(n, NAN);
+    E.last_clearance.assign(n, INFINITY); E.clear.assign(n, INFINITY); E.clear_ahead.assign(n, INFINITY);
+    E.state.assign(n, 0); E.fails.assign(n, 0); E.stats.assign(8 * n, -1);
+    return FOT_OK;
+}
+
+int fot_loop_step(fot_handle *h, const fot_loop_frame *frame, const int32_t *episode, fot_loop_step_out *out)
+{
+    if (!h) return FOT_ERR_INVALID;
+    if (!frame || !out) return fail(h, FOT_ERR_INVALID, "fot_loop_step: frame / out");
+    LoopState &L = h->loop;
+    LoopEpisodes &E = L.ep;
+    const fot_loop_config &c = E.cfg;
+    const int n = frame->n_episodes;
+    if (n < 0 || (n > 0 && !episode)) return fail(h, FOT_ERR_INVALID, "fot_loop_step: episode");
+    out->records = nullptr; out->n_records = 0;
+    if (n == 0) return FOT_OK;
+    std::vector<uint8_t> seen((size_t)std::max(E.n, 1), 0);
+    for (int i = 0; i < n; ++i) {
+        if (episode[i] < 0 || episode[i] >= E.n || seen[(size_t)episode[i]]) return fail(h, FOT_ERR_INVALID, "fot_loop_step: episode slots must be distinct and below fot_loop_begin's count");
+        seen[(size_t)episode[i]] = 1;
+    }
+    const int max_lvl = 1 + c.max_replan < 3 ? 1 + c.max_replan : 3;     // NORMAL -> CAUTION -> EMERGENCY, then no change
+    // --- level 0 of every episode: the configuration of its current state (issued on LAST step's clearance), with the
+    //     frame's prediction and the metrics of the current ego states
+    std::vector<int> st0((size_t)n), n_lvl((size_t)n);
+    std::vector<double> speed((size_t)n), ego4(4 * (size_t)n);
+    std::vector<fot_loop_request> req((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int e = episode[i];
+        st0[i] = E.state[e];
+        n_lvl[i] = std::min(3 - st0[i], max_lvl);
+        const double *g = &E.ego[5 * (size_t)e];
+        speed[i] = g[3];
+        for (int k = 0; k < 4; ++k) ego4[4 * (size_t)i + k] = g[k];
+        fot_loop_request &r = req[i];
+        r = fot_loop_request();
+        r.ego.x = g[0]; r.ego.y = g[1]; r.ego.yaw = g[2]; r.ego.v = g[3]; r.ego.a = g[4];
+        r.ego.last_kappa = E.last_kappa[e];
+        r.ego.has_prev_s = std::isnan(E.prev_s[e]) ? 0 : 1;
+        r.ego.prev_s = std::isnan(E.prev_s[e]) ? 0.0 : E.prev_s[e];
+        sm_config(c, st0[i], E.clear_ahead[e], &r.target_speed, &r.overrides, &r.max_stop_distance);
+        r.episode = i;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (L.observe_n > 0) { HIP_TRY(h, hipStreamSynchronize(h->stream)); L.observe_n = -1; }
+    // (all records of the step in one pinned block that must not move between the two plan calls)
+    HIP_TRY(h, L.hRec.ensure(sizeof(fot_result) * (size_t)n * (size_t)max_lvl));
+    fot_loop_frame fr = *frame;
+    fr.ego = ego4.data();
+    std::vector<fot_safety> m((size_t)n);
+    const fot_result *rec = nullptr;
+    { int rc = loop_plan_impl(h, &fr, n, req.data(), m.data(), &rec, 0); if (rc != FOT_OK) return rc; }
+    rec = (const fot_result *)L.hRec.p;
+    for (int i = 0; i < n; ++i) E.last_clearance[episode[i]] = m[i].clearance_ahead;
+    // --- episodes whose first attempt failed: every further escalation level they can reach in ONE more launch (the
+    //     configurations update(False, ...) would issue on THIS step's metrics, nearest-point cache chained)
+    std::vector<int> next_rec((size_t)n, -1);
+    std::vector<fot_loop_request> more;
+    for (int i = 0; i < n; ++i) {
+        if (rec[i].status == FOT_PLAN_OK || n_lvl[i] <= 1) continue;
+        const int e = episode[i];
+        next_rec[i] = n + (int)more.size();
+        const double nps0 = rec[i].new_prev_s, p = std::isnan(nps0) ? E.prev_s[e] : nps0;
+        for (int lvl = 1; lvl < n_lvl[i]; ++lvl) {
+            fot_loop_request r = req[i];
+            const bool chain = lvl > 1;
+            r.ego.has_prev_s = chain ? FOT_PREV_S_CHAINED : (std::isnan(p) ? 0 : 1);
+            r.ego.prev_s = (chain || std::isnan(p)) ? 0.0 : p;
+            sm_config(c, st0[i] + lvl, m[i].clearance_ahead, &r.target_speed, &r.overrides, &r.max_stop_distance);
+            more.push_back(r);
+        }
+    }
+    int n_rec = n;
+    if (!more.empty()) {
+        const fot_result *unused = nullptr;
+        int rc = loop_plan_impl(h, nullptr, (int)more.size(), more.data(), nullptr, &unused, n);
+        if (rc != FOT_OK) return rc;
+        rec = (const fot_result *)L.hRec.p;
+        n_rec += (int)more.size();
+    }
+    // --- replay of the retry loop (integrated_simulator.py:576-653), episode by episode
+    std::vector<int> path_rec((size_t)n, -1);
+    auto adopt = [&](int i, int r) {                             // planner state after a plan() call
+        const int e = episode[i];
+        if (!std::isnan(rec[r].new_prev_s)) E.prev_s[e] = rec[r].new_prev_s;
+        for (int k = 0; k < 8; ++k) E.stats[8 * (size_t)e + k] = rec[r].stats_valid ? rec[r].stats[k] : -1;
+        if (rec[r].status == FOT_PLAN_OK) { E.last_kappa[e] = rec[r].new_last_kappa; path_rec[i] = r; }
+    };
+    for (int i = 0; i < n; ++i) {
+        const int e = episode[i];
+        int cur = i, retries = 0;
+        adopt(i, cur);
+        bool found = rec[cur].status == FOT_PLAN_OK;
+        int issued = st0[i];                                      // state of the configuration the attempt ran under
+        sm_update(E, e, found, m[i].clearance, m[i].clearance_ahead, speed[i]);
+        while (!found && E.state[e] != issued && retries < c.max_replan && retries + 1 < n_lvl[i]) {
+            cur = retries == 0 ? next_rec[i] : cur + 1;
+            ++retries;
+            adopt(i, cur);
+            const bool ok = rec[cur].status == FOT_PLAN_OK;
+            found = found || ok;
+            issued = E.state[e];
+            if (!ok) sm_update(E, e, false, m[i].clearance, m[i].clearance_ahead, speed[i]);
+        }
+    }
+    // --- ego update (:655-676) or emergency stop (:749-802)
+    std::vector<double> ego5n(5 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int e = episode[i];
+        double *g = &E.ego[5 * (size_t)e];
+        const double old_a = g[4];
+        const int r = path_rec[i];
+        const int keep = r >= 0 ? rec[r].n_keep : 0;
+        double jerk;
+        if (keep >= 2) {
+            g[0] = rec[r].x[1]; g[1] = rec[r].y[1]; g[2] = rec[r].yaw[1]; g[3] = rec[r].v[1]; g[4] = rec[r].a[1];
+            jerk = (g[4] - old_a) / c.dt;
+        } else {
+            // the position integrates along the heading at the OLD speed; the deceleration is what stopping 0.2 m short
+            // of the nearest pedestrian ahead needs, bounded to [max_accel, emergency_decel]
+            const double v = g[3], clr = E.last_clearance[e];
+            const double cap = std::isnan(c.emergency_decel) ? c.max_accel * 2.0 : c.emergency_decel;
+            const double required = std::isfinite(clr) ? v * v / (2.0 * std::fmax(clr - 0.2, 0.05)) : cap;
+            const double max_dec = std::fmin(std::fmax(required, c.max_accel), cap);
+            const double nv = std::fmax(0.0, v - max_dec * c.dt), na = nv > 0.0 ? -max_dec : 0.0;
+            g[0] = g[0] + v * std::cos(g[2]) * c.dt; g[1] = g[1] + v * std::sin(g[2]) * c.dt;
+            g[3] = nv; g[4] = na;
+            jerk = (na - old_a) / c.dt;
+            E.last_kappa[e] = 0.0;                                // planner.reset_ego_curvature()
+        }
+        for (int k = 0; k < 5; ++k) ego5n[5 * (size_t)i + k] = g[k];
+        if (out->ego) for (int k = 0; k < 5; ++k) out->ego[5 * (size_t)i + k] = g[k];
+        if (out->jerk) out->jerk[i] = jerk;
+        if (out->record) out->record[i] = r;
+        if (out->keep) out->keep[i] = keep;
+        if (out->cost) out->cost[i] = rec[r >= 0 ? r : 0].cost;
+    }
+    // --- result metrics on the new ego states and the goal test's nearest point (:864-883): enqueued, the rest of the
+    //     outputs filled while they run
+    std::vector<double> gps((size_t)n);
+    for (int i = 0; i < n; ++i) gps[i] = E.goal_prev_s[episode[i]];
+    { int rc = fot_loop_observe_begin(h, n, ego5n.data(), gps.data()); if (rc != FOT_OK) return rc; }
+    for (int i = 0; i < n; ++i) {
+        const int e = episode[i];
+        if (out->state) out->state[i] = E.state[e];
+        if (out->stats) for (int k = 0; k < 8; ++k) out->stats[8 * (size_t)i + k] = E.stats[8 * (size_t)e + k];
+        if (out->before) out->before[i] = m[i];
+    }
+    std::vector<fot_safety> after((size_t)n);
+    { int rc = fot_loop_observe_end(h, after.data(), gps.data()); if (rc != FOT_OK) return rc; }
+    for (int i = 0; i < n; ++i) {
+        E.goal_prev_s[episode[i]] = gps[i];
+        if (out->after) out->after[i] = after[i];
+        if (out->s_now) out->s_now[i] = gps[i];
+    }
+    out->records = rec;
+    out->n_records = n_rec;
+    return FOT_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int fot_gather_paths(const fot_result *records, int32_t n, const int32_t *index, int32_t kmax, double *out)
 {

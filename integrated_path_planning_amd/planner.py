@@ -378,6 +378,64 @@ class BatchPlanner:
             records = np.zeros(0, dtype=self.RESULT_DT)
         return records, (metrics[:n] if metrics is not None else None)
 
+    def loop_begin(self, config: "_abi.LoopConfig", ego5: np.ndarray) -> None:
+        """``fot_loop_begin``: n episode slots (ego5 [n, 5] = x, y, yaw, v, a), every fail-safe machine NORMAL."""
+        ego = np.ascontiguousarray(ego5, dtype=np.float64).reshape(-1, 5)
+        self._loop_n = len(ego)
+        _abi.check(self._h, self._lib.fot_loop_begin(self._h, len(ego), C.addressof(config), _addr(ego) if len(ego) else None))
+
+    def loop_step(self, frame: dict, episode: np.ndarray) -> dict:
+        """``fot_loop_step``: the whole lock step of the frame's episodes (``episode[i]`` = slot of episode i) in one
+        call -- prediction, metrics, level-0 plans, escalation levels of the failed ones, the retry loop, ego update /
+        emergency stop, metrics of the new states and their nearest path point.  ``frame`` as for ``loop_plan`` (no
+        ``ego``).  Returns the per-episode outputs as arrays plus ``records``: a structured VIEW of the step's records in
+        the handle's pinned block, valid until the next loop call."""
+        f, keep = self._loop_frame(frame)
+        ep = np.ascontiguousarray(episode, dtype=np.int32)
+        n = len(ep)
+        o = dict(ego=np.zeros((n, 5)), jerk=np.zeros(n), state=np.zeros(n, np.int32), stats=np.zeros((n, 8), np.int32),
+                 record=np.zeros(n, np.int32), keep=np.zeros(n, np.int32), cost=np.zeros(n),
+                 before=np.zeros(max(n, 1), dtype=self.SAFETY_DT), after=np.zeros(max(n, 1), dtype=self.SAFETY_DT),
+                 s_now=np.zeros(n))
+        so = _abi.LoopStepOut()
+        for name, arr in o.items():
+            setattr(so, name, _addr(arr) if arr.size else None)
+        fn = _fast(self._lib, "fot_loop_step", _vp, _vp, _vp, _vp)
+        _abi.check(self._h, fn(self._h, C.addressof(f), _addr(ep) if n else None, C.addressof(so)))
+        if so.n_records and so.records:
+            buf = (C.c_char * (so.n_records * _abi.RESULT_BYTES)).from_address(so.records)
+            o["records"] = np.frombuffer(buf, dtype=self.RESULT_DT, count=so.n_records)
+        else:
+            o["records"] = np.zeros(0, dtype=self.RESULT_DT)
+        o["before"], o["after"] = o["before"][:n], o["after"][:n]
+        return o
+
+    def _loop_frame(self, frame: dict):
+        """fot_loop_frame from the dictionary ``loop_plan`` / ``loop_step`` take (+ the arrays it points into)."""
+        f, keep = _abi.LoopFrame(), []
+        off = np.ascontiguousarray(frame["ped_off"], dtype=np.int32)
+        n = len(off) - 1
+        f.n_episodes, f.pred_len = n, int(frame.get("pred_len", 1))
+        f.use_footprint = int(bool(frame.get("use_footprint", True)))
+        pos = np.ascontiguousarray(frame["ped_pos"], dtype=np.float64)
+        vel = np.ascontiguousarray(frame["ped_vel"], dtype=np.float64)
+        f.ped_off, f.ped_pos, f.ped_vel = _addr(off), _addr(pos) if pos.size else None, _addr(vel) if vel.size else None
+        keep += [off, pos, vel]
+        if frame.get("obs_last") is not None:
+            last = np.ascontiguousarray(frame["obs_last"], dtype=np.float32)
+            pre = np.ascontiguousarray(frame["prepend"], dtype=np.uint8)
+            f.obs_last, f.prepend = _addr(last), _addr(pre) if pre.size else None
+            keep += [last, pre]
+            if frame.get("obs_prev") is not None:
+                prev = np.ascontiguousarray(frame["obs_prev"], dtype=np.float32)
+                f.obs_prev = _addr(prev)
+                keep.append(prev)
+            f.rp = frame["rp"]
+        f.staleness = float(frame.get("staleness", 0.0))
+        f.ego_radius, f.ped_radius = float(frame["ego_radius"]), float(frame["ped_radius"])
+        f._keep = keep                                               # (the arrays live as long as the structure)
+        return f, keep
+
     def gather_paths(self, records: np.ndarray, index: np.ndarray, kmax: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         """The first ``kmax`` samples of the 15 path arrays of ``records[index]`` as one dense [15, n, kmax] block
         (``fot_gather_paths``; ``_abi.PATH_FIELDS`` order), written into ``out`` (C-contiguous, that shape) if given."""

@@ -111,10 +111,15 @@ def test_two_calls_per_step_equal_five_calls_per_step(episodes):
         for h, ep, n in zip(h_plain, plain.episodes, names):
             assert_episode_matches(h, ep.termination_reason, episodes, n)
         h_plain = [list(h) for h in h_plain]
-    with BatchedClosedLoop(cfg, tracks) as fused:
-        assert fused._fused
+    with BatchedClosedLoop(cfg, tracks, fused="two-call") as fused:
+        assert fused._fused and not fused._native
         h_fused = [list(h) for h in fused.run()]
     _same_histories(h_plain, h_fused)
+    # ... and the whole step behind ONE call (fot_loop_step: episode state, fail-safe machine and retry loop in the library)
+    with BatchedClosedLoop(cfg, tracks) as native:
+        assert native._native
+        h_native = [list(h) for h in native.run()]
+    _same_histories(h_plain, h_native)
 
 
 def test_fused_step_with_standing_and_walking_crowds(episodes):
@@ -129,8 +134,9 @@ def test_fused_step_with_standing_and_walking_crowds(episodes):
     none = np.zeros((len(walk), 0, 2))
     tracks = [stand, walk, none, stand[:, :3], walk[:, ::2]]
     runs = []
-    for fused in (False, True):
+    for fused in (False, "two-call", True):
         with BatchedClosedLoop(cfg, tracks, fused=fused) as sim:
             hists = sim.run(60)
         runs.append([list(h) for h in hists])
     _same_histories(runs[0], runs[1])
+    _same_histories(runs[0], runs[2])
