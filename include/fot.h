@@ -350,6 +350,15 @@ typedef struct fot_loop_frame {
     double staleness;               /* time since the observer's last sample (:463-470) */
     double ego_radius, ped_radius;
     fot_resample_params rp;
+    /* Distribution-aware planning (integrated_simulator.py:459-460, 514-525, 622-630) without a host round trip: the raw
+     * samples of a multi-sample predictor for ALL the frame's pedestrians, [dist_S][pred_len][sum P][2] in DEVICE memory
+     * (what dist_S Social-GAN forward passes on PyTorch-ROCm leave), anchored at obs_last.  They are resampled on the
+     * device (process_prediction, trajectory_predictor.py:233-313) straight into the handle's tensor, per episode a
+     * [dist_S][P_e][n_dense + 1][2] block led by the current positions in EVERY sample, and every request of the step
+     * plans against its episode's whole distribution under the handle's chance constraint.  NULL: the constant-velocity
+     * predictor above.  dist_dtype FOT_F32 | FOT_F64; dist_S <= FOT_MAX_SAMPLES. */
+    const void *dist_raw;
+    int32_t dist_S, dist_dtype;
 } fot_loop_frame;
 typedef struct fot_loop_request {
     fot_ego ego;

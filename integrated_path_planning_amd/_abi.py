@@ -89,7 +89,7 @@ class LoopFrame(C.Structure):                                      # fot_loop_fr
                 ("ped_off", C.c_void_p), ("ped_pos", C.c_void_p), ("ped_vel", C.c_void_p),
                 ("obs_last", C.c_void_p), ("obs_prev", C.c_void_p), ("prepend", C.c_void_p), ("ego", C.c_void_p),
                 ("staleness", C.c_double), ("ego_radius", C.c_double), ("ped_radius", C.c_double),
-                ("rp", ResampleParams)]
+                ("rp", ResampleParams), ("dist_raw", C.c_void_p), ("dist_S", C.c_int32), ("dist_dtype", C.c_int32)]
 
 
 class LoopRequest(C.Structure):                                    # fot_loop_request

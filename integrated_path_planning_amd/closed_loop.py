@@ -329,13 +329,17 @@ class BatchedClosedLoop:
     MAX_REPLAN = 3                                               # integrated_simulator.py:383
 
     def __init__(self, config, ped_tracks: Sequence[np.ndarray], ego_initial_states: Optional[Sequence] = None,
-                 device: int = -1, engine=None, resampler=None, sample_source=None, fused: Optional[bool] = None):
+                 device: int = -1, engine=None, resampler=None, sample_source=None, fused: Optional[bool] = None,
+                 device_samples: bool = False):
         """sample_source: the multi-sample predictor in front of the planner -- a callable
         ``(obs_last [P, 2], obs_prev [P, 2]) -> raw samples [S, pred_len, P, 2]`` at the predictor's own time step
         (what S forward passes of Social-GAN on PyTorch-ROCm return for the pedestrians of all running episodes; the
         tests script one).  With it the episodes plan against the whole distribution when the configuration says
         ``distribution_aware_planning`` (integrated_simulator.py:459-460, 514-525), otherwise against the sample closest
-        to the mean (``predict_single_best``, trajectory_predictor.py:340-352).  None: the constant-velocity predictor."""
+        to the mean (``predict_single_best``, trajectory_predictor.py:340-352).  None: the constant-velocity predictor.
+        device_samples: the sample source returns a ``torch`` tensor in DEVICE memory ([S, pred_len, sum P, 2], float32 or
+        float64) -- Social-GAN's own output on PyTorch-ROCm.  With ``distribution_aware_planning`` the samples then never
+        leave the GPU: they are resampled into the planner's tensor inside the lock step's one call (fot_loop_step)."""
         self.config = config if not isinstance(config, dict) else _Cfg(config)
         c = self.config
         self.dt = float(c.dt)
@@ -366,7 +370,10 @@ class BatchedClosedLoop:
         self.s_end = float(self.engine.path_coeffs()[0][-1])
         # the step's device work in two calls, prediction resident in HBM (fot_loop_*): the constant-velocity predictor
         # on the library's own engine; a sample source hands its samples over on the host, stand-in engines have no device
-        can_fuse = sample_source is None and resampler is None and hasattr(self.engine, "loop_plan")
+        self._device_samples = bool(device_samples)
+        if self._device_samples and not (sample_source is not None and self.distribution_aware and engine is None and resampler is None):
+            raise ValueError("device_samples needs a sample_source, distribution_aware_planning and the library's own engine")
+        can_fuse = (sample_source is None or self._device_samples) and resampler is None and hasattr(self.engine, "loop_plan")
         if fused not in (None, False, True, "two-call"):
             raise ValueError("fused: None (automatic), False, True or 'two-call'")
         if fused and not can_fuse:
@@ -376,6 +383,8 @@ class BatchedClosedLoop:
         # fail-safe machine and the retry loop live in the handle); fused="two-call" keeps the round-3 form (two calls,
         # the retry loop replayed here on arrays) -- the tests run both against each other and against the five-call step
         self._native = self._fused and fused != "two-call" and hasattr(self.engine, "loop_step")
+        if self._device_samples and not self._native:
+            raise ValueError("device_samples runs through the one-call step only")
         if self._fused:
             self.engine.loop_set_static(self.static_obstacle_points)
         self.sgan_dt = 0.4                                            # integrated_simulator.py:323-327
@@ -445,10 +454,9 @@ class BatchedClosedLoop:
         """Release the libfot handle (streams, workspace) now rather than at garbage collection."""
         if self.engine is not None:
             for s in self._steps:                                     # predictions of fused steps nobody has read yet
-                if s["pred"] is None and s.get("pred_src") is not None:
-                    o32, stale = s["pred_src"]
-                    s["pred"] = self.resampler.predict_cv(o32, staleness=stale, float32_observations=True)
-                    s["pred_src"] = None
+                if s["pred"] is None and s.get("pred_src") is not None and not isinstance(s["pred_src"][0], str):
+                    s["pred"] = self._materialise_prediction(s["pred_src"], s["off"])
+                    s["pred_src"] = None                              # (a distribution's samples: only while somebody asks)
         if self._owns_engine and self.engine is not None:
             self.engine.close()
         self.engine = None
@@ -539,11 +547,7 @@ class BatchedClosedLoop:
                 else:
                     # predict_single_best (:340-352), per episode: the sample closest to the sample mean over the
                     # episode's own pedestrians
-                    dev = np.linalg.norm(dist - dist.mean(axis=0)[None], axis=-1).sum(axis=2)      # [S, sum P]
-                    per_ep = np.add.reduceat(dev, off[:-1], axis=1) if dev.shape[1] else np.zeros((len(dist), len(sel)))
-                    per_ep[:, off[:-1] == off[1:]] = 0.0                                      # (episodes without pedestrians)
-                    best = np.argmin(per_ep, axis=0)                                         # [episodes]
-                    pred = dist[np.repeat(best, off[1:] - off[:-1]), np.arange(dist.shape[1])]
+                    pred = self._best_sample(dist, off)
         t_pred = (time.perf_counter() - t0) / len(sel)
         if pred is None:
             return None, np.zeros(len(sel), bool), t_pred, None
@@ -673,6 +677,27 @@ class BatchedClosedLoop:
                                  clearance, clearance_ahead, lambda new_ego: self.engine.loop_observe_begin(new_ego, self.goal_prev_s[sel]),
                                  first=rec0)
 
+    def _best_sample(self, dist: np.ndarray, off: np.ndarray) -> np.ndarray:
+        """predict_single_best (trajectory_predictor.py:340-352) per episode: the sample closest to the sample mean over
+        the episode's own pedestrians -> [sum P, T, 2]."""
+        n = len(off) - 1
+        dev = np.linalg.norm(dist - dist.mean(axis=0)[None], axis=-1).sum(axis=2)      # [S, sum P]
+        per_ep = np.add.reduceat(dev, off[:-1], axis=1) if dev.shape[1] else np.zeros((len(dist), n))
+        per_ep[:, off[:-1] == off[1:]] = 0.0                                      # (episodes without pedestrians)
+        best = np.argmin(per_ep, axis=0)                                         # [episodes]
+        return dist[np.repeat(best, off[1:] - off[:-1]), np.arange(dist.shape[1])]
+
+    def _materialise_prediction(self, pred_src, off):
+        """The prediction a fused step left in HBM, computed again for whoever reads the step's record (same kernels,
+        same numbers): the constant-velocity tracks, or the best sample of the distribution's raw samples."""
+        if isinstance(pred_src[0], str):                              # ("dist", raw samples in HBM, observations, staleness)
+            _, raw, o32, stale = pred_src
+            raw_h = raw.detach().cpu().numpy().astype(np.float64)
+            dist = self.resampler.process_prediction(raw_h, anchor_pos=o32[1].astype(np.float64), staleness=stale)
+            return dist[0] if raw_h.shape[0] == 1 else self._best_sample(dist, np.asarray(off))
+        o32, stale = pred_src
+        return self.resampler.predict_cv(o32, staleness=stale, float32_observations=True)
+
     def _loop_frame(self, sel, off, pos, vel):
         """The frame of fot_loop_plan / fot_loop_step for the running episodes: pedestrians, the observer's last two
         samples, per episode whether the current positions lead the prediction (:503-511), staleness."""
@@ -695,6 +720,18 @@ class BatchedClosedLoop:
             frame.update(obs_last=o32[1], obs_prev=o32[0], prepend=~same, staleness=stale,
                          pred_len=self.resampler.pred_len, rp=self.resampler.params)
             pred_src = (o32, stale)
+            if self._device_samples:
+                # the multi-sample predictor's raw output stays in HBM: handed to the step as a device pointer
+                raw = self.sample_source(o32[1].astype(np.float64), o32[0].astype(np.float64))
+                if not (hasattr(raw, "data_ptr") and raw.is_cuda and raw.is_contiguous() and raw.dim() == 4):
+                    raise TypeError("device_samples: the sample source must return a contiguous CUDA tensor [S, pred_len, sum P, 2]")
+                import torch
+                if raw.dtype not in (torch.float32, torch.float64):
+                    raise TypeError("device_samples: float32 or float64 samples")
+                torch.cuda.current_stream(raw.device).synchronize()   # (the library reads it on its own stream)
+                frame.update(dist_raw=raw.data_ptr(), dist_S=int(raw.shape[0]),
+                             dist_dtype=_abi.F32 if raw.dtype == torch.float32 else _abi.F64, _raw=raw)
+                pred_src = ("dist", raw, o32, stale)
 
         return frame, pred_src
 
@@ -859,8 +896,7 @@ class BatchedClosedLoop:
             m["n_collision_rejected"] = int(s["stats"][i, _abi.ST_COLLISION])
         p = self.peds[e]
         if s["pred"] is None and s.get("pred_src") is not None:       # fused step: the prediction stayed in HBM
-            o32, stale = s["pred_src"]
-            s["pred"] = self.resampler.predict_cv(o32, staleness=stale, float32_observations=True)
+            s["pred"] = self._materialise_prediction(s["pred_src"], s["off"])
             s["pred_src"] = None
         return StepRecord(s["time"], ego, s["pos"][lo:hi].copy(), s["vel"][lo:hi].copy(), p.goals.copy(),
                           None if s["pred"] is None else s["pred"][lo:hi], path, m,

@@ -132,6 +132,7 @@ struct LoopState {
     std::vector<int32_t> ped_off;            // of the frame
     std::vector<int64_t> blk_off;            // first point of each episode's block in the tensor
     std::vector<int32_t> t_len;              // samples per track of each episode's block
+    int dist_S = 0;                          // > 0: the blocks are [dist_S][P_e][t_len][2] distributions
     bool have_frame = false;
     const void *dyn_ptr = nullptr;           // the tensor: dDyn, or the pinned current positions (predictor not ready)
     const int32_t *p_off = nullptr;          // the frame's pedestrians in hFrame
@@ -994,17 +995,21 @@ int loop_plan_impl(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, co
         const size_t n_ped = n > 0 ? (size_t)frame->ped_off[n] : 0;
         if (n_ped > 0 && (!frame->ped_pos || !frame->ped_vel)) return fail(h, FOT_ERR_INVALID, "frame: NULL pedestrian array");
         const bool ready = frame->obs_last != nullptr;
-        if (ready && n > 0 && !frame->prepend) return fail(h, FOT_ERR_INVALID, "frame: prepend missing");
+        const bool dist = ready && frame->dist_raw != nullptr;
+        if (dist && (frame->dist_S < 1 || frame->dist_S > FOT_MAX_SAMPLES || (frame->dist_dtype != FOT_F32 && frame->dist_dtype != FOT_F64)))
+            return fail(h, dist && frame->dist_S > FOT_MAX_SAMPLES ? FOT_ERR_UNSUPPORTED : FOT_ERR_INVALID, "frame: dist_S / dist_dtype");
+        if (ready && !dist && n > 0 && !frame->prepend) return fail(h, FOT_ERR_INVALID, "frame: prepend missing");
         if (ready && (!(frame->rp.sim_dt > 0.0) || !(frame->rp.sgan_dt > 0.0) || frame->pred_len < 1 ||
                       frame->pred_len > FOT_MAX_PRED_LEN))
             return fail(h, FOT_ERR_INVALID, "frame: predictor parameters");
         const int n_dense = ready ? resample_n_dense(frame->rp.sgan_dt, frame->rp.sim_dt, frame->rp.plan_horizon, frame->pred_len) : 1;
         if (n_dense + 1 > FOT_MAX_NT) return fail(h, FOT_ERR_UNSUPPORTED, "more than FOT_MAX_NT time steps");
-        // pinned block: ego[n][4] | ped_off | pos | vel | obs_last (widened) | obs_prev (widened)
+        // pinned block: ego[n][4] | ped_off | pos | vel | obs_last (widened) | obs_prev (widened) | block offsets | ped -> episode
         const size_t ego_b = align256(sizeof(double) * 4 * (size_t)std::max(n, 1));
         const size_t off_b = align256(sizeof(int32_t) * ((size_t)n + 1));
         const size_t ped_b = align256(sizeof(double) * 2 * std::max<size_t>(n_ped, 1));
-        HIP_TRY(h, L.hFrame.ensure(ego_b + off_b + 4 * ped_b));
+        const size_t blk_b = align256(sizeof(int64_t) * ((size_t)n + 1)), pe_b = align256(sizeof(int32_t) * std::max<size_t>(n_ped, 1));
+        HIP_TRY(h, L.hFrame.ensure(ego_b + off_b + 4 * ped_b + blk_b + pe_b));
         char *p = (char *)L.hFrame.p;
         double *p_ego = (double *)p;
         int32_t *p_off = (int32_t *)(p + ego_b);
@@ -1021,14 +1026,26 @@ int loop_plan_impl(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, co
         L.ped_off.assign(frame->ped_off, frame->ped_off + n + 1);
         L.blk_off.assign((size_t)n + 1, 0);
         L.t_len.assign((size_t)std::max(n, 1), 1);
+        L.dist_S = dist ? frame->dist_S : 0;
         for (int e = 0; e < n; ++e) {
-            L.t_len[e] = ready ? n_dense + (frame->prepend[e] ? 1 : 0) : 1;
-            L.blk_off[e + 1] = L.blk_off[e] + (int64_t)(L.ped_off[e + 1] - L.ped_off[e]) * L.t_len[e];
+            L.t_len[e] = dist ? n_dense + 1 : ready ? n_dense + (frame->prepend[e] ? 1 : 0) : 1;
+            L.blk_off[e + 1] = L.blk_off[e] + (int64_t)(dist ? frame->dist_S : 1) * (L.ped_off[e + 1] - L.ped_off[e]) * L.t_len[e];
         }
         L.p_off = p_off; L.p_pos = p_pos; L.p_vel = p_vel;
         L.ego_radius = frame->ego_radius; L.ped_radius = frame->ped_radius; L.use_footprint = frame->use_footprint;
         L.dyn_ptr = p_pos;                                         // not ready: the current positions, read in place
-        if (ready && n_ped > 0) {
+        if (dist && n_ped > 0) {
+            // every sample of every pedestrian in one launch, each episode's samples into its own [S][P_e][T][2] block
+            int64_t *p_blk = (int64_t *)((char *)p_prev + ped_b);
+            int32_t *p_pe = (int32_t *)((char *)p_blk + blk_b);
+            for (int e = 0; e <= n; ++e) p_blk[e] = L.blk_off[e];
+            for (int e = 0; e < n; ++e) for (int q = L.ped_off[e]; q < L.ped_off[e + 1]; ++q) p_pe[q] = e;
+            HIP_TRY(h, L.dDyn.ensure(sizeof(double) * 2 * (size_t)L.blk_off[n]));
+            L.dyn_ptr = L.dDyn.p;
+            LAUNCH_TRY(h, launch_resample(frame->rp.sgan_dt, frame->rp.sim_dt, frame->staleness, frame->dist_S, frame->pred_len,
+                                          (int)n_ped, n_dense, 1, 1, 0, frame->dist_raw, frame->dist_dtype, p_last, p_pos,
+                                          L.dDyn.p, FOT_F64, 0, st, p_pe, p_off, p_blk));
+        } else if (ready && n_ped > 0) {
             HIP_TRY(h, L.dDyn.ensure(sizeof(double) * 2 * (size_t)L.blk_off[n]));
             L.dyn_ptr = L.dDyn.p;
             // one launch per run of episodes that agree on the prepend (normally one run: the whole frame)
@@ -1078,7 +1095,8 @@ int loop_plan_impl(fot_handle *h, const fot_loop_frame *frame, int32_t n_req, co
             s_off[j] = j * n_static;
             const int P_e = L.ped_off[e + 1] - L.ped_off[e];
             d_off[j] = L.blk_off[e];
-            dims[4 * j] = P_e > 0 ? FOT_DYN_SINGLE : FOT_DYN_NONE; dims[4 * j + 1] = 1; dims[4 * j + 2] = P_e; dims[4 * j + 3] = L.t_len[e];
+            dims[4 * j] = P_e > 0 ? (L.dist_S > 0 ? FOT_DYN_DISTRIBUTION : FOT_DYN_SINGLE) : FOT_DYN_NONE;
+            dims[4 * j + 1] = L.dist_S > 0 ? L.dist_S : 1; dims[4 * j + 2] = P_e; dims[4 * j + 3] = L.t_len[e];
             any_dyn = any_dyn || P_e > 0;
         }
         s_off[n_req] = n_req * n_static;

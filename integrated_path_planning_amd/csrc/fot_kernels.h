@@ -93,7 +93,8 @@ int launch_pack_wire(int n, int n_total, int stride, const fot_result *src, unsi
 int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipStream_t st);
 int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
                     int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
-                    const double *current, void *out, int out_dtype, int tmajor, hipStream_t st);
+                    const double *current, void *out, int out_dtype, int tmajor, hipStream_t st,
+                    const int32_t *ped_ep = nullptr, const int32_t *ep_ped0 = nullptr, const int64_t *ep_blk = nullptr);
 int launch_sample_dist(int S, int P, int T, int skip, const void *out, int out_dtype, int tmajor, double *dist,
                        hipStream_t st);
 int launch_safety(const DevParams *P, int n, const double *ego, const int32_t *ped_off, const double *ped_pos,

@@ -1648,6 +1648,10 @@ struct ResampleArgs {
     int S, pred_len, P, n_dense, T;          // T = n_dense + prepend
     int has_anchor, prepend, cv;             // cv: sources are (obs_prev, obs_last) -> constant velocity; 2: float32 obs
     int tmajor;                              // out[k][s][p][axis] (FOT_OUT_TMAJOR) instead of out[s][p][k][axis]
+    // per-episode blocks (the closed loop's distribution frame): pedestrian p belongs to episode ped_ep[p], whose
+    // pedestrians are [ep_ped0[e], ep_ped0[e + 1]) and whose [S][P_e][T][2] block starts at point ep_blk[e]; nullptr: one
+    // [S][P][T][2] tensor
+    const int32_t *ped_ep; const int32_t *ep_ped0; const int64_t *ep_blk;
 };
 
 // one thread per (sample, pedestrian, axis); out[s][p][k][axis]
@@ -1662,6 +1666,10 @@ __global__ void k_resample(ResampleArgs A, const TI *__restrict__ pred, const do
     // S x P plane apart in the T-major one (where neighbouring threads then write neighbouring addresses)
     const int64_t k_stride = A.tmajor ? (int64_t)A.S * A.P * 2 : 2;
     TO *dst = out + (A.tmajor ? (int64_t)sp * 2 : (int64_t)sp * A.T * 2) + ax;
+    if (A.ped_ep) {
+        const int e = A.ped_ep[p], p0 = A.ep_ped0[e], P_e = A.ep_ped0[e + 1] - p0;
+        dst = out + 2 * (A.ep_blk[e] + ((int64_t)smp * P_e + (p - p0)) * A.T) + ax;
+    }
     if (A.prepend) dst[0] = (TO)current[2 * p + ax];
     dst += k_stride * A.prepend;
     if (A.cv) {                                                     // predict_cv (:188-231)
@@ -1899,7 +1907,8 @@ int launch_spline_eval(SplineView sp, int n, const double *s, double *out, hipSt
 
 int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int pred_len, int P, int n_dense,
                     int has_anchor, int prepend, int cv, const void *pred, int pred_dtype, const double *anchor,
-                    const double *current, void *out, int out_dtype, int tmajor, hipStream_t st)
+                    const double *current, void *out, int out_dtype, int tmajor, hipStream_t st,
+                    const int32_t *ped_ep, const int32_t *ep_ped0, const int64_t *ep_blk)
 {
     const int total = S * P * 2;
     if (total <= 0) return 0;
@@ -1907,6 +1916,8 @@ int launch_resample(double sgan_dt, double sim_dt, double staleness, int S, int 
     A.sgan_dt = sgan_dt; A.sim_dt = sim_dt; A.staleness = staleness;
     A.S = S; A.pred_len = pred_len; A.P = P; A.n_dense = n_dense; A.T = n_dense + (prepend ? 1 : 0);
     A.has_anchor = has_anchor; A.prepend = prepend; A.cv = cv; A.tmajor = tmajor;
+    A.ped_ep = ped_ep; A.ep_ped0 = ep_ped0; A.ep_blk = ep_blk;
+    if (ped_ep && tmajor) return (int)hipErrorInvalidValue;
     const int bs = 128, grid = (total + bs - 1) / bs;
     if (pred_dtype == FOT_F32 && out_dtype == FOT_F32)
         k_resample<float, float><<<grid, bs, 0, st>>>(A, (const float *)pred, anchor, current, (float *)out);

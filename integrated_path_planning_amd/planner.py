@@ -431,6 +431,8 @@ class BatchPlanner:
                 f.obs_prev = _addr(prev)
                 keep.append(prev)
             f.rp = frame["rp"]
+        if frame.get("dist_raw") is not None:                          # raw samples of a multi-sample predictor, in HBM
+            f.dist_raw, f.dist_S, f.dist_dtype = int(frame["dist_raw"]), int(frame["dist_S"]), int(frame["dist_dtype"])
         f.staleness = float(frame.get("staleness", 0.0))
         f.ego_radius, f.ped_radius = float(frame["ego_radius"]), float(frame["ped_radius"])
         f._keep = keep                                               # (the arrays live as long as the structure)

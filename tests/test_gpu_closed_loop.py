@@ -63,6 +63,30 @@ def test_replicated_episodes_are_identical(episodes):
     sim.close()
 
 
+@pytest.mark.parametrize("name", ["s6_eps02", "s4_eps0"])
+def test_distribution_aware_episodes_with_samples_resident_in_hbm(name):
+    """The same reference episodes with the predictor's raw samples handed over as a DEVICE tensor (what Social-GAN on
+    PyTorch-ROCm leaves): resampled into the planner's tensor inside the step's one call (fot_loop_step with
+    fot_loop_frame.dist_raw), never crossing PCIe -- against the reference, and step by step against the run whose
+    samples travel through the host."""
+    import torch
+    ep = load_dist_episodes()
+    var = ep["meta"]["variants"][name]
+    cfg = dict(var["config"])
+    host_src = scripted_sample_source(var["n_samples"], cfg["pred_len"])
+    dev = torch.device("cuda", 0)
+    dev_src = lambda last, prev: torch.from_numpy(np.ascontiguousarray(host_src(last, prev), dtype=np.float64)).to(dev)
+    with BatchedClosedLoop(cfg, [ep[name + "_ped_traj"]] * 2, sample_source=dev_src, device_samples=True) as sim:
+        assert sim._native and sim._device_samples
+        hists = sim.run()
+        for h, e in zip(hists, sim.episodes):
+            assert_episode_matches(h, e.termination_reason, ep, name)
+        h_dev = [list(h) for h in hists]
+    with BatchedClosedLoop(cfg, [ep[name + "_ped_traj"]] * 2, sample_source=host_src) as sim:
+        h_host = [list(h) for h in sim.run()]
+    _same_histories(h_host, h_dev)
+
+
 @pytest.mark.parametrize("name", ["s6_eps02", "s4_eps0", "s5_best_only"])
 def test_distribution_aware_episodes_match_the_reference(name):
     """Rolling-horizon episodes of the headline workload's kind: every step a sampled prediction DISTRIBUTION of all
