@@ -705,19 +705,26 @@ class BatchedClosedLoop:
                      ped_radius=self.ped_radius, use_footprint=self.footprint is not None)
         pred_src = None
         if self.observer.is_ready:
-            rows = self._rows_of(sel)
             hist = self.observer.history
-            o32 = np.stack([hist[-2][rows], hist[-1][rows]], axis=0).astype(np.float32)
+            if len(sel) == len(self.peds):                            # every episode still runs: the samples as they are
+                o32 = np.empty((2,) + hist[-1].shape, np.float32)
+                o32[0], o32[1] = hist[-2], hist[-1]
+            else:
+                rows = self._rows_of(sel)
+                o32 = np.stack([hist[-2][rows], hist[-1][rows]], axis=0).astype(np.float32)
             last = self.observer.last_sample_time
             stale = max(self.ped_time - last, 0.0) if last is not None else 0.0
-            # np.allclose(pred[:, 0], current) (:503-511) needs the first predicted sample only: obs_last + v (dt + stale),
-            # the velocity formed in float32 as the kernel (and the reference, trajectory_predictor.py:216) forms it
-            vel32 = (o32[1] - o32[0]) / np.float32(self.sgan_dt)
-            first = o32[1].astype(np.float64) + vel32.astype(np.float64) * ((self.dt + 0.0 * self.dt) + stale)
-            far = np.any(np.abs(first - pos) > 1e-8 + 1e-5 * np.abs(pos), axis=1)
-            n_far = np.concatenate([[0], np.cumsum(far)])
-            same = n_far[off[1:]] == n_far[off[:-1]]                  # per episode (True without pedestrians)
-            frame.update(obs_last=o32[1], obs_prev=o32[0], prepend=~same, staleness=stale,
+            if self._device_samples:
+                prepend = np.ones(len(sel), bool)                     # (the current positions lead EVERY sample, :514-525)
+            else:
+                # np.allclose(pred[:, 0], current) (:503-511) needs the first predicted sample only: obs_last + v (dt + stale),
+                # the velocity formed in float32 as the kernel (and the reference, trajectory_predictor.py:216) forms it
+                vel32 = (o32[1] - o32[0]) / np.float32(self.sgan_dt)
+                first = o32[1].astype(np.float64) + vel32.astype(np.float64) * ((self.dt + 0.0 * self.dt) + stale)
+                far = np.any(np.abs(first - pos) > 1e-8 + 1e-5 * np.abs(pos), axis=1)
+                n_far = np.concatenate([[0], np.cumsum(far)])
+                prepend = n_far[off[1:]] != n_far[off[:-1]]           # per episode (False without pedestrians)
+            frame.update(obs_last=o32[1], obs_prev=o32[0], prepend=prepend, staleness=stale,
                          pred_len=self.resampler.pred_len, rp=self.resampler.params)
             pred_src = (o32, stale)
             if self._device_samples:

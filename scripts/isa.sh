@@ -1,7 +1,7 @@
 #!/bin/bash
 # device ISA of fot_kernels.hip into /tmp/isa/fot.s + register / spill summary per kernel; extra args go to hipcc
 mkdir -p /tmp/isa
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -S --cuda-device-only "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=on --offload-arch=gfx950 -Wno-unused-function -S --cuda-device-only "$@" \
     -o /tmp/isa/fot.s /root/repo/integrated_path_planning_amd/csrc/fot_kernels.hip 2>/dev/null
 python3 - <<'PY'
 import re

@@ -34,3 +34,50 @@ print("episodes %d: %.4f ms per lock step" % (n_ep, wall / n * 1e3))
 for k, v in sorted(spent.items(), key=lambda kv: -kv[1]):
     print("  %-22s %.4f ms per step (%d calls)" % (k, v / n * 1e3, calls[k]))
 loop.close()
+
+# ---- the distribution form (bench.py f4_closed_loop_dist): 256 episodes x 20 samples x 30 pedestrians from a device tensor
+if len(sys.argv) > 2 and sys.argv[2] == "dist":
+    dev = torch.device("cuda", 0)
+    n_epi, S, P = n_ep, 20, 30
+    cfg_d = dict(cfg, distribution_aware_planning=True, prediction_method="sgan")
+    rng = np.random.default_rng(4)
+    t_fr = np.arange(400)[:, None, None] * cfg_d["dt"]
+    tracks = []
+    for _ in range(n_epi):
+        p0 = np.column_stack([rng.uniform(-10.0, 90.0, P), rng.uniform(-25.0, 25.0, P)])
+        e0 = np.asarray(cfg_d["ego_initial_state"], float)[:2]
+        near = np.linalg.norm(p0 - e0, axis=1) < 8.0
+        p0[near, 1] += np.where(p0[near, 1] >= e0[1], 10.0, -10.0)
+        hd, sp = rng.uniform(0.0, 2.0 * np.pi, P), rng.normal(1.3, 0.2, P)
+        tracks.append(p0[None] + np.column_stack([sp * np.cos(hd), sp * np.sin(hd)])[None] * t_fr)
+    L = int(cfg_d["pred_len"])
+    dv = torch.randn(S, 1, n_epi * P, 2, device=dev) * 0.3
+    walk = torch.cumsum(torch.randn(S, L, n_epi * P, 2, device=dev) * 0.05, dim=1)
+    tk = (torch.arange(1, L + 1, device=dev, dtype=torch.float32) * 0.4).view(1, L, 1, 1)
+
+    def src(last, prev):
+        la = torch.from_numpy(last.astype(np.float32)).to(dev)
+        ve = (la - torch.from_numpy(prev.astype(np.float32)).to(dev)) / 0.4
+        m = la.shape[0]
+        out = (la.view(1, 1, -1, 2) + (ve.view(1, 1, -1, 2) + dv[:, :, :m]) * tk + walk[:, :, :m]).contiguous()
+        torch.cuda.current_stream(dev).synchronize()
+        return out
+    loop = BatchedClosedLoop(cfg_d, tracks, sample_source=src, device_samples=True)
+    spent.clear(); calls.clear()
+    for nm in ("loop_step", "gather_paths"):
+        wrap(loop.engine, nm)
+    wrap(loop, "_loop_frame"); wrap(loop, "_advance_pedestrians"); wrap(loop, "_step_native"); wrap(loop, "sample_source")
+    for _ in range(5): loop.step()
+    spent.clear(); calls.clear()
+    t0 = time.perf_counter(); n = 0
+    for _ in range(60):
+        if loop.step() == 0: break
+        n += 1
+    wall = time.perf_counter() - t0
+    print("dist, episodes %d: %.4f ms per lock step" % (n_epi, wall / n * 1e3))
+    for k, v in sorted(spent.items(), key=lambda kv: -kv[1]):
+        print("  %-22s %.4f ms per step (%d calls)" % (k, v / n * 1e3, calls[k]))
+    loop.engine.profile(True)
+    for _ in range(20): loop.step()
+    print("  kernels:", {k: round(v["total_ms"] / 20, 4) for k, v in loop.engine.profile_read().items()})
+    loop.close()

@@ -5,6 +5,6 @@ set -e
 cd "$(dirname "$0")/.."
 make -C integrated_path_planning_amd/csrc clean > /dev/null
 # (make runs the ISA guard on this build too and fails it on a finding: scripts/isa_check_async.py)
-make -C integrated_path_planning_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DFOT_TIMELINE" | grep -v hipcc
+make -C integrated_path_planning_amd/csrc EXTRA="-DFOT_TIMELINE" | grep -v hipcc
 # the cut the handle picks (grouped for the default lattice); FOT_TILE_CUT=wave|group forces one
 timeout -k 10 200 python3 scripts/timeline.py

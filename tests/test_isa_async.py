@@ -117,7 +117,7 @@ def test_makefile_runs_the_guard():
 @pytest.mark.parametrize("flags", [[], ["-DFOT_TIMELINE"]], ids=["default", "timeline"])
 def test_current_sources_pass_under_every_flag_set_the_scripts_build(tmp_path, flags):
     s = tmp_path / "fot.s"
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only",
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "-ffp-contract=on", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only",
                     *flags, "-o", str(s), os.path.join(ROOT, "integrated_path_planning_amd", "csrc", "fot_kernels.hip")],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
     r = subprocess.run([sys.executable, GUARD, str(s)], capture_output=True, text=True, timeout=120)
