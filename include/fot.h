@@ -126,8 +126,8 @@ typedef struct fot_result {
     double frenet0[6];           /* s, s_d, s_dd, d, d_d, d_dd of the ego (frenet_planner.py:371) */
     double ref0[6];              /* rs, rx, ry, rtheta, rkappa, rdkappa (coordinate_converter.py:308) */
     /* path arrays: entries [0, n_keep) hold the path, [n_keep, n_total) are written as zero, entries from
-     * n_total = round(max_t/dt)+1 on are NEVER touched (fot_plan_batch hands them back zero; a caller of
-     * fot_plan_batch_device who compares whole records zero-fills its buffer once) */
+     * n_total = round(max_t/dt)+1 on are NEVER touched, neither in a device-resident record nor in the caller's host
+     * record (a caller who compares whole records zero-fills its buffer once) */
     double t[FOT_MAX_NT], s[FOT_MAX_NT], s_d[FOT_MAX_NT], s_dd[FOT_MAX_NT], s_ddd[FOT_MAX_NT];
     double d[FOT_MAX_NT], d_d[FOT_MAX_NT], d_dd[FOT_MAX_NT], d_ddd[FOT_MAX_NT];
     double x[FOT_MAX_NT], y[FOT_MAX_NT], yaw[FOT_MAX_NT], v[FOT_MAX_NT], a[FOT_MAX_NT], c[FOT_MAX_NT];

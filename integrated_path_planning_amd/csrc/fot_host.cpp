@@ -1516,7 +1516,15 @@ int fot_plan_batch(fot_handle *h, const fot_batch *batch, fot_result *out)
         if (rc != FOT_OK) { h->done_seq_armed = false; return rc; }
         rc = wait_records(h, batch->n_inst, h->stream);
         if (rc != FOT_OK) return rc;
-        std::memcpy(out, h->hRecOut.p, out_bytes);
+        // what the device wrote of each record: the header and the first n_total entries of the 15 path arrays (a fifth of
+        // the record at 51 samples -- the whole-record copy cost a one-ego call 2 us); the caller's entries past n_total stay
+        // as they are
+        const size_t head = offsetof(fot_result, t), used = sizeof(double) * (size_t)h->P.n_total;
+        for (int i = 0; i < batch->n_inst; ++i) {
+            const fot_result *src = (const fot_result *)h->hRecOut.p + i;
+            std::memcpy(&out[i], src, head);
+            for (int f = 0; f < 15; ++f) std::memcpy(out[i].t + (size_t)f * FOT_MAX_NT, src->t + (size_t)f * FOT_MAX_NT, used);
+        }
         return FOT_OK;
     }
     HIP_TRY(h, h->dUserStatic.ensure(std::max<size_t>(st_bytes, 16)));
