@@ -422,8 +422,17 @@ int enqueue_lane(fot_handle *h, Workspace &w, const fot_batch &b, const void *d_
     imp.d_desc = (InstDesc *)w.dMeta.p;
     // one scan block per 256 KB of an instance's tensor (few, fat blocks: each first reads its descriptor out of the
     // pinned staging block, a PCIe round trip), at most 64 per instance
+    // Only time-major tensors are scanned (k_cull finds the NaN tracks of the caller's [S][P][T] layout itself, among the
+    // few its boxes touch); a small call's tensors in pinned memory take the same blocks for their one pass over PCIe.
+    // (FOT_NAN_SCAN=eager: the scan blocks for every layout, as before round 4 -- the scan then doubles as a prefetch of
+    // the tensor into the memory-side cache: 4 us less on the serial step of config 4, the same step with three calls in
+    // flight, the tensor read twice.  A small call's staging pass leaves the flags behind anyway: k_cull uses them.)
+    static const bool eager_env = getenv("FOT_NAN_SCAN") && !std::strcmp(getenv("FOT_NAN_SCAN"), "eager");
+    const bool eager_nan = eager_env || d_dyn_stage != nullptr;
+    ea.eager_nan = eager_nan ? 1 : 0;
     NanScan scan;
-    if (L.n_tracks > 0) {
+    scan.eager = ea.eager_nan;
+    if (L.n_tracks > 0 && (L.any_tmajor || eager_nan)) {
         scan.dyn_xy = d_dyn; scan.dtype = b.obstacle_dtype; scan.flag = w.dNanFlag.as<uint8_t>();
         scan.blocks_per_inst = (int)std::min<int64_t>(64, std::max<int64_t>(1, (L.max_dyn_bytes + 262143) / 262144));
         if (d_dyn_stage) {                                       // (cull and the rest read the copy)

@@ -41,6 +41,7 @@ struct EntryArrays {
     uint8_t *sid;      // prediction sample of the entry, SID_STATIC for static obstacles
     TileStep *rng;     // [n_tiles][n_total] what a tile needs of time step k: chunk range + float32 thresholds
     const uint8_t *nan_flag = nullptr;   // [n_tracks] NanScan::flag
+    int eager_nan = 0;                   // the flags are there for every layout (NanScan::eager): k_cull looks nothing up itself
 };
 
 // The reference ignores a pedestrian whose track holds a NaN coordinate at ANY time step, at EVERY time step (its
@@ -53,6 +54,7 @@ struct NanScan {
     int dtype = 0;
     uint8_t *flag = nullptr;            // [n_tracks] 1: the track holds a NaN
     int blocks_per_inst = 0;
+    int eager = 0;                      // scan [S][P][T] tensors too (FOT_NAN_SCAN=eager; default: k_cull finds their NaNs)
     void *stage = nullptr;              // HBM copy of the tensors, written as they are scanned (same offsets), or nullptr:
                                         // a small call's tensors lie in pinned host memory -- one pass over PCIe instead
                                         // of three (scan, classification, scatter)

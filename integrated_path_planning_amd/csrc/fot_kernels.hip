@@ -246,6 +246,7 @@ __device__ __forceinline__ void frenet_state_block(const DevParams *__restrict__
         const int b = inst - n_inst, si = b / scan.blocks_per_inst, part = b - si * scan.blocks_per_inst;
         if (si >= n_inst) return;
         const InstDesc &D = (imp.h_desc ? imp.h_desc : desc)[si];
+        if (!D.dyn_tmajor && !scan.stage && !scan.eager) return;                // ([S][P][T] tensors in HBM: k_cull looks for NaNs itself)
         if (scan.dtype == FOT_F32)
             scan_nan_tracks(D, (const float *)scan.dyn_xy, scan.flag, part, scan.blocks_per_inst, (float *)scan.stage);
         else
@@ -1190,6 +1191,9 @@ constexpr int CULL_KG = 8;              // time steps (= waves) of a group in k_
 constexpr int CULL_LIST = 256;          // kept obstacles per time step remembered between the two passes
 constexpr int CULL_PBOX = 96;           // profiles per instance whose boxes are kept in LDS (more: recomputed)
 constexpr uint32_t CULL_IDX_MASK = 0xFFFFFu;   // obstacle index (< 2^20, fot_setup.hpp) | bin << 20
+constexpr int CULL_VER = 256;           // pedestrian tracks a group checks for NaN (the ones inside its boxes), [S][P][T] layout
+constexpr int CULL_BAD = 32;            // ... and tracks found to hold one, remembered by the group
+constexpr uint32_t CULL_DEAD = 0xFFFFFFFFu;    // a remembered obstacle that turned out to be such a track
 
 // One group: KG waves, the KG consecutive time steps from k0 of instance `inst`.  `sp`: the reference path as the caller
 // staged it; `dyn_lds`: (n_ti + n_brake) * (KG * 2 + 9) doubles of dynamic LDS (launch_cull).
@@ -1205,6 +1209,9 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     __shared__ int s_start[KG][CULL_BINS + 1];
     __shared__ int s_nin[KG];
     __shared__ uint32_t s_list[KG][CULL_LIST];              // kept obstacles of each step: index | bin << 20
+    __shared__ uint32_t s_ver[CULL_VER];                    // (lazy NaN check) tracks inside some box of the group
+    __shared__ uint32_t s_bad[CULL_BAD];                    // ... those that hold a NaN
+    __shared__ int s_nver, s_nbad;
     __shared__ Box32 s_box[KG];                             // per-step constants
     __shared__ BinMap s_bm[KG];
     __shared__ float s_margin[KG];
@@ -1243,6 +1250,7 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     __syncthreads();
     if (ablate & 16) return;                                     // (timing diagnostics: launch + per-instance constants)
 
+    struct Raw { T x, y; };                                       // as stored: widened only when it is classified
     const bool dyn_on = D.dyn_mode != FOT_DYN_NONE;
     const int n_dyn = dyn_on ? D.S * D.P : 0;
     const int total = D.n_static + n_dyn;
@@ -1256,7 +1264,6 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int i_first = tmajor ? lane : wv * (WAVE / KG) + lane / KG;
     constexpr int STRIDE = WAVE;                                  // obstacles between two of a lane's loads
     const int row_l = k0 + kl < D.T - 1 ? k0 + kl : D.T - 1;
-    struct Raw { T x, y; };                                       // as stored: widened only when it is classified
     // Branch-free: an index past the end is clamped (classify() ignores its value) and static / dynamic is a select
     // between two addresses, so the UNROLL loads of a lane are issued back to back -- behind a branch each one would
     // wait for the one before it, one gather in flight per lane, and the pass would crawl along at memory latency.
@@ -1305,8 +1312,28 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
         const float mw = cull_margin(sq_max, bw) + slack;
         if (lane == 0) { s_box[wv] = bw; s_margin[wv] = mw; s_bm[wv] = bin_map(bw, mw); s_nin[wv] = 0; }
         if (lane <= CULL_BINS) s_cnt[wv][lane] = 0;
+        if (tid == 0) { s_nver = 0; s_nbad = 0; }
     }
     __syncthreads();
+
+    // Which pedestrian tracks hold a NaN (NanScan, fot_kernels.h).  Time-major tensors: the flags k_frenet_state's scan
+    // blocks left.  The caller's [S][P][T][2] layout: LAZILY, here -- only a track that lies inside some box of the group
+    // can become an entry, its T samples are one contiguous run (408 bytes at T = 51: one wave-wide load) and the group's
+    // first pass has the 8 lanes of a track side by side, so the group collects the few dozen tracks its boxes touch
+    // (s_ver), its waves share them out and look through them, and nobody reads the tensor a second time just to find
+    // NaNs: the whole tensor crosses HBM once per plan call instead of twice.  (Every wave looking through its OWN
+    // tracks right behind its gathers, one barrier less, was 8 us slower: the slowest wave sets the pace.)
+    const bool lazy = dyn_on && !tmajor && !(ablate & 128);       // (128: NanScan::eager, the flags are there)
+    const Raw *tracks = (const Raw *)(dyn_xy + 2 * D.dyn_off);   // [n_dyn][T] in the caller's layout
+    auto track_has_nan = [&](int j) {                            // one lane on its own (the paths that did not fit)
+        bool bad = false;
+        for (int t = 0; t < D.T; ++t) { const Raw p = tracks[(int64_t)j * D.T + t]; bad |= (p.x != p.x) | (p.y != p.y); }
+        return bad;
+    };
+    auto track_bad = [&](int i) {                                // obstacle i, by whatever this instance's layout offers
+        if (i < D.n_static) return false;
+        return lazy ? track_has_nan(i - D.n_static) : nan_flag[D.nan_off + (i - D.n_static)] != 0;
+    };
 
     // pass 1: histogram per step, kept obstacles remembered
     {
@@ -1316,7 +1343,22 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
         const bool live_l = kl < nk && bl.x0 <= bl.x1 && !(ablate & 4);
         auto classify = [&](int i, const Raw &o) {
             const float fx = (float)((double)o.x - D.ego.x), fy = (float)((double)o.y - D.ego.y);
-            if (i < total && live_l && cull_inside(bl, ml, fx, fy)) {
+            const bool in = i < total && live_l && cull_inside(bl, ml, fx, fy);
+            if (lazy) {
+                // remembered, not yet counted: its track is looked through first.  The KG lanes of an obstacle are
+                // neighbours (lane & (KG - 1) = step): the first of them enters the track once for the whole group
+                const uint64_t m = __ballot(in && i >= D.n_static);
+                if ((lane & (KG - 1)) == 0 && ((m >> lane) & ((1ull << KG) - 1ull)) != 0ull) {
+                    const int v = atomicAdd(&s_nver, 1);
+                    if (v < CULL_VER) s_ver[v] = (uint32_t)i;
+                }
+                if (in) {
+                    const int j = atomicAdd(&s_nin[kl], 1);
+                    if (j < CULL_LIST) s_list[kl][j] = (uint32_t)i | ((uint32_t)bin_of(bml, fx, fy) << 20);
+                }
+                return;
+            }
+            if (in) {
                 // a pedestrian whose track holds a NaN anywhere is no obstacle at any step (NanScan; asked for the few
                 // obstacles inside the box only)
                 if (i >= D.n_static && nan_flag[D.nan_off + (i - D.n_static)]) return;
@@ -1326,7 +1368,10 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
                 if (j < CULL_LIST) s_list[kl][j] = (uint32_t)i | ((uint32_t)bin << 20);
             }
         };
-        constexpr int UNROLL = 4;                                 // gathers in flight per lane
+#ifndef FOT_CULL_UNROLL
+#define FOT_CULL_UNROLL 4
+#endif
+        constexpr int UNROLL = FOT_CULL_UNROLL;                   // gathers in flight per lane
         if (ablate & 64) {                                        // (timing diagnostics: no gathers)
         } else if (D.n_static == 0) {
             // only the prediction tensor (the usual case): a lane's obstacles are a fixed number of bytes apart, so the
@@ -1356,28 +1401,46 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
         }
     }
     __syncthreads();
+    if (lazy) {
+        // the tracks inside the group's boxes, one wave-wide load each (lane = sample), VU of them in flight per wave
+#ifndef FOT_CULL_VU
+#define FOT_CULL_VU 4
+#endif
+        constexpr int VU = FOT_CULL_VU;
+        const int n_ver = s_nver < CULL_VER ? s_nver : CULL_VER;
+        for (int v0 = wv; v0 < n_ver; v0 += VU * KG) {
+            Raw p[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int v = v0 + u * KG < n_ver ? v0 + u * KG : v0;
+                p[u] = tracks[(int64_t)((int)s_ver[v] - D.n_static) * D.T + (lane < D.T ? lane : D.T - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int v = v0 + u * KG;
+                if (v >= n_ver) break;
+                bool bad = (p[u].x != p[u].x) | (p[u].y != p[u].y);
+                for (int t = WAVE + lane; t < D.T; t += WAVE) {   // (more than 64 samples per track)
+                    const Raw q = tracks[(int64_t)((int)s_ver[v] - D.n_static) * D.T + t];
+                    bad |= (q.x != q.x) | (q.y != q.y);
+                }
+                if (__ballot(bad) != 0ull && lane == 0) {
+                    const int nb = atomicAdd(&s_nbad, 1);
+                    if (nb < CULL_BAD) s_bad[nb] = s_ver[v];
+                }
+            }
+        }
+        __syncthreads();
+    }
     // wave wv: everything else of time step k0 + wv
     if (wv >= nk) return;
     const int kk = wv, k = k0 + wv;
-    {   // exclusive prefix over the bins (lane = bin; entry CULL_BINS ends with the total); cursors = starts
-        const int c = lane < CULL_BINS ? s_cnt[kk][lane] : 0;
-        int incl = c;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const int t = __shfl_up(incl, off, WAVE);
-            if (lane >= off) incl += t;
-        }
-        if (lane <= CULL_BINS) { s_start[kk][lane] = incl - c; s_cnt[kk][lane] = incl - c; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // this wave's LDS writes (other lanes') before the reads below
-    __builtin_amdgcn_wave_barrier();
+    // lazy: did everything fit (the remembered obstacles of this step, the group's tracks, the NaN tracks among them)?
+    const bool listed = !lazy || (s_nin[kk] <= CULL_LIST && s_nver <= CULL_VER && s_nbad <= CULL_BAD);
     const Box32 bk = s_box[kk];
     const BinMap bmk = s_bm[kk];
     const float mk = s_margin[kk];
     const bool live_k = bk.x0 <= bk.x1;
-    const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
-    TileStep *rng = wave_rng + (int64_t)D.tile0 * P.n_total + k;                   // + tile * n_total
-    const int count = s_start[kk][CULL_BINS];
     const int row = k < D.T - 1 ? k : D.T - 1;
     auto point = [&](int i, d2 &o, int &sid) {                                      // obstacle i at step k
         sid = SID_STATIC;
@@ -1391,10 +1454,51 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
             sid = j / D.P;
         }
     };
+    if (lazy) {
+        // the histogram of this step, now that the NaN tracks are known: over the remembered obstacles, or -- something
+        // did not fit -- over the whole row again, every kept track looked through by its own lane
+        if (listed) {
+            const int n_bad = s_nbad;
+            for (int j = lane; j < s_nin[kk]; j += WAVE) {
+                const uint32_t e = s_list[kk][j];
+                bool bad = false;
+                for (int b = 0; b < n_bad; ++b) bad |= s_bad[b] == (e & CULL_IDX_MASK);
+                if (bad) s_list[kk][j] = CULL_DEAD;
+                else atomicAdd(&s_cnt[kk][e >> 20], 1);
+            }
+        } else {
+            for (int i0 = 0; i0 < total; i0 += WAVE) {
+                const int i = i0 + lane;
+                if (i >= total) continue;
+                d2 o; int sid;
+                point(i, o, sid);
+                const float fx = (float)(o.x - D.ego.x), fy = (float)(o.y - D.ego.y);
+                if (live_k && cull_inside(bk, mk, fx, fy) && !track_bad(i)) atomicAdd(&s_cnt[kk][bin_of(bmk, fx, fy)], 1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    {   // exclusive prefix over the bins (lane = bin; entry CULL_BINS ends with the total); cursors = starts
+        const int c = lane < CULL_BINS ? s_cnt[kk][lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int t = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += t;
+        }
+        if (lane <= CULL_BINS) { s_start[kk][lane] = incl - c; s_cnt[kk][lane] = incl - c; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // this wave's LDS writes (other lanes') before the reads below
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = D.ent_off + (int64_t)k * D.ent_cap;
+    TileStep *rng = wave_rng + (int64_t)D.tile0 * P.n_total + k;                   // + tile * n_total
+    const int count = s_start[kk][CULL_BINS];
     // pass 2: scatter into the list (order inside a bin is irrelevant)
-    if (count <= CULL_LIST) {                                    // straight from the remembered indices
-        for (int j = lane; j < ((ablate & 2) ? 0 : count); j += WAVE) {
+    if (lazy ? listed : count <= CULL_LIST) {                    // straight from the remembered indices
+        for (int j = lane; j < ((ablate & 2) ? 0 : (lazy ? s_nin[kk] : count)); j += WAVE) {
             const uint32_t e = s_list[kk][j];
+            if (e == CULL_DEAD) continue;
             const int i = (int)(e & CULL_IDX_MASK), bin = (int)(e >> 20);
             d2 o; int sid;
             point(i, o, sid);
@@ -1410,7 +1514,7 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
             d2 o; int sid;
             point(i, o, sid);
             const float fx = (float)(o.x - D.ego.x), fy = (float)(o.y - D.ego.y);
-            if (live_k && cull_inside(bk, mk, fx, fy) && !(i >= D.n_static && nan_flag[D.nan_off + (i - D.n_static)])) {
+            if (live_k && cull_inside(bk, mk, fx, fy) && !track_bad(i)) {
                 const int bin = bin_of(bmk, fx, fy);
                 const int pos = atomicAdd(&s_cnt[kk][bin], 1);
                 ent32_store(ent32, base + pos, fx, fy);
@@ -1810,7 +1914,8 @@ int launch_cull(const DevParams *P, const InstDesc *desc, const InstState *state
 {
     if (n_inst <= 0 || n_total <= 0) return 0;
     const unsigned grid = (unsigned)((int64_t)((n_inst + 7) / 8 * 8) * ((n_total + CULL_KG - 1) / CULL_KG));
-    static const int ablate = getenv("FOT_CULL_ABLATE") ? atoi(getenv("FOT_CULL_ABLATE")) : 0;   // timing diagnostics
+    static const int ablate_env = getenv("FOT_CULL_ABLATE") ? atoi(getenv("FOT_CULL_ABLATE")) : 0;   // timing diagnostics
+    const int ablate = (ablate_env & ~128) | (e.eager_nan ? 128 : 0);
     const int lds_knots = sp.n <= 64 ? sp.n : 0;                           // a short spline rides along in LDS
     // + per horizon / brake-ladder entry: lateral extents of the group's steps, the two extreme lateral quintics
     const size_t lds = sizeof(double) * (9 * (size_t)lds_knots + (size_t)n_ext * (CULL_KG * 2 + 9));

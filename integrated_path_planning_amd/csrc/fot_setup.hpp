@@ -293,6 +293,7 @@ struct BatchLayout {
     int64_t n_tracks = 0;         // pedestrian tracks (S * P per instance, rounded up to 16): one NaN flag each
     int64_t max_dyn_bytes = 0;    // largest dynamic tensor of one instance (sizes the NaN scan)
     bool any_obstacles = false;
+    bool any_tmajor = false;      // some instance's tensor is time-major (its NaN flags come from k_frenet_state's scan blocks)
 };
 
 inline int build_batch_layout(const fot_params &hp, const DevParams &P, const TileShapes &shapes, const fot_batch &b,
@@ -375,6 +376,7 @@ inline int build_batch_layout(const fot_params &hp, const DevParams &P, const Ti
                 if (S > FOT_MAX_SAMPLES) { err = "more prediction samples than FOT_MAX_SAMPLES"; return FOT_ERR_UNSUPPORTED; }
                 if (b.dyn_off[i] < 0) { err = "dyn_off < 0"; return FOT_ERR_INVALID; }
                 D.dyn_mode = mode; D.S = S; D.P = Pn; D.T = T;
+                if (D.dyn_tmajor) L.any_tmajor = true;
                 D.dyn_off = b.dyn_off[i];
                 const int64_t pts = (int64_t)S * Pn * T;
                 if (D.dyn_off + pts > L.dyn_src_points) L.dyn_src_points = D.dyn_off + pts;

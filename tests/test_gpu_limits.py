@@ -28,6 +28,18 @@ def _check(bp, params, sp, reqs):
     return res
 
 
+def _plan_resident(bp, pb):
+    """The records of fot_plan_batch_device on tensors that lie in HBM already."""
+    import torch
+    dev = torch.device("cuda", 0)
+    dyn = torch.from_numpy(pb.dyn_xy).to(dev)
+    out = torch.zeros(pb.n * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    bp.plan_packed_device(pb.with_device_obstacles(None, dyn.data_ptr()), out.data_ptr(),
+                          torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    return out.cpu().numpy().tobytes()
+
+
 def test_dense_static_crowd_many_chunk_passes():
     """3000 static points in the corridor: ~100 chunks per time step (more than one 32-chunk pass), every strip full."""
     kw = dict(dt=0.2, max_road_width=3.0, d_road_w=1.0, robot_radius=0.3, obstacle_radius=0.1, max_t=4.4)
@@ -56,6 +68,68 @@ def test_distribution_larger_than_cull_cache_with_budget():
     reqs = [PlanRequest(3.0, 0.0, 0.0, 5.0, 0.0, target_speed=6.0, dist=dist),
             PlanRequest(20.0, 0.5, 0.0, 7.0, -0.5, target_speed=8.0, dist=dist[:, ::3])]
     _check(bp, orc.make_params(**okw), orc.Spline(WX, WY), reqs)
+
+
+@pytest.mark.parametrize("S,P,n_block,n_extra,label", [(3, 30, 1, 0, "a few NaN tracks among the remembered ones"),
+                                                       (4, 40, 10, 5, "more NaN tracks than the group remembers"),
+                                                       (64, 80, 1, 0, "more tracks inside the boxes than the group lists"),
+                                                       (64, 80, 10, 300, "both, and more kept obstacles than a step remembers")])
+def test_nan_tracks_beyond_every_cache_of_the_lazy_check(S, P, n_block, n_extra, label):
+    """k_cull looks for NaNs itself in the caller's [S][P][T] layout -- only in the tracks its boxes touch, up to 256 of
+    them per group of steps, up to 32 NaN tracks remembered: every combination of what fits and what does not.  A crowd
+    along the left road edge fills the lists; a line of pedestrians ACROSS the lane holds the NaNs (every sample of them,
+    plus some of the crowd): with them the lane is free (frenet_planner.py:1211-1219: a track with a NaN anywhere is
+    no obstacle at any step), without the NaNs it is blocked.  Time-major layout (flags from the scan blocks): same bytes."""
+    from integrated_path_planning_amd.batch import PackedBatch
+    kw = dict(dt=0.2, max_road_width=2.0, d_road_w=1.0, robot_radius=0.8, obstacle_radius=0.2, max_t=4.4)
+    rng = np.random.default_rng(S * 100 + n_block)
+    T = 23
+    p0 = np.column_stack([rng.uniform(4, 40, P), rng.uniform(2.3, 3.0, P)])
+    p0[:n_block] = np.column_stack([rng.uniform(22, 26, n_block), np.linspace(-3.2, 1.0, n_block)])
+    vel = rng.normal(0, 0.05, (S, P, 1, 2))
+    clean = p0[None, :, None, :] + vel * (np.arange(T) * 0.2)[None, None, :, None]
+    dist = clean.copy()
+    bad = [s * P + p for s in range(S) for p in range(n_block)]
+    bad += list(rng.choice(np.setdiff1d(np.arange(S * P), bad), n_extra, replace=False))
+    for j in bad:
+        dist[j // P, j % P, rng.integers(0, T), rng.integers(0, 2)] = np.nan
+    bp = BatchPlanner(waypoints=(WX, WY), **kw)
+    reqs = [PlanRequest(2.0, 0.1, 0.0, 6.0, 0.0, target_speed=7.0, dist=dist),
+            PlanRequest(12.0, -0.3, 0.02, 4.0, 0.3, target_speed=5.0, dist=dist[:, ::2]),
+            PlanRequest(2.0, 0.1, 0.0, 6.0, 0.0, target_speed=7.0, dist=clean)]
+    res = _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
+    assert res.records[0].stats[_abi.ST_COLLISION] < res.records[2].stats[_abi.ST_COLLISION], label
+    for dtype in (np.float32, np.float64):
+        spt = bp.plan_packed(PackedBatch(reqs, dtype))
+        tsp = bp.plan_packed(PackedBatch(reqs, dtype, dyn_layout_tsp=True))
+        assert bytes(spt.records) == bytes(tsp.records), label
+        # HBM-resident tensors (fot_plan_batch_device): no staging pass, so k_cull finds the NaN tracks of [S][P][T] itself
+        for tsp_layout in (False, True):
+            got = _plan_resident(bp, PackedBatch(reqs, dtype, dyn_layout_tsp=tsp_layout))
+            assert got == bytes(spt.records)[: len(got)], f"{label} (resident, time-major {tsp_layout}, {dtype.__name__})"
+    bp.close()
+
+
+def test_nan_behind_the_64th_sample_of_a_track():
+    """121 samples per track: the wave-wide look through a track takes two loads, the NaN sits in the second."""
+    kw = dict(dt=0.05, max_road_width=2.0, d_road_w=1.0, robot_radius=0.8, obstacle_radius=0.2, min_t=5.0, max_t=6.0)
+    rng = np.random.default_rng(77)
+    S, P, T = 2, 12, 121
+    p0 = np.column_stack([rng.uniform(4, 30, P), rng.uniform(-2.5, 2.5, P)])
+    dist = p0[None, :, None, :] + rng.normal(0, 0.3, (S, P, 1, 2)) * (np.arange(T) * 0.05)[None, None, :, None]
+    for j in range(0, S * P, 2):
+        dist[j // P, j % P, rng.integers(64, T), 1] = np.nan
+    bp = BatchPlanner(waypoints=(WX, WY), **kw)
+    reqs = [PlanRequest(2.0, 0.0, 0.0, 5.0, 0.0, target_speed=6.0, dist=dist),
+            PlanRequest(2.0, 0.0, 0.0, 5.0, 0.0, target_speed=6.0, dyn=dist[1])]
+    _check(bp, orc.make_params(**kw), orc.Spline(WX, WY), reqs)
+    from integrated_path_planning_amd.batch import PackedBatch
+    for dtype in (np.float32, np.float64):
+        want = bytes(bp.plan_packed(PackedBatch(reqs, dtype)).records)
+        for tsp_layout in (False, True):
+            got = _plan_resident(bp, PackedBatch(reqs, dtype, dyn_layout_tsp=tsp_layout))
+            assert got == want[: len(got)], f"resident, time-major {tsp_layout}, {dtype.__name__}"
+    bp.close()
 
 
 @pytest.mark.parametrize("dt,max_t,n_samples", [(0.1, 6.3, 64), (0.1, 6.4, 65), (0.1, 12.7, 128), (0.1, 12.8, 129),
