@@ -110,6 +110,59 @@ def test_nan_tracks_beyond_every_cache_of_the_lazy_check(S, P, n_block, n_extra,
     bp.close()
 
 
+_NAN_CHILD = r"""
+import faulthandler, hashlib, sys
+faulthandler.dump_traceback_later(150, exit=True)
+import numpy as np, torch
+from integrated_path_planning_amd import _abi
+from integrated_path_planning_amd.batch import PackedBatch, PlanRequest
+from integrated_path_planning_amd.planner import BatchPlanner
+WX, WY = np.linspace(0.0, 120.0, 13), np.zeros(13)
+kw = dict(dt=0.2, max_road_width=2.0, d_road_w=1.0, robot_radius=0.8, obstacle_radius=0.2, max_t=4.4)
+rng = np.random.default_rng(410)
+S, P, T, n_block = 4, 40, 23, 10
+p0 = np.column_stack([rng.uniform(4, 40, P), rng.uniform(2.3, 3.0, P)])
+p0[:n_block] = np.column_stack([rng.uniform(22, 26, n_block), np.linspace(-3.2, 1.0, n_block)])
+dist = p0[None, :, None, :] + rng.normal(0, 0.05, (S, P, 1, 2)) * (np.arange(T) * 0.2)[None, None, :, None]
+for j in [s * P + p for s in range(S) for p in range(n_block)]:
+    dist[j // P, j % P, rng.integers(0, T), rng.integers(0, 2)] = np.nan
+with BatchPlanner(waypoints=(WX, WY), **kw) as bp:
+    reqs = [PlanRequest(2.0, 0.1, 0.0, 6.0, 0.0, target_speed=7.0, dist=dist),
+            PlanRequest(12.0, -0.3, 0.02, 4.0, 0.3, target_speed=5.0, dist=dist[:, ::2])]
+    dev = torch.device("cuda", 0)
+    h = hashlib.sha256()
+    for dtype in (np.float32, np.float64):
+        pb = PackedBatch(reqs, dtype)
+        dyn = torch.from_numpy(pb.dyn_xy).to(dev)
+        out = torch.zeros(pb.n * _abi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+        bp.plan_packed_device(pb.with_device_obstacles(None, dyn.data_ptr()), out.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        h.update(out.cpu().numpy().tobytes())
+print("RECORDS", h.hexdigest(), flush=True)
+"""
+
+
+def test_scan_blocks_for_every_layout_give_the_same_records():
+    """FOT_NAN_SCAN=eager (read once per process): k_frenet_state's scan blocks flag the NaN tracks of [S][P][T] tensors
+    too, as before round 4, and k_cull looks nothing up itself -- same records as the default, on HBM-resident tensors
+    with forty NaN tracks across the lane.  Two child processes, one per setting."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("lazy", "eager"):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("FOT_NAN_SCAN", None)
+        if mode == "eager":
+            env["FOT_NAN_SCAN"] = "eager"
+        r = subprocess.run([sys.executable, "-c", _NAN_CHILD], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, f"{mode}: {r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+        got[mode] = [l for l in r.stdout.splitlines() if l.startswith("RECORDS")][-1]
+    assert got["lazy"] == got["eager"]
+
+
 def test_nan_behind_the_64th_sample_of_a_track():
     """121 samples per track: the wave-wide look through a track takes two loads, the NaN sits in the second."""
     kw = dict(dt=0.05, max_road_width=2.0, d_road_w=1.0, robot_radius=0.8, obstacle_radius=0.2, min_t=5.0, max_t=6.0)
