@@ -152,7 +152,7 @@ typedef struct fot_batch {
      * instance i starts at point dyn_off[i]; dyn_dims[i] = {mode, S, P, T} (S = 1 for FOT_DYN_SINGLE).
      * Non-finite coordinates never hit, and a pedestrian whose track holds a NaN anywhere is no obstacle at ANY
      * time step, as in the reference (np.min / np.max in its box pre-filter, frenet_planner.py:1211-1219): the
-     * library scans the tensor for such tracks itself, whoever produced it. */
+     * library finds such tracks itself, whoever produced the tensor. */
     const void *dyn_xy;                  /* host | device */
     const int64_t *dyn_off;              /* [n_inst] host, or NULL (no dynamic obstacles) */
     const int32_t *dyn_dims;             /* [n_inst][4] host */
