@@ -1187,7 +1187,10 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
 // grown by the collision radius, ordered by bin along the longer side of the box (counting sort through LDS
 // atomics), FAR32-padded to chunk pairs.  Then, per tile of the instance (k_evaluate's unit of work), the chunk range
 // its own profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
-constexpr int CULL_KG = 8;              // time steps (= waves) of a group in k_cull; the fused small-batch kernel takes 4
+#ifndef FOT_CULL_KG
+#define FOT_CULL_KG 8
+#endif
+constexpr int CULL_KG = FOT_CULL_KG;    // time steps (= waves) of a group in k_cull; the fused small-batch kernel takes 4
 constexpr int CULL_LIST = 256;          // kept obstacles per time step remembered between the two passes
 constexpr int CULL_PBOX = 96;           // profiles per instance whose boxes are kept in LDS (more: recomputed)
 constexpr uint32_t CULL_IDX_MASK = 0xFFFFFu;   // obstacle index (< 2^20, fot_setup.hpp) | bin << 20
