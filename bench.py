@@ -28,7 +28,7 @@ Two timed legs of exactly K steps each (barrier + synchronize on both sides):
 the SERIAL leg (one plan call in flight) yields `serial`, `kernel_ms` and the
 `roofline` of the dominant kernel -- a launch has the GPU to itself there, so
 kernel_ms[dominant] <= serial.ms_per_step -- and the HEADLINE leg (`--overlap`
-plan calls in flight, default 3: how a server keeps batches in flight) yields
+plan calls in flight, default 4: how a server keeps batches in flight) yields
 `value` / `ms_per_step`.  `--overlap 1` runs the serial leg only.
 
 Prints ONE JSON line on rank 0 with the extra objects "roofline" (dominant
@@ -143,7 +143,7 @@ def parse_args():
     ap.add_argument("--instances-per-gpu", type=int, default=0,
                     help="0 = 256 at --gpus 1 (config 4), 512 at --gpus > 1 (config 5's shard)")
     ap.add_argument("--batches", type=int, default=8, help="distinct batches rotated through the timed loop")
-    ap.add_argument("--overlap", type=int, default=3,
+    ap.add_argument("--overlap", type=int, default=4,
                     help="plan calls in flight in the headline leg: consecutive steps alternate between this many "
                          "handles/streams (1 = strictly serial, one leg only)")
     ap.add_argument("--dyn-layout", choices=("spt", "tsp"), default="spt",

@@ -1187,10 +1187,14 @@ k_evaluate_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ 
 // grown by the collision radius, ordered by bin along the longer side of the box (counting sort through LDS
 // atomics), FAR32-padded to chunk pairs.  Then, per tile of the instance (k_evaluate's unit of work), the chunk range
 // its own profiles' boxes can reach (strip_range) -- the only thing k_evaluate reads per time step.
+// Groups of FOUR steps: 62.4 us solo against 61.4 with eight (the step-independent solves are repeated by twice as many
+// workgroups), but a 256-thread workgroup with 16 KB of LDS finds room beside the evaluation's workgroups where a
+// 512-thread one with 29 KB does not -- the step with four plan calls in flight is 1.5 % shorter (scripts/ab_kg.sh;
+// sixteen steps: 79 us, two: 77 us).
 #ifndef FOT_CULL_KG
-#define FOT_CULL_KG 8
+#define FOT_CULL_KG 4
 #endif
-constexpr int CULL_KG = FOT_CULL_KG;    // time steps (= waves) of a group in k_cull; the fused small-batch kernel takes 4
+constexpr int CULL_KG = FOT_CULL_KG;    // time steps (= waves) of a group in k_cull
 constexpr int CULL_LIST = 256;          // kept obstacles per time step remembered between the two passes
 constexpr int CULL_PBOX = 96;           // profiles per instance whose boxes are kept in LDS (more: recomputed)
 constexpr uint32_t CULL_IDX_MASK = 0xFFFFFu;   // obstacle index (< 2^20, fot_setup.hpp) | bin << 20
@@ -1259,8 +1263,8 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     const int total = D.n_static + n_dyn;
     const bool tmajor = D.dyn_tmajor != 0;                       // [T][S][P][2] instead of the caller's [S][P][T][2]
 
-    // Pass-1 lane roles.  Caller layout: lane = (obstacle slot, step) -- the 8 lanes of one obstacle read its 8
-    // consecutive samples, a contiguous 64-byte run of the [S][P][T][2] tensor, so a wave-wide load touches 8 such runs
+    // Pass-1 lane roles.  Caller layout: lane = (obstacle slot, step) -- the KG lanes of one obstacle read its KG
+    // consecutive samples, a contiguous run of the [S][P][T][2] tensor (32 bytes at KG = 4, float32), so a wave-wide load touches 64 / KG such runs
     // instead of 64 scattered cache lines; the group's 8 waves share the obstacles.  T-major layout: the obstacles of
     // one time row are contiguous, so wave w takes step k0 + w alone and its lanes read 64 consecutive obstacles.
     const int kl = tmajor ? wv : (lane & (KG - 1));          // this lane's step inside the group
@@ -1280,7 +1284,7 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     };
     // Boxes of the group's time steps over all longitudinal profiles of the instance.  The (step, horizon) lateral
     // extents and then the (step, profile) boxes are spread over ALL threads of the workgroup -- full waves of float64
-    // work instead of eight waves with a third of their lanes busy --, then wave wv merges the boxes of step k0 + wv.
+    // work instead of waves with a third of their lanes busy --, then wave wv merges the boxes of step k0 + wv.
     if (!(ablate & 8)) {
         for (int i = tid; i < nk * n_ext; i += KG * WAVE) {
             const int ks = i / n_ext, e = i - ks * n_ext;
@@ -1322,7 +1326,7 @@ cull_group(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, 
     // Which pedestrian tracks hold a NaN (NanScan, fot_kernels.h).  Time-major tensors: the flags k_frenet_state's scan
     // blocks left.  The caller's [S][P][T][2] layout: LAZILY, here -- only a track that lies inside some box of the group
     // can become an entry, its T samples are one contiguous run (408 bytes at T = 51: one wave-wide load) and the group's
-    // first pass has the 8 lanes of a track side by side, so the group collects the few dozen tracks its boxes touch
+    // first pass has the KG lanes of a track side by side, so the group collects the few dozen tracks its boxes touch
     // (s_ver), its waves share them out and look through them, and nobody reads the tensor a second time just to find
     // NaNs: the whole tensor crosses HBM once per plan call instead of twice.  (Every wave looking through its OWN
     // tracks right behind its gathers, one barrier less, was 8 us slower: the slowest wave sets the pace.)
@@ -1570,7 +1574,7 @@ k_cull(const DevParams *__restrict__ Pp, const InstDesc *__restrict__ desc, cons
     const SplineView sp = stage_spline(sp_hbm, lds_knots);      // every wave, before any of them leaves
     const int groups = (Pp->n_total + CULL_KG - 1) / CULL_KG;
     // workgroups go round-robin over the 8 XCDs: all groups of instance i run back to back on XCD i mod 8, so the
-    // 64-byte runs that neighbouring groups cut out of the same cache lines of the prediction tensor meet in one L2
+    // runs that neighbouring groups cut out of the same cache lines of the prediction tensor meet in one L2
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int inst = xcd + 8 * (seq / groups), k0 = (seq % groups) * CULL_KG;
     if (inst >= n_inst) return;

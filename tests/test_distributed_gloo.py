@@ -110,7 +110,7 @@ def _pipe_worker(rank, world, port, ret, depth=2):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("depth", [2, 3])
+@pytest.mark.parametrize("depth", [2, 3, 4])
 def test_pipelined_all_gather_world2(depth):
     """Multi-buffered asynchronous gather (what bench.py runs at N > 1, one buffer pair per plan call in flight: three
     by default): buffers rotate, nothing is overwritten early."""
