@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic (GPU box): the full step (four calls in flight) and the serial step of a build with extra flags against the
-# default build, alternating, on one box.     scripts/ab_flag.sh "-DFOT_FRENET_WAVES=4"
+# default build, alternating, on one box.     scripts/ab_flag.sh "-DFOT_CULL_KG=8"
 set -e
 cd "$(dirname "$0")/.."
 one() {
